@@ -1,0 +1,519 @@
+// ftmpc_capi.hip -- host side of the C-ABI declared in include/ftmpc.h.
+//
+// Owns the device workspace, converts the double-precision problem constants into the
+// kernel argument block and enqueues the two kernels of the path:
+//   ftmpc_linearize_kernel  (one lane per instance)      ftmpc_linearize.hip
+//   ftmpc_solve_f32_kernel  (one wavefront per instance)  ftmpc_solve.hip
+// There is deliberately NO CPU fallback: every entry point fails with FTMPC_ERR_NODEVICE /
+// FTMPC_ERR_HIP when the gfx950 device or the code object is unusable.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/ftmpc.h"
+#include "ftmpc_common.h"
+
+// single translation unit: the kernels are compiled together with their launcher
+#include "ftmpc_linearize.hip"
+#include "ftmpc_solve.hip"
+
+using ftmpc::DeviceConsts;
+using ftmpc::LinParams;
+using ftmpc::SolveParams;
+
+static thread_local std::string g_create_error;
+
+struct ftmpc_handle {
+    ftmpc_config cfg;
+    DeviceConsts dc;
+    int device = 0;
+    int num_cu = 0;
+    int nb_max = 0;  // ceil(N*NT/16)
+    std::string err;
+    hipStream_t stream = nullptr;  // internal stream of the host-buffer entry point
+    // workspace
+    int64_t cap_batch = 0;
+    void* rec = nullptr;
+    // device mirrors of host buffers
+    double *d_x0 = nullptr, *d_ub = nullptr, *d_stuck = nullptr, *d_xref = nullptr, *d_uref = nullptr;
+    double *d_warm = nullptr, *d_u0 = nullptr, *d_U = nullptr;
+    int32_t *d_status = nullptr, *d_iters = nullptr;
+    int64_t cap_xref = 0, cap_uref = 0;
+    // per-instantiation Hessian slots
+    float* hs8 = nullptr;
+    float* hs10 = nullptr;
+    int grid8 = 0, grid10 = 0;
+    // debug
+    float *d_dbgH = nullptr, *d_dbgv = nullptr;
+    // profiling
+    bool profiling = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+};
+
+namespace {
+
+int fail(ftmpc_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                          \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess)                                                                    \
+            return fail((h), FTMPC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+bool inv3(const double* M, double* out) {
+    const double a = M[0], b = M[1], c = M[2], d = M[3], e = M[4], f = M[5], g = M[6], h = M[7], i = M[8];
+    const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    if (!(std::fabs(det) > 1e-300)) return false;
+    const double s = 1.0 / det;
+    out[0] = (e * i - f * h) * s; out[1] = (c * h - b * i) * s; out[2] = (b * f - c * e) * s;
+    out[3] = (f * g - d * i) * s; out[4] = (a * i - c * g) * s; out[5] = (c * d - a * f) * s;
+    out[6] = (d * h - e * g) * s; out[7] = (b * g - a * h) * s; out[8] = (a * e - b * d) * s;
+    return true;
+}
+
+// lower Cholesky of a 9x9 PSD matrix (zero pivots give zero columns)
+bool chol9(const double* P, double* L) {
+    std::memset(L, 0, 81 * sizeof(double));
+    for (int j = 0; j < 9; ++j) {
+        double d = P[9 * j + j];
+        for (int k = 0; k < j; ++k) d -= L[9 * j + k] * L[9 * j + k];
+        if (d < -1e-9 * std::fabs(P[9 * j + j]) - 1e-300) return false;
+        const double l = d > 0 ? std::sqrt(d) : 0.0;
+        L[9 * j + j] = l;
+        for (int i = j + 1; i < 9; ++i) {
+            double s = P[9 * i + j];
+            for (int k = 0; k < j; ++k) s -= L[9 * i + k] * L[9 * j + k];
+            L[9 * i + j] = l > 0 ? s / l : 0.0;
+        }
+    }
+    return true;
+}
+
+int build_consts(const ftmpc_config& c, DeviceConsts& d, std::string& why) {
+    if (c.N < 1 || c.N > 64) { why = "N out of range 1..64"; return FTMPC_ERR_ARG; }
+    if (c.NT < 1 || c.NT > FTMPC_MAX_NT) { why = "NT out of range 1..16"; return FTMPC_ERR_ARG; }
+    if (!(c.dt > 0) || !(c.mass > 0)) { why = "dt and mass must be positive"; return FTMPC_ERR_ARG; }
+    if (!(c.rho > 0)) { why = "rho must be positive (strict convexity)"; return FTMPC_ERR_ARG; }
+    std::memset(&d, 0, sizeof(d));
+    d.N = c.N;
+    d.NT = c.NT;
+    d.max_iters = c.max_iters > 0 ? c.max_iters : 16;
+    d.dt = c.dt;
+    d.inv_mass = 1.0 / c.mass;
+    std::memcpy(d.J, c.J, sizeof(d.J));
+    if (!inv3(c.J, d.Jinv)) { why = "J is singular"; return FTMPC_ERR_ARG; }
+    std::memcpy(d.r, c.r, sizeof(d.r));
+    std::memcpy(d.fvirt, c.f_virt, sizeof(d.fvirt));
+    // ArT = -[r]x Jinv
+    const double* r = c.r;
+    const double S[9] = {0, -r[2], r[1], r[2], 0, -r[0], -r[1], r[0], 0};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += S[3 * i + k] * d.Jinv[3 * k + j];
+            d.ArT[3 * i + j] = -s;
+        }
+    for (int g = 0; g < 6; ++g)
+        for (int t = 0; t < c.NT; ++t) d.D[g * ftmpc::MAX_NT + t] = c.D[g * c.NT + t];
+    for (int i = 0; i < 9; ++i) {
+        if (!(c.Q[i] >= 0)) { why = "Q must be non-negative"; return FTMPC_ERR_ARG; }
+        d.Q[i] = c.Q[i];
+        d.sq2Q[i] = std::sqrt(2.0 * c.Q[i]);
+    }
+    for (int i = 0; i < 6; ++i) {
+        if (!(c.R[i] >= 0)) { why = "R must be non-negative"; return FTMPC_ERR_ARG; }
+        d.R[i] = c.R[i];
+    }
+    std::memcpy(d.P, c.P, sizeof(d.P));
+    double L[81];
+    if (!chol9(c.P, L)) { why = "P must be symmetric positive semi-definite"; return FTMPC_ERR_ARG; }
+    const double s2 = std::sqrt(2.0);
+    for (int i = 0; i < 9; ++i)
+        for (int j = 0; j < 9; ++j) d.LPt[9 * i + j] = s2 * L[9 * j + i];  // sqrt(2) L'
+    d.rho = c.rho;
+    d.mu_stop = c.mu_stop > 0 ? c.mu_stop : 1e-10;
+    return FTMPC_OK;
+}
+
+template <typename T>
+int grow(ftmpc_handle* h, T** p, int64_t count) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    if (count <= 0) return FTMPC_OK;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), (size_t)count * sizeof(T));
+    if (e != hipSuccess) return fail(h, FTMPC_ERR_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return FTMPC_OK;
+}
+
+int tiles_of(int nb) { return nb * (nb + 1) / 2; }
+
+int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, const double* stuck,
+            const double* xref, int64_t xref_stride, const double* uref, int64_t uref_stride,
+            const double* warmU, double* out_u0, double* out_U, int32_t* status, int32_t* iters,
+            hipStream_t s, int64_t dbg_inst) {
+    if (B <= 0) return FTMPC_OK;
+    LinParams lp;
+    lp.B = B;
+    lp.x0 = x0; lp.ub = ub; lp.stuck = stuck;
+    lp.xref = xref; lp.xref_stride = xref_stride;
+    lp.uref = uref; lp.uref_stride = uref_stride;
+    lp.warmU = warmU;
+    lp.rec = h->rec;
+    const int lin_blocks = (int)((B + 63) / 64);
+    if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[0], s));
+    hipLaunchKernelGGL(ftmpc::ftmpc_linearize_kernel<float>, dim3(lin_blocks), dim3(64), 0, s, h->dc, lp);
+    HIP_TRY(h, hipGetLastError());
+    if (h->profiling) {
+        HIP_TRY(h, hipEventRecord(h->ev[1], s));
+        HIP_TRY(h, hipEventRecord(h->ev[2], s));
+    }
+    SolveParams sp;
+    sp.B = B;
+    sp.rec = h->rec;
+    sp.ub = ub; sp.stuck = stuck; sp.warmU = warmU;
+    sp.out_u0 = out_u0; sp.out_U = out_U; sp.status = status; sp.iters = iters;
+    sp.dbg_inst = dbg_inst;
+    sp.dbg_H = h->d_dbgH;
+    sp.dbg_vec = h->d_dbgv;
+    // NB = 8 instantiation: instances with at most 128 active variables (and the empty ones)
+    {
+        sp.hscratch = h->hs8;
+        sp.tile_words = (int64_t)tiles_of(8) * 256;
+        sp.nb_lo = 0;
+        sp.nb_hi_owner = (h->nb_max <= 8) ? 1 : 0;
+        const int grid = (int)std::min<int64_t>(B, h->grid8);
+        hipLaunchKernelGGL(ftmpc::ftmpc_solve_f32_kernel<8>, dim3(grid), dim3(64), 0, s, h->dc, sp);
+        HIP_TRY(h, hipGetLastError());
+    }
+    if (h->nb_max > 8) {
+        sp.hscratch = h->hs10;
+        sp.tile_words = (int64_t)tiles_of(10) * 256;
+        sp.nb_lo = 8;
+        sp.nb_hi_owner = 1;
+        const int grid = (int)std::min<int64_t>(B, h->grid10);
+        hipLaunchKernelGGL(ftmpc::ftmpc_solve_f32_kernel<10>, dim3(grid), dim3(64), 0, s, h->dc, sp);
+        HIP_TRY(h, hipGetLastError());
+    }
+    if (h->profiling) {
+        HIP_TRY(h, hipEventRecord(h->ev[3], s));
+        h->ev_valid = true;
+    }
+    return FTMPC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t ftmpc_version(void) { return 100; }
+
+int ftmpc_default_config(ftmpc_config* cfg, int32_t N, int32_t NT) {
+    if (!cfg || N < 1 || N > 64 || NT < 1 || NT > FTMPC_MAX_NT) return FTMPC_ERR_ARG;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->N = N;
+    cfg->NT = NT;
+    cfg->dtype = FTMPC_DTYPE_F32;
+    cfg->max_iters = 16;
+    cfg->device_id = 0;
+    cfg->dt = 0.1;                                   // reactive.yaml:2
+    cfg->mass = 16.8;                                // sys_model.py:52
+    cfg->J[0] = 0.2; cfg->J[4] = 0.3; cfg->J[8] = 0.25;  // sys_model.py:53-57
+    const double Q[9] = {1, 1, 1, 1, 1, 1, 2, 2, 2};       // reactive.yaml:32
+    const double R[6] = {0.1, 0.1, 0.1, 0.01, 0.01, 0.01}; // reactive.yaml:33
+    std::memcpy(cfg->Q, Q, sizeof(Q));
+    std::memcpy(cfg->R, R, sizeof(R));
+    // quadratic part of config/terminal.yaml
+    const double pp = 19.574136382485836, pv = 28.1433488118291, vv = 98.382994426126402;
+    const double po[3] = {645.23036107820451, 645.43124119008723, 645.70261416462426};
+    for (int a = 0; a < 3; ++a) {
+        cfg->P[9 * a + a] = pp;
+        cfg->P[9 * a + 3 + a] = pv;
+        cfg->P[9 * (3 + a) + a] = pv;
+        cfg->P[9 * (3 + a) + 3 + a] = vv;
+        cfg->P[9 * (6 + a) + 6 + a] = po[a];
+    }
+    // spiral_parameters.py:33-39: omega_des = [0,0,.6], f_virt = 3.5 y, r = |f_virt|/(m |omega_des|^2) y
+    cfg->f_virt[1] = 3.5;
+    cfg->r[1] = 3.5 / (cfg->mass * 0.6 * 0.6);
+    cfg->rho = 0.05;
+    cfg->mu_stop = 1e-10;
+    if (NT == 16) {
+        // sys_model.py:73-123 restated from the thruster geometry
+        const double d1 = 0.12, d2 = 0.09, d3 = 0.05;
+        const double fx[8] = {-1, -1, 1, 1, -1, -1, 1, 1};
+        const double ty[8] = {-1, 1, 1, -1, -1, 1, 1, -1};
+        const double tz[8] = {1, 1, -1, -1, -1, -1, 1, 1};
+        for (int i = 0; i < 8; ++i) {
+            cfg->D[0 * 16 + i] = fx[i];
+            cfg->D[4 * 16 + i] = d3 * ty[i];
+            cfg->D[5 * 16 + i] = d1 * tz[i];
+        }
+        const double fy[4] = {-1, -1, 1, 1}, tzy[4] = {-1, 1, 1, -1};
+        const double fz[4] = {-1, 1, -1, 1}, txz[4] = {-1, 1, 1, -1};
+        for (int i = 0; i < 4; ++i) {
+            cfg->D[1 * 16 + 8 + i] = fy[i];
+            cfg->D[5 * 16 + 8 + i] = d2 * tzy[i];
+            cfg->D[2 * 16 + 12 + i] = fz[i];
+            cfg->D[3 * 16 + 12 + i] = d1 * txz[i];
+        }
+    }
+    return FTMPC_OK;
+}
+
+int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
+    if (!cfg || !out) return fail(nullptr, FTMPC_ERR_ARG, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, FTMPC_ERR_NODEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(nullptr, FTMPC_ERR_ARG, "device_id out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device_id) != hipSuccess)
+        return fail(nullptr, FTMPC_ERR_HIP, "hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, FTMPC_ERR_NODEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    if (cfg->dtype != FTMPC_DTYPE_F32)
+        return fail(nullptr, FTMPC_ERR_ARG, "only FTMPC_DTYPE_F32 is implemented in this build");
+    ftmpc_handle* h = new (std::nothrow) ftmpc_handle();
+    if (!h) return fail(nullptr, FTMPC_ERR_ALLOC, "out of host memory");
+    h->cfg = *cfg;
+    std::string why;
+    int rc = build_consts(*cfg, h->dc, why);
+    if (rc != FTMPC_OK) {
+        delete h;
+        return fail(nullptr, rc, why);
+    }
+    h->nb_max = (cfg->N * cfg->NT + 15) / 16;
+    if (h->nb_max > 10) {
+        delete h;
+        return fail(nullptr, FTMPC_ERR_ARG, "N*NT > 160 is not supported by the LDS-resident solve kernel in this build");
+    }
+    h->device = cfg->device_id;
+    h->num_cu = prop.multiProcessorCount;
+    if (hipSetDevice(h->device) != hipSuccess) {
+        delete h;
+        return fail(nullptr, FTMPC_ERR_HIP, "hipSetDevice failed");
+    }
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete h;
+        return fail(nullptr, FTMPC_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    for (int i = 0; i < 4; ++i) (void)hipEventCreate(&h->ev[i]);
+    // persistent grids: resident workgroups per CU from the occupancy query (LDS-bound)
+    int per8 = 0, per10 = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per8, ftmpc::ftmpc_solve_f32_kernel<8>, 64, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per10, ftmpc::ftmpc_solve_f32_kernel<10>, 64, 0);
+    if (per8 < 1) per8 = 1;
+    if (per10 < 1) per10 = 1;
+    h->grid8 = h->num_cu * per8;
+    h->grid10 = h->num_cu * per10;
+    if (grow(h, &h->hs8, (int64_t)h->grid8 * tiles_of(8) * 256) != FTMPC_OK ||
+        (h->nb_max > 8 && grow(h, &h->hs10, (int64_t)h->grid10 * tiles_of(10) * 256) != FTMPC_OK) ||
+        grow(h, &h->d_dbgH, 160 * 160) != FTMPC_OK || grow(h, &h->d_dbgv, 3 * 160 + 4) != FTMPC_OK) {
+        g_create_error = h->err;
+        ftmpc_destroy(h);
+        return FTMPC_ERR_ALLOC;
+    }
+    *out = h;
+    return FTMPC_OK;
+}
+
+int ftmpc_destroy(ftmpc_handle* h) {
+    if (!h) return FTMPC_OK;
+    (void)hipSetDevice(h->device);
+    void* ptrs[] = {h->rec, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, h->d_uref, h->d_warm, h->d_u0, h->d_U,
+                    h->d_status, h->d_iters, h->hs8, h->hs10, h->d_dbgH, h->d_dbgv};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (int i = 0; i < 4; ++i)
+        if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return FTMPC_OK;
+}
+
+const char* ftmpc_last_error(const ftmpc_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int ftmpc_reserve(ftmpc_handle* h, int64_t max_batch) {
+    if (!h || max_batch < 0) return FTMPC_ERR_ARG;
+    if (max_batch <= h->cap_batch) return FTMPC_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int N = h->cfg.N, NT = h->cfg.NT;
+    const int64_t B = max_batch;
+    float* recf = nullptr;
+    if (h->rec) (void)hipFree(h->rec);
+    h->rec = nullptr;
+    int rc = grow(h, &recf, B * N * ftmpc::REC_STRIDE);
+    if (rc != FTMPC_OK) return rc;
+    h->rec = recf;
+    if ((rc = grow(h, &h->d_x0, B * 13)) != FTMPC_OK) return rc;
+    if ((rc = grow(h, &h->d_ub, B * NT)) != FTMPC_OK) return rc;
+    if ((rc = grow(h, &h->d_stuck, B * NT)) != FTMPC_OK) return rc;
+    if ((rc = grow(h, &h->d_warm, B * N * NT)) != FTMPC_OK) return rc;
+    if ((rc = grow(h, &h->d_u0, B * NT)) != FTMPC_OK) return rc;
+    if ((rc = grow(h, &h->d_U, B * N * NT)) != FTMPC_OK) return rc;
+    if ((rc = grow(h, &h->d_status, B)) != FTMPC_OK) return rc;
+    if ((rc = grow(h, &h->d_iters, B)) != FTMPC_OK) return rc;
+    h->cap_batch = B;
+    return FTMPC_OK;
+}
+
+static int stage_refs(ftmpc_handle* h, int64_t B, const double* xref, int64_t xref_stride, const double* uref,
+                      int64_t uref_stride) {
+    const int N = h->cfg.N;
+    const int64_t nx = xref_stride == 0 ? 9 * (N + 1) : B * xref_stride;
+    if (nx > h->cap_xref) {
+        int rc = grow(h, &h->d_xref, nx);
+        if (rc != FTMPC_OK) return rc;
+        h->cap_xref = nx;
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->d_xref, xref, nx * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (uref) {
+        const int64_t nu = uref_stride == 0 ? 6 * (N + 1) : B * uref_stride;
+        if (nu > h->cap_uref) {
+            int rc = grow(h, &h->d_uref, nu);
+            if (rc != FTMPC_OK) return rc;
+            h->cap_uref = nu;
+        }
+        HIP_TRY(h, hipMemcpyAsync(h->d_uref, uref, nu * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    return FTMPC_OK;
+}
+
+static int check_strides(ftmpc_handle* h, int64_t xref_stride, int64_t uref_stride, const double* uref) {
+    const int N = h->cfg.N;
+    if (xref_stride != 0 && xref_stride < 9 * (N + 1)) return fail(h, FTMPC_ERR_ARG, "xref_stride must be 0 or >= 9*(N+1)");
+    if (uref && uref_stride != 0 && uref_stride < 6 * (N + 1)) return fail(h, FTMPC_ERR_ARG, "uref_stride must be 0 or >= 6*(N+1)");
+    return FTMPC_OK;
+}
+
+int ftmpc_solve_batch(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, const double* stuck,
+                      const double* xref, int64_t xref_stride, const double* uref, int64_t uref_stride,
+                      double* warmU, double* out_u0, double* out_U, int32_t* status, int32_t* iters) {
+    if (!h) return FTMPC_ERR_ARG;
+    if (B < 0 || !x0 || !ub || !stuck || !xref || !out_u0) return fail(h, FTMPC_ERR_ARG, "null buffer or negative batch");
+    if (B == 0) return FTMPC_OK;
+    int rc = check_strides(h, xref_stride, uref_stride, uref);
+    if (rc != FTMPC_OK) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if ((rc = ftmpc_reserve(h, B)) != FTMPC_OK) return rc;
+    const int N = h->cfg.N, NT = h->cfg.NT;
+    hipStream_t s = h->stream;
+    HIP_TRY(h, hipMemcpyAsync(h->d_x0, x0, B * 13 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_ub, ub, B * NT * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_stuck, stuck, B * NT * sizeof(double), hipMemcpyHostToDevice, s));
+    if ((rc = stage_refs(h, B, xref, xref_stride, uref, uref_stride)) != FTMPC_OK) return rc;
+    if (warmU) HIP_TRY(h, hipMemcpyAsync(h->d_warm, warmU, B * N * NT * sizeof(double), hipMemcpyHostToDevice, s));
+    const bool wantU = out_U != nullptr || warmU != nullptr;
+    rc = enqueue(h, B, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, xref_stride, uref ? h->d_uref : nullptr, uref_stride,
+                 warmU ? h->d_warm : nullptr, h->d_u0, wantU ? h->d_U : nullptr, h->d_status, h->d_iters, s, -1);
+    if (rc != FTMPC_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(out_u0, h->d_u0, B * NT * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (out_U) HIP_TRY(h, hipMemcpyAsync(out_U, h->d_U, B * N * NT * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (warmU) HIP_TRY(h, hipMemcpyAsync(warmU, h->d_U, B * N * NT * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (status) HIP_TRY(h, hipMemcpyAsync(status, h->d_status, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (iters) HIP_TRY(h, hipMemcpyAsync(iters, h->d_iters, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return FTMPC_OK;
+}
+
+int ftmpc_solve_batch_device(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, const double* stuck,
+                             const double* xref, int64_t xref_stride, const double* uref, int64_t uref_stride,
+                             const double* warmU, double* out_u0, double* out_U, int32_t* status, int32_t* iters,
+                             void* stream) {
+    if (!h) return FTMPC_ERR_ARG;
+    if (B < 0 || !x0 || !ub || !stuck || !xref || !out_u0) return fail(h, FTMPC_ERR_ARG, "null buffer or negative batch");
+    if (B == 0) return FTMPC_OK;
+    int rc = check_strides(h, xref_stride, uref_stride, uref);
+    if (rc != FTMPC_OK) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (B > h->cap_batch) {
+        // growing the workspace allocates: callers that time or graph-capture must ftmpc_reserve first
+        if ((rc = ftmpc_reserve(h, B)) != FTMPC_OK) return rc;
+    }
+    return enqueue(h, B, x0, ub, stuck, xref, xref_stride, uref, uref_stride, warmU, out_u0, out_U, status, iters,
+                   reinterpret_cast<hipStream_t>(stream), -1);
+}
+
+int ftmpc_shift_warm(int64_t B, int32_t N, int32_t NT, double* warmU) {
+    if (B < 0 || N < 1 || NT < 1 || !warmU) return FTMPC_ERR_ARG;
+    for (int64_t b = 0; b < B; ++b) {
+        double* w = warmU + b * (int64_t)N * NT;
+        std::memmove(w, w + NT, (size_t)(N - 1) * NT * sizeof(double));
+        std::memset(w + (size_t)(N - 1) * NT, 0, NT * sizeof(double));
+    }
+    return FTMPC_OK;
+}
+
+int ftmpc_set_profiling(ftmpc_handle* h, int32_t enabled) {
+    if (!h) return FTMPC_ERR_ARG;
+    h->profiling = enabled != 0;
+    h->ev_valid = false;
+    return FTMPC_OK;
+}
+
+int ftmpc_last_kernel_ms(ftmpc_handle* h, float ms[2]) {
+    if (!h || !ms) return FTMPC_ERR_ARG;
+    if (!h->ev_valid) return fail(h, FTMPC_ERR_ARG, "no profiled solve recorded");
+    HIP_TRY(h, hipEventSynchronize(h->ev[3]));
+    HIP_TRY(h, hipEventElapsedTime(&ms[0], h->ev[0], h->ev[1]));
+    HIP_TRY(h, hipEventElapsedTime(&ms[1], h->ev[2], h->ev[3]));
+    return FTMPC_OK;
+}
+
+const char* ftmpc_solve_kernel_name(const ftmpc_handle* h) {
+    if (!h) return "";
+    return h->nb_max > 8 ? "ftmpc_solve_f32_kernel<10>" : "ftmpc_solve_f32_kernel<8>";
+}
+
+int ftmpc_debug_build_qp(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, const double* stuck,
+                         const double* xref, int64_t xref_stride, const double* uref, int64_t uref_stride,
+                         const double* warmU, int64_t inst, double* H, int64_t H_cap, double* g, double* lo,
+                         double* hi, int32_t* n_out) {
+    if (!h || !H || !g || !lo || !hi || !n_out || inst < 0 || inst >= B) return FTMPC_ERR_ARG;
+    int rc = check_strides(h, xref_stride, uref_stride, uref);
+    if (rc != FTMPC_OK) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if ((rc = ftmpc_reserve(h, B)) != FTMPC_OK) return rc;
+    const int N = h->cfg.N, NT = h->cfg.NT;
+    hipStream_t s = h->stream;
+    HIP_TRY(h, hipMemcpyAsync(h->d_x0, x0, B * 13 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_ub, ub, B * NT * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_stuck, stuck, B * NT * sizeof(double), hipMemcpyHostToDevice, s));
+    if ((rc = stage_refs(h, B, xref, xref_stride, uref, uref_stride)) != FTMPC_OK) return rc;
+    if (warmU) HIP_TRY(h, hipMemcpyAsync(h->d_warm, warmU, B * N * NT * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemsetAsync(h->d_dbgv, 0, (3 * 160 + 4) * sizeof(float), s));
+    rc = enqueue(h, B, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, xref_stride, uref ? h->d_uref : nullptr, uref_stride,
+                 warmU ? h->d_warm : nullptr, h->d_u0, nullptr, h->d_status, h->d_iters, s, inst);
+    if (rc != FTMPC_OK) return rc;
+    std::vector<float> Hf(160 * 160), vf(3 * 160 + 4);
+    HIP_TRY(h, hipMemcpyAsync(Hf.data(), h->d_dbgH, Hf.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(vf.data(), h->d_dbgv, vf.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    const int n = (int)vf[480], npad = (int)vf[481];
+    if (n == 0) return fail(h, FTMPC_ERR_ARG, "instance has no active thruster or was not dumped");
+    if ((int64_t)n * n > H_cap) return fail(h, FTMPC_ERR_ARG, "H buffer too small");
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < n; ++j) H[(int64_t)i * n + j] = Hf[(size_t)i * npad + j];
+        g[i] = vf[i];
+        lo[i] = vf[npad + i];
+        hi[i] = vf[2 * npad + i];
+    }
+    *n_out = n;
+    return FTMPC_OK;
+}
+
+}  // extern "C"

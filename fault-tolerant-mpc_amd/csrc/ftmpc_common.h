@@ -1,0 +1,95 @@
+// ftmpc_common.h -- shared host/device definitions of the MI355X MPC QP-step path.
+//
+// Per-stage linearisation record written by the linearise kernel (one per instance and
+// stage, REC_STRIDE words) and consumed by the condense+IPM kernel.  The RK4 transition of
+// the orbit-centre model (reference: ft_mpc/models/spiral_model.py:44-76 discretised by
+// ft_mpc/models/sys_model.py:138-162) has the block structure
+//        p        v       w      q            F     tau
+//   p [  I      dt*I     Apw    Apq  ]     [ BpF   BpT ]
+//   v [  0       I       Avw    Avq  ]     [ BvF   BvT ]
+//   w [  0       0       Aww     0   ]     [  0    BwT ]
+//   q [  0       0       Aqw    Aqq  ]     [  0    BqT ]
+// (p enters nothing, v only p, the attitude chain (w,q) is autonomous), so only the named
+// blocks are stored.
+#pragma once
+#include <stdint.h>
+
+namespace ftmpc {
+
+enum : int {
+    REC_APW = 0,    // 3x3
+    REC_APQ = 9,    // 3x4
+    REC_AVW = 21,   // 3x3
+    REC_AVQ = 30,   // 3x4
+    REC_AWW = 42,   // 3x3
+    REC_AQW = 51,   // 4x3
+    REC_AQQ = 63,   // 4x4
+    REC_BPF = 79,   // 3x3
+    REC_BPT = 88,   // 3x3
+    REC_BVF = 97,   // 3x3
+    REC_BVT = 106,  // 3x3
+    REC_BWT = 115,  // 3x3
+    REC_BQT = 124,  // 4x3
+    REC_WE = 136,   // 9 : W (c_{k+1}[0:9] - xref_{k+1}),  W = diag(Q) or P (terminal)
+    REC_RUT = 145,  // 6 : R .* (gen_k - ur_k - [f_virt;0])
+    REC_USED = 151,
+    REC_STRIDE = 152
+};
+
+constexpr int MAX_NT = 16;
+
+// constants shared by both kernels (passed by value as kernel argument)
+struct DeviceConsts {
+    int N, NT;
+    int max_iters;
+    int pad0;
+    double dt, inv_mass;
+    double J[9], Jinv[9];
+    double ArT[9];          // -[r]x Jinv : d a_b / d tau
+    double r[3];
+    double fvirt[3];
+    double D[6 * MAX_NT];   // row-major 6 x NT (row stride MAX_NT)
+    double Q[9], R[6], P[81];
+    double LPt[81];         // sqrt(2) * chol(P)^T (upper triangular), row-major: E_N = LPt * G9
+    double sq2Q[9];         // sqrt(2 Q)
+    double rho;
+    double mu_stop;
+};
+
+struct LinParams {
+    int64_t B;
+    const double* x0;       // [B*13]
+    const double* ub;       // [B*NT]
+    const double* stuck;    // [B*NT]
+    const double* xref;     // 9 x (N+1) col-major, stride xref_stride per instance (0 shared)
+    int64_t xref_stride;
+    const double* uref;     // or nullptr
+    int64_t uref_stride;
+    const double* warmU;    // [B*N*NT] or nullptr
+    void* rec;              // [B*N*REC_STRIDE] float or double
+};
+
+struct SolveParams {
+    int64_t B;
+    const void* rec;        // [B*N*REC_STRIDE]
+    const double* ub;
+    const double* stuck;
+    const double* warmU;    // or nullptr
+    double* out_u0;         // [B*NT]
+    double* out_U;          // [B*N*NT] or nullptr
+    int32_t* status;        // or nullptr
+    int32_t* iters;         // or nullptr
+    float* hscratch;        // [gridDim.x * tile_words] per-workgroup Hessian slot
+    int64_t tile_words;     // words per slot
+    // instance routing between instantiations: this launch owns instances with
+    // nb_lo < ceil(N*na/16) <= NB; the launch with nb_hi_owner != 0 also reports shapes
+    // beyond every instantiation (status 2)
+    int32_t nb_lo;
+    int32_t nb_hi_owner;
+    // debug dump (test hook): instance dbg_inst writes its QP here; -1 = off
+    int64_t dbg_inst;
+    float* dbg_H;           // [npad*npad] row-major
+    float* dbg_vec;         // [484]: g | lo | hi at stride npad, [480] = n, [481] = npad
+};
+
+}  // namespace ftmpc

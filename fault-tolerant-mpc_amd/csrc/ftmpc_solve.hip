@@ -1,0 +1,713 @@
+// ftmpc_solve.hip -- kernel 2 of the MPC QP-step path: condensed-QP build + primal-dual IPM.
+//
+// ONE WAVEFRONT (64 lanes, one workgroup) PER QP INSTANCE, persistent over the batch
+// (instance = blockIdx.x, += gridDim.x).  For its instance the wave
+//   1. propagates the horizon-stacked input-to-state map  G_{k+1} = A_k G_k | B_k D_act
+//      one COLUMN PER LANE in registers (the stage records come from ftmpc_linearize.hip),
+//   2. contracts  H = sum_k E_k' E_k,  E_k = sqrt(2 W_k) G_k[0:9],  with fp32 MFMA
+//      (v_mfma_f32_16x16x4_f32) into register-resident 16x16 accumulator tiles,
+//   3. runs a Mehrotra predictor-corrector interior-point method on
+//         min 1/2 d'H d + g'd,  lo <= d <= hi      (d = U - Ubar, active thrusters only)
+//      whose KKT matrix H + Sigma is factorised by a left-looking 16x16-blocked Cholesky in
+//      LDS (SYRK/GEMM/TRSM tile updates on MFMA, diagonal tiles factorised and inverted in
+//      registers with v_readlane broadcasts), solved with the stored diagonal inverses,
+//      and whose gradient H d + g is re-evaluated every iteration with float64 accumulation.
+// The algorithm is the one restated in oracle/qp_oracle.py (ipm_box); the reference solves
+// the corresponding NLP with CasADi/IPOPT (ft_mpc/controllers/spiraling_mpc.py:87-238,319-354)
+// followed by a cvxpy min-norm allocation (controllers/tools/control_allocator.py:65-94).
+//
+// LDS per wave (NB = max tiles per dimension): NB(NB+1)/2 tiles x 1 KiB + ~3 KiB
+//   NB=8  (n<=128): 39.9 KiB -> 4 waves/CU (one per SIMD)
+//   NB=10 (n<=160): 59.4 KiB -> 2 waves/CU
+// H is kept in a per-workgroup global slot (L2/MALL resident) and re-staged into LDS once per
+// IPM iteration because the factorisation overwrites it in place.
+#include <hip/hip_runtime.h>
+
+#include "ftmpc_common.h"
+
+namespace ftmpc {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- tile addressing -------------------------------------------------------------------
+// A 16x16 tile is stored row-major with its 16-B chunks permuted so that the MFMA operand
+// read (lane (r = lane&15, q = lane>>4) needs columns {q, 4+q, 8+q, 12+q} of row r) is ONE
+// conflict-free ds_read_b128:  word(r, c) = 16 r + 4 ((c&3) ^ g4[r>>2]) + (c>>2).
+// chunk swizzle table {0,2,3,1} by row quad, packed in 2-bit fields (0 | 2<<2 | 3<<4 | 1<<6 = 0x78):
+// makes the four 16-lane service groups of ds_read_b128 hit 16 distinct 4-bank slots.
+__device__ __forceinline__ int swz(int rq) { return (0x78 >> (2 * rq)) & 3; }
+__device__ __forceinline__ int toff(int r, int c) { return 16 * r + 4 * ((c & 3) ^ swz(r >> 2)) + (c >> 2); }
+__device__ __forceinline__ int chunk_off(int r, int ch) { return 16 * r + 4 * (ch ^ swz(r >> 2)); }
+__device__ __forceinline__ int tidx(int I, int J) { return (I * (I + 1)) / 2 + J; }
+// position of element c of a 16-block inside the permuted LDS vectors (matches chunk reads)
+__device__ __forceinline__ int vpos(int c) { return (c & 3) * 4 + (c >> 2); }
+
+__device__ __forceinline__ float readlane_f(float x, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+}
+__device__ __forceinline__ float wave_sum(float x) {
+    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+    return x;
+}
+__device__ __forceinline__ float wave_min(float x) {
+    for (int m = 32; m >= 1; m >>= 1) x = fminf(x, __shfl_xor(x, m, 64));
+    return x;
+}
+__device__ __forceinline__ float wave_max(float x) {
+    for (int m = 32; m >= 1; m >>= 1) x = fmaxf(x, __shfl_xor(x, m, 64));
+    return x;
+}
+__device__ __forceinline__ float quad_sum(float x) {  // sum over the 4 lanes sharing lane&15
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    return x;
+}
+__device__ __forceinline__ double quad_sum_d(double x) {
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    return x;
+}
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+template <int NB>
+struct Shape {
+    static constexpr int NPAD = 16 * NB;
+    static constexpr int NV = (NPAD + 63) / 64;
+    static constexpr int NTILES = NB * (NB + 1) / 2;
+    static constexpr int ESTR = (NPAD % 32 == 16) ? NPAD : NPAD + 16;  // ebuf row stride
+    static constexpr int WORK = (2 * NPAD > 288) ? 2 * NPAD : 288;     // dvp|xvp, aliased by the potrf scratch
+};
+
+// ---- 16x16 Cholesky + inverse of the diagonal tile, in registers --------------------------
+// Lane l works on row (l&15) of the symmetric tile staged row-major (stride 17) in S; the four
+// 16-lane groups do identical work.  On return w[i] = (L^-1)[i][l&15] (column l&15 of the
+// inverse).  Returns false if a pivot is not positive.
+__device__ __forceinline__ bool potrf_inv16(const float* S, int li, float w[16]) {
+    float a[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = S[li * 17 + k];
+    float invs[16];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float djj = readlane_f(a[j], j);
+        ok = ok && (djj > 0.0f);
+        const float inv = 1.0f / sqrtf(djj);
+        invs[j] = inv;
+        a[j] *= inv;
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) a[k] -= a[j] * readlane_f(a[j], k);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float s = (i == li) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= readlane_f(a[k], i) * w[k];
+        w[i] = s * invs[i];
+    }
+    return ok;
+}
+
+// ---- blocked Cholesky of the nb x nb tile matrix in LDS (lower, in place) -----------------
+// After return: off-diagonal tiles hold L_IJ, diagonal tiles hold W_J = L_JJ^-1.
+template <int NB>
+__device__ __forceinline__ bool chol_tiles(float* tiles, float* S, int nb, int lane) {
+    const int li = lane & 15, lq = lane >> 4;
+    const int opoff = chunk_off(li, lq);
+    bool ok = true;
+    for (int J = 0; J < nb; ++J) {
+        // B operands of block row J (tiles (J,K), K<J)
+        f32x4 bJ[NB - 1];
+#pragma unroll
+        for (int K = 0; K < NB - 1; ++K)
+            if (K < J) bJ[K] = lds4(tiles + tidx(J, K) * 256 + opoff);
+        for (int I = J; I < nb; ++I) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float* rowI = tiles + tidx(I, 0) * 256;
+#pragma unroll
+            for (int K = 0; K < NB - 1; ++K)
+                if (K < J) {
+                    const f32x4 a4 = lds4(rowI + K * 256 + opoff);
+                    acc = mfma4(a4.x, bJ[K].x, acc);
+                    acc = mfma4(a4.y, bJ[K].y, acc);
+                    acc = mfma4(a4.z, bJ[K].z, acc);
+                    acc = mfma4(a4.w, bJ[K].w, acc);
+                }
+            float* tij = tiles + tidx(I, J) * 256;
+            float c[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) c[rr] = tij[toff(4 * lq + rr, li)] - acc[rr];
+            if (I == J) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) S[(4 * lq + rr) * 17 + li] = c[rr];
+                __syncthreads();
+                float w[16];
+                ok = potrf_inv16(S, li, w) && ok;
+                if (lq == 0) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) tij[toff(i, li)] = w[i];
+                }
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) tij[toff(4 * lq + rr, li)] = c[rr];
+            }
+        }
+        __syncthreads();
+        // TRSM: L_IJ = C_IJ W_J'   (X[i][j] = sum_k C[i][k] W[j][k])
+        const f32x4 w4 = lds4(tiles + tidx(J, J) * 256 + opoff);
+        for (int I = J + 1; I < nb; ++I) {
+            float* tij = tiles + tidx(I, J) * 256;
+            const f32x4 a4 = lds4(tij + opoff);
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+            x = mfma4(a4.x, w4.x, x);
+            x = mfma4(a4.y, w4.y, x);
+            x = mfma4(a4.z, w4.z, x);
+            x = mfma4(a4.w, w4.w, x);
+            __syncthreads();  // every lane has read C_IJ before anyone overwrites it
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) tij[toff(4 * lq + rr, li)] = x[rr];
+        }
+        __syncthreads();
+    }
+    return ok;
+}
+
+// ---- solve (L L') x = b with the factor of chol_tiles; b/x live in the permuted LDS vector --
+__device__ __forceinline__ void solve_tiles(const float* tiles, float* xvp, int nb, int lane) {
+    const int li = lane & 15, lq = lane >> 4;
+    const int opoff = chunk_off(li, lq);
+    const int myp = vpos(li);
+    // forward  L y = b
+    for (int J = 0; J < nb; ++J) {
+        float part = 0.f;
+        const float* rowJ = tiles + tidx(J, 0) * 256;
+        for (int K = 0; K < J; ++K) {
+            const f32x4 t4 = lds4(rowJ + K * 256 + opoff);
+            const f32x4 y4 = lds4(xvp + 16 * K + 4 * lq);
+            part += t4.x * y4.x + t4.y * y4.y + t4.z * y4.z + t4.w * y4.w;
+        }
+        part = quad_sum(part);
+        const float r = xvp[16 * J + myp] - part;
+        const f32x4 w4 = lds4(rowJ + J * 256 + opoff);
+        float y = w4.x * __shfl(r, lq, 64) + w4.y * __shfl(r, 4 + lq, 64) + w4.z * __shfl(r, 8 + lq, 64) +
+                  w4.w * __shfl(r, 12 + lq, 64);
+        y = quad_sum(y);
+        __syncthreads();
+        if (lq == 0) xvp[16 * J + myp] = y;
+        __syncthreads();
+    }
+    // backward  L' x = y
+    for (int J = nb - 1; J >= 0; --J) {
+        float part = 0.f;
+        for (int I = J + 1; I < nb; ++I) {
+            const float* t = tiles + tidx(I, J) * 256;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) part += t[toff(4 * lq + rr, li)] * xvp[16 * I + rr * 4 + lq];
+        }
+        part = quad_sum(part);
+        const float r = xvp[16 * J + myp] - part;
+        const float* t = tiles + tidx(J, J) * 256;
+        float x = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) x += t[toff(4 * lq + rr, li)] * __shfl(r, 4 * lq + rr, 64);
+        x = quad_sum(x);
+        __syncthreads();
+        if (lq == 0) xvp[16 * J + myp] = x;
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+template <int NB>
+__global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceConsts C, const SolveParams P) {
+    using SH = Shape<NB>;
+    constexpr int NPAD = SH::NPAD, NV = SH::NV, NTILES = SH::NTILES, ESTR = SH::ESTR;
+    __shared__ __attribute__((aligned(16))) float tiles[NTILES * 256];
+    __shared__ __attribute__((aligned(16))) float recbuf[2 * REC_STRIDE];
+    __shared__ __attribute__((aligned(16))) float work[SH::WORK];
+    __shared__ __attribute__((aligned(16))) float s_Da[6 * MAX_NT];
+    __shared__ unsigned char s_stg[NPAD], s_thr[NPAD];
+    __shared__ int s_act[MAX_NT];
+    float* const ebuf = tiles;       // build phase only
+    float* const dvp = work;         // d, permuted layout (gradient mat-vec)
+    float* const xvp = work + NPAD;  // rhs / solution of the KKT solves
+    float* const S = work;           // potrf scratch (dvp/xvp are dead while factorising)
+
+    const int lane = threadIdx.x;
+    const int li = lane & 15, lq = lane >> 4;
+    const int N = C.N, NT = C.NT;
+    const float rho = (float)C.rho;
+    const float mu_stop = (float)C.mu_stop;
+    float Rf[6];
+#pragma unroll
+    for (int g = 0; g < 6; ++g) Rf[g] = (float)C.R[g];
+
+    for (int64_t inst = blockIdx.x; inst < P.B; inst += gridDim.x) {
+        __syncthreads();
+        // ---------------- prologue: active thrusters, index tables ----------------
+        double ub_l = 0.0;
+        if (lane < NT) ub_l = P.ub[inst * NT + lane];
+        const unsigned long long amask = __ballot(lane < NT && ub_l > 0.0);
+        const int na = __popcll(amask);
+        const int n = N * na;
+        const int nb = (n + 15) >> 4;
+        const int npad = nb * 16;
+        if (nb <= P.nb_lo && !(na == 0 && P.nb_lo == 0)) continue;  // another instantiation's instance
+        if (nb > NB && P.nb_hi_owner == 0) continue;
+        if (na == 0 || nb > NB) {  // nothing to optimise / shape not supported by any instantiation
+            if (lane < NT) P.out_u0[inst * NT + lane] = 0.0;
+            if (P.out_U)
+                for (int i = lane; i < N * NT; i += 64) P.out_U[inst * N * NT + i] = 0.0;
+            if (lane == 0) {
+                if (P.status) P.status[inst] = (na == 0) ? 0 : 2;
+                if (P.iters) P.iters[inst] = 0;
+            }
+            continue;
+        }
+        const int myrank = __popcll(amask & ((1ull << lane) - 1ull));
+        if (lane < NT && ub_l > 0.0) s_act[myrank] = lane;
+        __syncthreads();
+        if (lane < na) {
+#pragma unroll
+            for (int g = 0; g < 6; ++g) s_Da[g * MAX_NT + lane] = (float)C.D[g * MAX_NT + s_act[lane]];
+        }
+        for (int e = lane; e < npad; e += 64) {
+            const int s = e / na;
+            s_stg[e] = (unsigned char)(e < n ? s : 255);
+            s_thr[e] = (unsigned char)(e < n ? e - s * na : 255);
+        }
+        // zero rows 9..11 of the E buffer (K padding of the MFMA contraction)
+        for (int i = lane; i < 3 * ESTR; i += 64) ebuf[9 * ESTR + i] = 0.f;
+        const float* recg = reinterpret_cast<const float*>(P.rec) + inst * (int64_t)N * REC_STRIDE;
+        f32x4 pre = {0.f, 0.f, 0.f, 0.f};
+        if (lane < REC_STRIDE / 4) pre = *reinterpret_cast<const f32x4*>(recg + 4 * lane);
+        __syncthreads();
+
+        // per-lane column bookkeeping: column e = v*64 + lane
+        int kcol[NV], acol[NV];
+        float ubar[NV], ubv[NV], gacc[NV];
+        float G[13][NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int e = v * 64 + lane;
+            kcol[v] = (e < npad) ? s_stg[e] : 255;
+            acol[v] = (e < npad) ? s_thr[e] : 255;
+            ubar[v] = 0.f;
+            ubv[v] = 1.f;
+            gacc[v] = 0.f;
+            if (kcol[v] != 255) {
+                const int t = s_act[acol[v]];
+                ubv[v] = (float)P.ub[inst * NT + t];
+                if (P.warmU) {
+                    const float wv = (float)P.warmU[(inst * N + kcol[v]) * NT + t];
+                    ubar[v] = fminf(fmaxf(wv, 0.f), ubv[v]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 13; ++r) G[r][v] = 0.f;
+        }
+        f32x4 acc[NTILES];
+#pragma unroll
+        for (int t = 0; t < NTILES; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        // ---------------- build: stage loop ----------------
+        for (int k = 0; k < N; ++k) {
+            float* rb = recbuf + (k & 1) * REC_STRIDE;
+            if (lane < REC_STRIDE / 4) *reinterpret_cast<f32x4*>(rb + 4 * lane) = pre;
+            if (k + 1 < N && lane < REC_STRIDE / 4)
+                pre = *reinterpret_cast<const f32x4*>(recg + (k + 1) * REC_STRIDE + 4 * lane);
+            __syncthreads();
+            const bool terminal = (k + 1 == N);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                if (kcol[v] < k) {
+                    // G <- A_k G  (block-structured, see ftmpc_common.h)
+                    float p[3], vv[3], w[3], q[4];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        p[a] = G[a][v] + (float)C.dt * G[3 + a][v];
+                        vv[a] = G[3 + a][v];
+                        w[a] = 0.f;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            p[a] += rb[REC_APW + 3 * a + c] * G[6 + c][v];
+                            vv[a] += rb[REC_AVW + 3 * a + c] * G[6 + c][v];
+                            w[a] += rb[REC_AWW + 3 * a + c] * G[6 + c][v];
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            p[a] += rb[REC_APQ + 4 * a + c] * G[9 + c][v];
+                            vv[a] += rb[REC_AVQ + 4 * a + c] * G[9 + c][v];
+                        }
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        q[a] = 0.f;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) q[a] += rb[REC_AQW + 3 * a + c] * G[6 + c][v];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) q[a] += rb[REC_AQQ + 4 * a + c] * G[9 + c][v];
+                    }
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        G[a][v] = p[a];
+                        G[3 + a][v] = vv[a];
+                        G[6 + a][v] = w[a];
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) G[9 + a][v] = q[a];
+                } else if (kcol[v] == k) {
+                    // new column: B_k D_act[:, a]
+                    float F[3], T[3];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        F[a] = s_Da[a * MAX_NT + acol[v]];
+                        T[a] = s_Da[(3 + a) * MAX_NT + acol[v]];
+                    }
+                    float gr = 0.f;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) gr += F[a] * rb[REC_RUT + a] + T[a] * rb[REC_RUT + 3 + a];
+                    gacc[v] += gr;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        float sp = 0.f, sv = 0.f, sw = 0.f;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            sp += rb[REC_BPF + 3 * a + c] * F[c] + rb[REC_BPT + 3 * a + c] * T[c];
+                            sv += rb[REC_BVF + 3 * a + c] * F[c] + rb[REC_BVT + 3 * a + c] * T[c];
+                            sw += rb[REC_BWT + 3 * a + c] * T[c];
+                        }
+                        G[a][v] = sp;
+                        G[3 + a][v] = sv;
+                        G[6 + a][v] = sw;
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        float sq = 0.f;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) sq += rb[REC_BQT + 3 * a + c] * T[c];
+                        G[9 + a][v] = sq;
+                    }
+                }
+                // gradient:  G9' (W e)
+                float gs = 0.f;
+#pragma unroll
+                for (int r = 0; r < 9; ++r) gs += G[r][v] * rb[REC_WE + r];
+                gacc[v] += gs;
+                // E = sqrt(2 W) G9  -> LDS
+                const int e = v * 64 + lane;
+                if (e < npad) {
+                    if (!terminal) {
+#pragma unroll
+                        for (int r = 0; r < 9; ++r) ebuf[r * ESTR + e] = (float)C.sq2Q[r] * G[r][v];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 9; ++r) {
+                            float s = 0.f;
+#pragma unroll
+                            for (int c = r; c < 9; ++c) s += (float)C.LPt[9 * r + c] * G[c][v];
+                            ebuf[r * ESTR + e] = s;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // MFMA contraction: acc(I,J) += E_I' E_J over the 12 (9 used) rows
+            const int Imax = ((k + 1) * na - 1) >> 4;
+            float op[NB][3];
+#pragma unroll
+            for (int X = 0; X < NB; ++X)
+                if (X <= Imax) {
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) op[X][s] = ebuf[(4 * s + lq) * ESTR + 16 * X + li];
+                }
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+                if (I <= Imax) {
+#pragma unroll
+                    for (int J = 0; J <= I; ++J) {
+#pragma unroll
+                        for (int s = 0; s < 3; ++s) acc[(I * (I + 1)) / 2 + J] = mfma4(op[I][s], op[J][s], acc[(I * (I + 1)) / 2 + J]);
+                    }
+                }
+            __syncthreads();
+        }
+
+        // ---------------- finalise H: + 2 (Da' R Da + rho I) per stage block, unit pad diagonal ----
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+            if (I < nb) {
+#pragma unroll
+                for (int dJ = 0; dJ < 2; ++dJ) {
+                    const int J = I - 1 + dJ;
+                    if (J < 0) continue;
+                    const int e2 = 16 * J + li;
+                    const int s2 = s_stg[e2], a2 = s_thr[e2];
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int e1 = 16 * I + 4 * lq + rr;
+                        const int s1 = s_stg[e1], a1 = s_thr[e1];
+                        float add = 0.f;
+                        if (s1 != 255 && s1 == s2) {
+#pragma unroll
+                            for (int g = 0; g < 6; ++g) add += s_Da[g * MAX_NT + a1] * Rf[g] * s_Da[g * MAX_NT + a2];
+                            if (a1 == a2) add += rho;
+                            add *= 2.f;
+                        }
+                        if (s1 == 255 && e1 == e2) add = 1.f;
+                        acc[(I * (I + 1)) / 2 + J][rr] += add;
+                    }
+                }
+            }
+        // H -> LDS tiles (operand layout), then -> this workgroup's global slot
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+            if (I < nb) {
+#pragma unroll
+                for (int J = 0; J <= I; ++J) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) tiles[((I * (I + 1)) / 2 + J) * 256 + toff(4 * lq + rr, li)] = acc[(I * (I + 1)) / 2 + J][rr];
+                }
+            }
+        __syncthreads();
+        const int ntl = (nb * (nb + 1)) / 2;
+        float* hslot = P.hscratch + (int64_t)blockIdx.x * P.tile_words;
+        for (int i = lane; i < ntl * 64; i += 64) *reinterpret_cast<f32x4*>(hslot + 4 * i) = lds4(tiles + 4 * i);
+
+        // g, bounds, start point
+        float gv[NV], lo[NV], hi[NV], sl[NV], su[NV], zl[NV], zu[NV], grad[NV];
+        bool valid[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            valid[v] = kcol[v] != 255;
+            gv[v] = valid[v] ? 2.f * (gacc[v] + rho * ubar[v]) : 0.f;
+            lo[v] = -ubar[v];
+            hi[v] = ubv[v] - ubar[v];
+            sl[v] = su[v] = 0.5f * ubv[v];
+        }
+        if (P.dbg_inst == inst) {  // test hook: dump the QP this wave is about to solve
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+                if (I < nb) {
+#pragma unroll
+                    for (int J = 0; J <= I; ++J) {
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const int e1 = 16 * I + 4 * lq + rr, e2 = 16 * J + li;
+                            const float h = acc[(I * (I + 1)) / 2 + J][rr];
+                            if (I != J || e1 >= e2) {
+                                P.dbg_H[(int64_t)e1 * npad + e2] = h;
+                                P.dbg_H[(int64_t)e2 * npad + e1] = h;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int e = v * 64 + lane;
+                if (e < npad) {
+                    P.dbg_vec[e] = gv[v];
+                    P.dbg_vec[npad + e] = lo[v];
+                    P.dbg_vec[2 * npad + e] = hi[v];
+                }
+            }
+            if (lane == 0) {
+                P.dbg_vec[480] = (float)n;
+                P.dbg_vec[481] = (float)npad;
+            }
+        }
+
+        // ---------------- interior-point iterations ----------------
+        int status = 1, nit = 0;
+        bool first = true;
+        const float inv2n = 1.0f / (float)(2 * n);
+        for (int it = 0; it <= C.max_iters; ++it) {
+            // d (permuted) -> LDS, gradient  H d + g  with float64 accumulation
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int e = v * 64 + lane;
+                if (e < npad) dvp[16 * (e >> 4) + vpos(e & 15)] = valid[v] ? ((sl[v] < su[v]) ? lo[v] + sl[v] : hi[v] - su[v]) : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+                if (I < nb) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int J = 0; J < NB; ++J)
+                        if (J < nb) {
+                            if (J <= I) {
+                                const f32x4 t4 = lds4(tiles + ((I * (I + 1)) / 2 + J) * 256 + chunk_off(li, lq));
+                                const f32x4 d4 = lds4(dvp + 16 * J + 4 * lq);
+                                a += (double)t4.x * (double)d4.x + (double)t4.y * (double)d4.y + (double)t4.z * (double)d4.z + (double)t4.w * (double)d4.w;
+                            } else {
+                                const float* t = tiles + ((J * (J + 1)) / 2 + I) * 256;
+#pragma unroll
+                                for (int rr = 0; rr < 4; ++rr) a += (double)t[toff(4 * lq + rr, li)] * (double)dvp[16 * J + rr * 4 + lq];
+                            }
+                        }
+                    a = quad_sum_d(a);
+                    if (lq == (I & 3)) grad[I >> 2] = valid[I >> 2] ? (float)(a + (double)gv[I >> 2]) : 0.f;
+                }
+            // complementarity
+            float t = 0.f;
+            if (first) {
+                float gm = 0.f, wm = 0.f;
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+                    if (valid[v]) {
+                        gm = fmaxf(gm, fabsf(grad[v]));
+                        wm = fmaxf(wm, ubv[v]);
+                    }
+                gm = wave_max(gm);
+                wm = wave_max(wm);
+                const float mu0 = fmaxf(0.25f * gm * wm, 1e-3f);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    zl[v] = valid[v] ? mu0 / sl[v] : 0.f;
+                    zu[v] = valid[v] ? mu0 / su[v] : 0.f;
+                }
+                first = false;
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                if (valid[v]) t += sl[v] * zl[v] + su[v] * zu[v];
+            const float mu = wave_sum(t) * inv2n;
+            if (__builtin_amdgcn_readfirstlane(!(mu >= mu_stop))) {
+                status = (mu == mu) ? 0 : 2;
+                break;
+            }
+            if (it == C.max_iters) break;
+            ++nit;
+            // KKT matrix: H + Sigma on the diagonal
+            float Sig[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                Sig[v] = valid[v] ? zl[v] / sl[v] + zu[v] / su[v] : 0.f;
+                const int e = v * 64 + lane;
+                if (e < npad) {
+                    const int I = e >> 4, r = e & 15;
+                    tiles[((I * (I + 1)) / 2 + I) * 256 + toff(r, r)] += Sig[v];
+                }
+            }
+            __syncthreads();
+            const bool ok = chol_tiles<NB>(tiles, S, nb, lane);
+            if (__builtin_amdgcn_readfirstlane(!ok)) {
+                status = 2;
+                break;
+            }
+            // predictor: (H+Sig) da = -grad
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int e = v * 64 + lane;
+                if (e < npad) xvp[16 * (e >> 4) + vpos(e & 15)] = -grad[v];
+            }
+            __syncthreads();
+            solve_tiles(tiles, xvp, nb, lane);
+            float da[NV], dzl_a[NV], dzu_a[NV];
+            float ap = 1.f, ad = 1.f;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int e = v * 64 + lane;
+                da[v] = (e < npad && valid[v]) ? xvp[16 * (e >> 4) + vpos(e & 15)] : 0.f;
+                dzl_a[v] = dzu_a[v] = 0.f;
+                if (valid[v]) {
+                    dzl_a[v] = -zl[v] - zl[v] * da[v] / sl[v];
+                    dzu_a[v] = -zu[v] + zu[v] * da[v] / su[v];
+                    if (da[v] < 0.f) ap = fminf(ap, -sl[v] / da[v]);
+                    if (da[v] > 0.f) ap = fminf(ap, su[v] / da[v]);
+                    if (dzl_a[v] < 0.f) ad = fminf(ad, -zl[v] / dzl_a[v]);
+                    if (dzu_a[v] < 0.f) ad = fminf(ad, -zu[v] / dzu_a[v]);
+                }
+            }
+            ap = wave_min(ap);
+            ad = wave_min(ad);
+            t = 0.f;
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                if (valid[v]) t += (sl[v] + ap * da[v]) * (zl[v] + ad * dzl_a[v]) + (su[v] - ap * da[v]) * (zu[v] + ad * dzu_a[v]);
+            const float mu_aff = wave_sum(t) * inv2n;
+            float sigma = mu_aff / mu;
+            sigma = fminf(fmaxf(sigma * sigma * sigma, 0.f), 1.f);
+            // corrector
+            float rcl[NV], rcu[NV], rhs[NV];
+            __syncthreads();
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                rcl[v] = rcu[v] = rhs[v] = 0.f;
+                if (valid[v]) {
+                    rcl[v] = sl[v] * zl[v] + da[v] * dzl_a[v] - sigma * mu;
+                    rcu[v] = su[v] * zu[v] - da[v] * dzu_a[v] - sigma * mu;
+                    rhs[v] = -(grad[v] - zl[v] + zu[v]) - rcl[v] / sl[v] + rcu[v] / su[v];
+                }
+                const int e = v * 64 + lane;
+                if (e < npad) xvp[16 * (e >> 4) + vpos(e & 15)] = rhs[v];
+            }
+            __syncthreads();
+            solve_tiles(tiles, xvp, nb, lane);
+            float dd[NV], dzl[NV], dzu[NV];
+            ap = 1e30f;
+            ad = 1e30f;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int e = v * 64 + lane;
+                dd[v] = (e < npad && valid[v]) ? xvp[16 * (e >> 4) + vpos(e & 15)] : 0.f;
+                dzl[v] = dzu[v] = 0.f;
+                if (valid[v]) {
+                    dzl[v] = (-rcl[v] - zl[v] * dd[v]) / sl[v];
+                    dzu[v] = (-rcu[v] + zu[v] * dd[v]) / su[v];
+                    if (dd[v] < 0.f) ap = fminf(ap, -sl[v] / dd[v]);
+                    if (dd[v] > 0.f) ap = fminf(ap, su[v] / dd[v]);
+                    if (dzl[v] < 0.f) ad = fminf(ad, -zl[v] / dzl[v]);
+                    if (dzu[v] < 0.f) ad = fminf(ad, -zu[v] / dzu[v]);
+                }
+            }
+            ap = fminf(1.f, 0.995f * wave_min(ap));
+            ad = fminf(1.f, 0.995f * wave_min(ad));
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                if (valid[v]) {
+                    sl[v] += ap * dd[v];
+                    su[v] -= ap * dd[v];
+                    zl[v] += ad * dzl[v];
+                    zu[v] += ad * dzu[v];
+                }
+            // re-stage H for the next gradient / factorisation
+            __syncthreads();
+            for (int i = lane; i < ntl * 64; i += 64) *reinterpret_cast<f32x4*>(tiles + 4 * i) = *reinterpret_cast<const f32x4*>(hslot + 4 * i);
+            __syncthreads();
+        }
+
+        // ---------------- outputs ----------------
+        __syncthreads();
+        float* ubuf = tiles;  // N*NT words, zero = broken thruster
+        for (int i = lane; i < N * NT; i += 64) ubuf[i] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            if (valid[v]) {
+                float u = (sl[v] < su[v]) ? sl[v] : ubv[v] - su[v];
+                if (status == 2) u = ubar[v];
+                ubuf[kcol[v] * NT + s_act[acol[v]]] = u;
+            }
+        __syncthreads();
+        if (lane < NT) P.out_u0[inst * NT + lane] = (double)ubuf[lane];
+        if (P.out_U)
+            for (int i = lane; i < N * NT; i += 64) P.out_U[inst * (int64_t)N * NT + i] = (double)ubuf[i];
+        if (lane == 0) {
+            if (P.status) P.status[inst] = status;
+            if (P.iters) P.iters[inst] = nit;
+        }
+    }
+}
+
+template __global__ void ftmpc_solve_f32_kernel<8>(const DeviceConsts, const SolveParams);
+template __global__ void ftmpc_solve_f32_kernel<10>(const DeviceConsts, const SolveParams);
+
+}  // namespace ftmpc

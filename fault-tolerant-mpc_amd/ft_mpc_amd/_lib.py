@@ -1,0 +1,92 @@
+"""ctypes binding of include/ftmpc.h (libftmpc_hip.so, built in-tree by csrc/Makefile).
+
+The product path has no CPU fallback: `load_library()` raises if the shared object is
+missing, and `ftmpc_create` fails when no gfx950 device is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+_CSRC = _HERE.parent / "csrc"
+_SO = _HERE / "libftmpc_hip.so"
+
+MAX_NT = 16
+
+# every symbol include/ftmpc.h declares (tests check the list against the header)
+SYMBOLS = (
+    "ftmpc_default_config", "ftmpc_create", "ftmpc_destroy", "ftmpc_last_error", "ftmpc_reserve",
+    "ftmpc_solve_batch", "ftmpc_solve_batch_device", "ftmpc_shift_warm", "ftmpc_set_profiling",
+    "ftmpc_last_kernel_ms", "ftmpc_solve_kernel_name", "ftmpc_debug_build_qp", "ftmpc_version",
+)
+
+
+class FtmpcError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"ftmpc error {code}: {msg}")
+        self.code = code
+
+
+class ftmpc_config(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("NT", C.c_int32), ("dtype", C.c_int32), ("max_iters", C.c_int32),
+        ("device_id", C.c_int32), ("reserved0", C.c_int32),
+        ("dt", C.c_double), ("mass", C.c_double), ("J", C.c_double * 9),
+        ("D", C.c_double * (6 * MAX_NT)), ("Q", C.c_double * 9), ("R", C.c_double * 6),
+        ("P", C.c_double * 81), ("r", C.c_double * 3), ("f_virt", C.c_double * 3),
+        ("rho", C.c_double), ("mu_stop", C.c_double),
+    ]
+
+
+def library_path() -> Path:
+    return _SO
+
+
+def build_library(force: bool = False) -> Path:
+    """Compiles csrc/*.hip for gfx950 into ft_mpc_amd/libftmpc_hip.so (hipcc cross-compiles
+    without a GPU).  Idempotent: make decides whether anything is stale."""
+    if force and _SO.exists():
+        _SO.unlink()
+    subprocess.run(["make", "-C", str(_CSRC)], check=True, stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _SO.exists():
+        raise FileNotFoundError(
+            f"{_SO} is missing: build it with `make -C {_CSRC}` (or __graft_entry__.build()). "
+            "There is no CPU fallback for the MPC QP-step path.")
+    lib = C.CDLL(str(_SO))
+    dp = C.POINTER(C.c_double)
+    ip = C.POINTER(C.c_int32)
+    vp = C.c_void_p
+    lib.ftmpc_default_config.argtypes = [C.POINTER(ftmpc_config), C.c_int32, C.c_int32]
+    lib.ftmpc_create.argtypes = [C.POINTER(ftmpc_config), C.POINTER(vp)]
+    lib.ftmpc_destroy.argtypes = [vp]
+    lib.ftmpc_last_error.argtypes = [vp]
+    lib.ftmpc_last_error.restype = C.c_char_p
+    lib.ftmpc_reserve.argtypes = [vp, C.c_int64]
+    lib.ftmpc_solve_batch.argtypes = [vp, C.c_int64, dp, dp, dp, dp, C.c_int64, dp, C.c_int64, dp, dp, dp, ip, ip]
+    lib.ftmpc_solve_batch_device.argtypes = [vp, C.c_int64, vp, vp, vp, vp, C.c_int64, vp, C.c_int64, vp, vp, vp, vp, vp, vp]
+    lib.ftmpc_shift_warm.argtypes = [C.c_int64, C.c_int32, C.c_int32, dp]
+    lib.ftmpc_set_profiling.argtypes = [vp, C.c_int32]
+    lib.ftmpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.ftmpc_solve_kernel_name.argtypes = [vp]
+    lib.ftmpc_solve_kernel_name.restype = C.c_char_p
+    lib.ftmpc_debug_build_qp.argtypes = [vp, C.c_int64, dp, dp, dp, dp, C.c_int64, dp, C.c_int64, dp, C.c_int64,
+                                         dp, C.c_int64, dp, dp, dp, ip]
+    lib.ftmpc_version.restype = C.c_int32
+    for name in SYMBOLS:
+        if name not in ("ftmpc_last_error", "ftmpc_solve_kernel_name", "ftmpc_version"):
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib

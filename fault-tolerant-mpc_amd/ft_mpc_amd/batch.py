@@ -1,0 +1,211 @@
+"""Batched front-end of the HIP MPC QP-step path (numpy in / numpy out, or device pointers).
+
+`BatchedMPC.solve` is the batched form of SpiralingController.get_control
+(reference: ft_mpc/controllers/spiraling_mpc.py:288-317): B robot states + fault scenarios in,
+B thruster command vectors out.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from .models.sys_model import allocation_matrix_16, allocation_matrix_8
+
+F_MAX = 3.4  # sys_model.py:60
+
+
+@dataclass
+class MPCConfig:
+    """Problem constants; defaults are the reference's (see include/ftmpc.h ftmpc_config)."""
+    N: int = 20
+    NT: int = 8
+    dt: float = 0.1
+    mass: float = 16.8
+    J: np.ndarray = field(default_factory=lambda: np.diag([0.2, 0.3, 0.25]))
+    D: np.ndarray = None
+    Q: np.ndarray = field(default_factory=lambda: np.array([1, 1, 1, 1, 1, 1, 2, 2, 2], float))
+    R: np.ndarray = field(default_factory=lambda: np.array([0.1, 0.1, 0.1, 0.01, 0.01, 0.01]))
+    P: np.ndarray = None
+    r: np.ndarray = None
+    f_virt: np.ndarray = field(default_factory=lambda: np.array([0.0, 3.5, 0.0]))
+    rho: float = 0.05
+    max_iters: int = 16
+    mu_stop: float = 1e-10
+    device_id: int = 0
+
+
+def _ptr(a, ct=C.c_double):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ct))
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+class BatchedMPC:
+    """One handle == one GPU.  Not re-entrant (like the reference controller, which keeps its
+    warm start in `self.optimal_solution`); use one instance per host thread / GPU."""
+
+    def __init__(self, cfg: MPCConfig | None = None, **kw):
+        cfg = cfg or MPCConfig(**kw)
+        self.cfg = cfg
+        self.lib = _lib.load_library()
+        c = _lib.ftmpc_config()
+        rc = self.lib.ftmpc_default_config(C.byref(c), cfg.N, cfg.NT)
+        if rc != 0:
+            raise _lib.FtmpcError(rc, "bad N/NT")
+        c.dt, c.mass, c.rho, c.mu_stop = cfg.dt, cfg.mass, cfg.rho, cfg.mu_stop
+        c.max_iters, c.device_id = cfg.max_iters, cfg.device_id
+        c.J[:] = list(_f64(cfg.J, 9))
+        D = cfg.D
+        if D is None:
+            D = allocation_matrix_16() if cfg.NT == 16 else (allocation_matrix_8() if cfg.NT == 8 else None)
+        if D is None:
+            raise ValueError("MPCConfig.D (6 x NT) is required for NT not in (8, 16)")
+        D = _f64(D, (6, cfg.NT))
+        self.D = D
+        flat = np.zeros(6 * _lib.MAX_NT)
+        flat[:6 * cfg.NT] = D.reshape(-1)
+        c.D[:] = list(flat)
+        c.Q[:] = list(_f64(cfg.Q, 9))
+        c.R[:] = list(_f64(cfg.R, 6))
+        if cfg.P is not None:
+            c.P[:] = list(_f64(cfg.P, 81))
+        if cfg.r is not None:
+            c.r[:] = list(_f64(cfg.r, 3))
+        c.f_virt[:] = list(_f64(cfg.f_virt, 3))
+        self.r = np.array(list(c.r))
+        self.P = np.array(list(c.P)).reshape(9, 9)
+        self._c = c
+        self._h = C.c_void_p()
+        rc = self.lib.ftmpc_create(C.byref(c), C.byref(self._h))
+        if rc != 0:
+            msg = self.lib.ftmpc_last_error(None).decode()
+            raise _lib.FtmpcError(rc, msg)
+
+    # -- lifetime -----------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.ftmpc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise _lib.FtmpcError(rc, self.lib.ftmpc_last_error(self._h).decode())
+
+    def reserve(self, max_batch: int):
+        self._check(self.lib.ftmpc_reserve(self._h, int(max_batch)))
+
+    @property
+    def kernel_name(self) -> str:
+        return self.lib.ftmpc_solve_kernel_name(self._h).decode()
+
+    # -- host-buffer path ---------------------------------------------------------------
+    def _refs(self, B, xref, uref):
+        N = self.cfg.N
+        xref = _f64(xref)
+        xs = 0 if xref.size == 9 * (N + 1) else xref.size // B
+        us = 0
+        if uref is not None:
+            uref = _f64(uref)
+            us = 0 if uref.size == 6 * (N + 1) else uref.size // B
+        return xref, xs, uref, us
+
+    def solve(self, x0, ub, stuck, xref, uref=None, warmU=None, return_U=False):
+        """x0 [B,13], ub/stuck [B,NT], xref 9x(N+1) column-major flat (shared) or [B, 9(N+1)],
+        uref likewise with 6 rows or None (hover), warmU [B,N,NT] or None (updated in place).
+        Returns dict(u0 [B,NT], U [B,N,NT]|None, status [B], iters [B])."""
+        N, NT = self.cfg.N, self.cfg.NT
+        x0 = _f64(x0).reshape(-1, 13)
+        B = x0.shape[0]
+        ub = _f64(ub, (B, NT))
+        stuck = _f64(stuck, (B, NT))
+        xref, xs, uref, us = self._refs(B, xref, uref)
+        if warmU is not None and not (isinstance(warmU, np.ndarray) and warmU.dtype == np.float64
+                                      and warmU.flags.c_contiguous and warmU.size == B * N * NT):
+            raise ValueError("warmU must be a C-contiguous float64 array of B*N*NT (updated in place)")
+        u0 = np.empty((B, NT))
+        U = np.empty((B, N, NT)) if return_U else None
+        status = np.empty(B, np.int32)
+        iters = np.empty(B, np.int32)
+        self._check(self.lib.ftmpc_solve_batch(self._h, B, _ptr(x0), _ptr(ub), _ptr(stuck), _ptr(xref), xs,
+                                               _ptr(uref), us, _ptr(warmU), _ptr(u0), _ptr(U),
+                                               _ptr(status, C.c_int32), _ptr(iters, C.c_int32)))
+        return dict(u0=u0, U=U, status=status, iters=iters)
+
+    # -- device-pointer path (HBM-resident inputs; used by bench.py with torch tensors) --
+    def solve_device(self, B, x0, ub, stuck, xref, xref_stride, uref, uref_stride, warmU, out_u0, out_U,
+                     status, iters, stream=0):
+        """All buffer arguments are integer device addresses (e.g. torch.Tensor.data_ptr())."""
+        vp = lambda p: C.c_void_p(int(p)) if p else None
+        self._check(self.lib.ftmpc_solve_batch_device(self._h, int(B), vp(x0), vp(ub), vp(stuck), vp(xref),
+                                                      int(xref_stride), vp(uref), int(uref_stride), vp(warmU),
+                                                      vp(out_u0), vp(out_U), vp(status), vp(iters), vp(stream)))
+
+    def set_profiling(self, on: bool):
+        self._check(self.lib.ftmpc_set_profiling(self._h, 1 if on else 0))
+
+    def last_kernel_ms(self):
+        ms = (C.c_float * 2)()
+        self._check(self.lib.ftmpc_last_kernel_ms(self._h, ms))
+        return float(ms[0]), float(ms[1])
+
+    # -- test hook ----------------------------------------------------------------------
+    def debug_build_qp(self, x0, ub, stuck, xref, inst, uref=None, warmU=None):
+        N, NT = self.cfg.N, self.cfg.NT
+        x0 = _f64(x0).reshape(-1, 13)
+        B = x0.shape[0]
+        ub = _f64(ub, (B, NT))
+        stuck = _f64(stuck, (B, NT))
+        xref, xs, uref, us = self._refs(B, xref, uref)
+        warm = None if warmU is None else _f64(warmU)
+        nmax = N * NT
+        H = np.zeros(nmax * nmax)
+        g = np.zeros(nmax)
+        lo = np.zeros(nmax)
+        hi = np.zeros(nmax)
+        n = C.c_int32(0)
+        self._check(self.lib.ftmpc_debug_build_qp(self._h, B, _ptr(x0), _ptr(ub), _ptr(stuck), _ptr(xref), xs,
+                                                  _ptr(uref), us, _ptr(warm), int(inst), _ptr(H), H.size,
+                                                  _ptr(g), _ptr(lo), _ptr(hi), C.byref(n)))
+        n = n.value
+        return H[:n * n].reshape(n, n).copy(), g[:n].copy(), lo[:n].copy(), hi[:n].copy()
+
+
+def make_synthetic_batch(B, N, NT, nfault, seed, f_max=F_MAX, omega_des=(0.0, 0.0, 0.6)):
+    """Seeded random-pose / random-fault batch of BASELINE.md section 4:
+    p~U(-2,2)^3, v~U(-.5,.5)^3, q uniform on S^3, omega~omega_des+U(-.2,.2)^3, hover reference,
+    `nfault` distinct broken thrusters per instance with iid U(0,1) intensities.
+    Returns (x0 [B,13], ub [B,NT], stuck [B,NT], xref 9x(N+1))."""
+    rng = np.random.default_rng(seed)
+    od = np.asarray(omega_des, float)
+    x0 = np.zeros((B, 13))
+    x0[:, 0:3] = rng.uniform(-2, 2, (B, 3))
+    x0[:, 3:6] = rng.uniform(-0.5, 0.5, (B, 3))
+    q = rng.standard_normal((B, 4))
+    x0[:, 6:10] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    x0[:, 10:13] = od + rng.uniform(-0.2, 0.2, (B, 3))
+    ub = np.full((B, NT), f_max)
+    stuck = np.zeros((B, NT))
+    if nfault > 0:
+        keys = rng.random((B, NT))
+        idx = np.argsort(keys, axis=1)[:, :nfault]
+        inten = rng.uniform(0, 1, (B, nfault))
+        rows = np.arange(B)[:, None]
+        ub[rows, idx] = 0.0
+        stuck[rows, idx] = inten * f_max
+    xref = np.zeros((9, N + 1))
+    xref[6:9, :] = od.reshape(3, 1)
+    return x0, ub, stuck, xref

@@ -1,0 +1,170 @@
+/*
+ * ftmpc.h -- C-ABI of the MI355X-native batched MPC QP-step path.
+ *
+ * Drop-in boundary.  The reference (DISCOWER/fault-tolerant-mpc) has
+ * no FFI: its seam is the duck-typed Python controller consumed by
+ * ft_mpc/simulation/sim_env.py:82.  These entry points are what a ctypes binding behind
+ *     SpiralingController.get_control(x0, t)   ft_mpc/controllers/spiraling_mpc.py:288-317
+ *     SpiralingController.solve_mpc(c0)        ft_mpc/controllers/spiraling_mpc.py:319-354
+ * calls; INTEGRATION.md shows that binding.  Plain C types only, caller-owned buffers, int
+ * return codes (0 ok, <0 error) and per-instance status/iters arrays instead of the
+ * reference's logged-but-ignored IPOPT status (spiraling_mpc.py:347-352) or the allocator's
+ * exit() (controllers/tools/control_allocator.py:88-93).  No global state: one opaque
+ * handle per GPU; distinct handles may be used concurrently from distinct host threads.
+ *
+ * All host-visible numbers are IEEE double (the reference works in numpy float64).
+ * State layout x0 = [p(3), v(3), q(4; x,y,z,w), omega(3)]   ft_mpc/models/sys_model.py:35-41.
+ */
+#ifndef FTMPC_H
+#define FTMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FTMPC_MAX_NT 16
+#define FTMPC_NX 13
+#define FTMPC_NOPT 9
+#define FTMPC_NG 6
+
+/* return codes */
+#define FTMPC_OK 0
+#define FTMPC_ERR_ARG (-1)       /* bad argument / unsupported shape */
+#define FTMPC_ERR_HIP (-2)       /* HIP runtime failure; see ftmpc_last_error */
+#define FTMPC_ERR_NODEVICE (-3)  /* no usable gfx950 device */
+#define FTMPC_ERR_ALLOC (-4)
+
+/* per-instance status[] values */
+#define FTMPC_STATUS_CONVERGED 0   /* complementarity gap fell below mu_stop */
+#define FTMPC_STATUS_MAXITER 1     /* stopped at max_iters (last iterate returned, like the reference) */
+#define FTMPC_STATUS_NUMERIC 2     /* non-finite value met; u0 = clip(warm start) returned */
+
+/* arithmetic of the solve path */
+#define FTMPC_DTYPE_F32 0
+#define FTMPC_DTYPE_F64 1
+
+/*
+ * Problem constants.  Replaces what the reference hard-codes or reads from YAML:
+ *   N        tuning.spiraling.horizon          ft_mpc/config/reactive.yaml:26, spiraling_mpc.py:38
+ *   dt       time_step                         reactive.yaml:2
+ *   mass,J   SystemModel                       ft_mpc/models/sys_model.py:52-57
+ *   D        6 x NT allocation matrix, row-major, sys_model.py:73-123 (NT=16); runtime data so
+ *            that the NT=8 benchmark can pass its synthetic matrix
+ *   Q,R      diag weights                      reactive.yaml:32-33, spiraling_mpc.py:91-93
+ *   P        9x9 terminal weight, row-major (quadratic part of ft_mpc/config/terminal.yaml)
+ *   r        orbit radius vector               controllers/tools/spiral_parameters.py:39
+ *   f_virt   virtual force                     spiral_parameters.py:34-36
+ *   rho      min-energy allocation weight      controllers/tools/control_allocator.py:32
+ *            (folded into the QP as strict-convexity regulariser; QP-spec)
+ */
+typedef struct ftmpc_config {
+    int32_t N;          /* horizon stages, 1..64 */
+    int32_t NT;         /* thrusters, 1..FTMPC_MAX_NT */
+    int32_t dtype;      /* FTMPC_DTYPE_F32 | FTMPC_DTYPE_F64 : arithmetic of the IPM/KKT solve */
+    int32_t max_iters;  /* IPM iteration cap (fixed upper bound; early exit at mu_stop) */
+    int32_t device_id;  /* HIP device ordinal */
+    int32_t reserved0;
+    double dt;
+    double mass;
+    double J[9];
+    double D[FTMPC_NG * FTMPC_MAX_NT]; /* row-major 6 x NT, row stride NT */
+    double Q[FTMPC_NOPT];
+    double R[FTMPC_NG];
+    double P[FTMPC_NOPT * FTMPC_NOPT];
+    double r[3];
+    double f_virt[3];
+    double rho;
+    double mu_stop;     /* stop when mean complementarity < mu_stop (<=0: library default) */
+} ftmpc_config;
+
+typedef struct ftmpc_handle ftmpc_handle;
+
+/* Fills *cfg with the reference constants for (N, NT).  NT==16 gets the reference D
+ * (sys_model.py:73-123); any other NT leaves D zero for the caller to fill. */
+int ftmpc_default_config(ftmpc_config* cfg, int32_t N, int32_t NT);
+
+/* Creates a solver bound to cfg->device_id.  Fails (FTMPC_ERR_NODEVICE) when no gfx950
+ * device is present: there is no CPU fallback in this library. */
+int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out);
+int ftmpc_destroy(ftmpc_handle* h);
+const char* ftmpc_last_error(const ftmpc_handle* h); /* h may be NULL: last create error */
+
+/* Pre-allocates device workspace for batches up to max_batch (optional; solve calls grow
+ * the workspace on demand, which allocates and must not happen inside a timed region). */
+int ftmpc_reserve(ftmpc_handle* h, int64_t max_batch);
+
+/*
+ * One MPC step for B independent instances -- the batched form of get_control()
+ * (spiraling_mpc.py:288-317) up to and including the thruster command.  HOST buffers.
+ *
+ *   x0      [B*13]        robot states
+ *   ub      [B*NT]        per-thruster upper bound, 0 for a broken thruster (u_ub_physical,
+ *                         sys_model.py:237-240)
+ *   stuck   [B*NT]        intensity*f_max for a broken thruster else 0 (faulty_force,
+ *                         sys_model.py:236)
+ *   xref    [9*(N+1)] if xref_stride==0 (shared) else [B*xref_stride]; column-major 9 x (N+1)
+ *                         exactly the reference's x_sp (spiraling_mpc.py:295)
+ *   uref    NULL (== hover, u_ref = 0) or as xref with 6 x (N+1)   (spiraling_mpc.py:296)
+ *   warmU   NULL (cold start: linearise about thrusters-off) or [B*N*NT] in/out: on entry the
+ *           previous solution ALREADY shifted by the caller's policy (the reference shifts by
+ *           one stage, spiraling_mpc.py:324-334; ftmpc_shift_warm does that); on exit U*.
+ *   out_u0  [B*NT]        thruster forces of stage 0 (0 at broken thrusters)
+ *   out_U   NULL or [B*N*NT]
+ *   status  NULL or [B]   FTMPC_STATUS_*
+ *   iters   NULL or [B]   IPM iterations run
+ */
+int ftmpc_solve_batch(ftmpc_handle* h, int64_t B,
+                      const double* x0, const double* ub, const double* stuck,
+                      const double* xref, int64_t xref_stride,
+                      const double* uref, int64_t uref_stride,
+                      double* warmU,
+                      double* out_u0, double* out_U,
+                      int32_t* status, int32_t* iters);
+
+/* Same contract with DEVICE pointers (HBM-resident inputs/outputs) enqueued on `stream`
+ * (a hipStream_t passed as void*; NULL = the default stream).  Asynchronous: returns after
+ * enqueue.  warmU is read only; pass the same buffer as out_U to update it in place. */
+int ftmpc_solve_batch_device(ftmpc_handle* h, int64_t B,
+                             const double* x0, const double* ub, const double* stuck,
+                             const double* xref, int64_t xref_stride,
+                             const double* uref, int64_t uref_stride,
+                             const double* warmU,
+                             double* out_u0, double* out_U,
+                             int32_t* status, int32_t* iters,
+                             void* stream);
+
+/* Shifts a [B*N*NT] host warm-start buffer by one stage in place, zero-filling the last
+ * stage (spiraling_mpc.py:327-329). */
+int ftmpc_shift_warm(int64_t B, int32_t N, int32_t NT, double* warmU);
+
+/* Per-kernel device timing of the LAST solve call, measured with hipEvents on the launch
+ * stream when enabled.  ms[0] = linearise kernel, ms[1] = condense+IPM kernel. */
+int ftmpc_set_profiling(ftmpc_handle* h, int32_t enabled);
+int ftmpc_last_kernel_ms(ftmpc_handle* h, float ms[2]);
+
+/* Name of the dominant kernel as it appears in rocprofv3 traces for this handle's shape. */
+const char* ftmpc_solve_kernel_name(const ftmpc_handle* h);
+
+/*
+ * Test hook: runs the build for instance `inst` of a host batch and returns the condensed
+ * QP the solve kernel sees (active thrusters only):  n = N*na,  H [n*n] row-major,
+ * g [n], lo [n], hi [n] (bounds on d = U - Ubar), all as double.  *n_out receives n.
+ * H_cap is the capacity of H in elements (>= n*n).
+ */
+int ftmpc_debug_build_qp(ftmpc_handle* h, int64_t B,
+                         const double* x0, const double* ub, const double* stuck,
+                         const double* xref, int64_t xref_stride,
+                         const double* uref, int64_t uref_stride,
+                         const double* warmU, int64_t inst,
+                         double* H, int64_t H_cap, double* g, double* lo, double* hi,
+                         int32_t* n_out);
+
+/* Library/ABI version: major*10000 + minor*100 + patch. */
+int32_t ftmpc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FTMPC_H */

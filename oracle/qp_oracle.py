@@ -1,0 +1,307 @@
+"""
+oracle/qp_oracle.py -- float64 restatement of the QP-spec and of the
+fixed-iteration Mehrotra primal-dual IPM the HIP kernels run.
+
+TEST INFRASTRUCTURE ONLY (see oracle/refmath.py header).  Parity status: the QP-spec is a
+build decision derived from the reference physics/weights (the reference solves an NLP
+with IPOPT, spiraling_mpc.py:217-230, tol=1e-3, which is not runnable here): the
+*physics* under it is pinned by oracle/refmath.py's golden checks, the *QP solution* is
+pinned by an independent exact solver (scipy.optimize.lsq_linear(method='bvls')) and by
+KKT-residual checks; parity against IPOPT's NLP output is UNPINNED.
+
+QP-spec (per instance; thruster space; condensed):
+  decision  U = (u_0..u_{N-1}), u_k in R^NT, 0 <= u_k <= ub (ub_i = 0 for a broken thruster)
+  model     c_hat = c_bar + Bbar (U - Ubar): horizon-stacked linearisation of the RK4 centre
+            dynamics (spiral_model.py:44-76 through sys_model.py:138-162) about the nonlinear
+            rollout c_bar from c0 = robot_to_center(x0) under Ubar = clip(warm,0,ub) (cold: 0),
+            total generalized force gen_k = D (u_k + stuck)
+  cost      sum_{k=1}^{N-1} e_k' Q e_k + e_N' P e_N + sum_{k=0}^{N-1} [ut_k' R ut_k + rho |u_k|^2]
+            e_k = c_hat_k[0:9] - xref_k ; ut_k = gen_k - ur_k - [f_virt;0]
+            (spiraling_mpc.py:171,188: the reference's deviation input u_t with applied input
+             u_t + u_r + u_comp and u_comp = [f_virt;0] - D f_fault, spiral_parameters.py:37)
+            ur_k = [Rot(qbar_k)^T uref_k[0:3]; uref_k[3:6]]   (spiraling_mpc.py:156-166, with the
+            linearisation quaternion in place of the decision-variable quaternion)
+            P = quadratic part of terminal.yaml ; rho = allocator min-energy weight
+            (control_allocator.py:32) folded in as strict-convexity regulariser
+  output    u0 = U*_0 (thruster forces; 0 at broken thrusters), U*, iterations, status
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import refmath as rm
+
+
+@dataclass
+class QPConfig:
+    N: int = 20
+    NT: int = 8
+    dt: float = rm.DT
+    mass: float = rm.MASS
+    J: np.ndarray = field(default_factory=lambda: rm.INERTIA.copy())
+    D: np.ndarray = None
+    f_max: float = rm.F_MAX
+    Q: np.ndarray = field(default_factory=lambda: rm.Q_DIAG.copy())
+    R: np.ndarray = field(default_factory=lambda: rm.R_DIAG.copy())
+    P: np.ndarray = field(default_factory=rm.terminal_P_quadratic)
+    r: np.ndarray = field(default_factory=rm.spiral_r)
+    f_virt: np.ndarray = field(default_factory=lambda: rm.F_VIRT.copy())
+    rho: float = 0.05
+    iters: int = 12
+
+    def __post_init__(self):
+        if self.D is None:
+            self.D = rm.allocation_matrix_16() if self.NT == 16 else rm.allocation_matrix_8()
+        assert self.D.shape == (6, self.NT)
+
+
+def linearize(cfg: QPConfig, x0, ub, stuck, warmU=None):
+    """Nonlinear rollout + per-stage Jacobians.  Returns cbar (N+1,13), A (N,13,13),
+    Bg (N,13,6), Ubar (N,NT)."""
+    N, NT = cfg.N, cfg.NT
+    Ubar = np.zeros((N, NT)) if warmU is None else np.clip(np.asarray(warmU, float).reshape(N, NT), 0.0, ub)
+    c = rm.robot_to_center(x0, cfg.r)
+    cbar = np.zeros((N + 1, 13))
+    A = np.zeros((N, 13, 13))
+    Bg = np.zeros((N, 13, 6))
+    cbar[0] = c
+    for k in range(N):
+        gen = cfg.D @ (Ubar[k] + stuck)
+        c, A[k], Bg[k] = rm.rk4_with_jac(c, gen, cfg.r, cfg.dt, cfg.mass, cfg.J)
+        cbar[k + 1] = c
+    return cbar, A, Bg, Ubar
+
+
+def build_qp(cfg: QPConfig, x0, ub, stuck, xref, uref=None, warmU=None):
+    """Dense condensed QP over the ACTIVE thrusters only.
+
+    Returns dict(H (n,n), g (n,), Ubar_act (n,), ub_act (n,), act (indices into NT), n,
+    cbar, Bbar) with  cost(U) = 1/2 d'H d + g'd + const, d = U_act - Ubar_act,
+    H = 2 (Bbar' Qbar Bbar + Rbar),  g = gradient of the cost at Ubar.
+    The factor 2 is kept so that H,g are the true Hessian/gradient of the reference's
+    un-halved stage cost (spiraling_mpc.py:76).
+    """
+    N, NT = cfg.N, cfg.NT
+    ub = np.asarray(ub, float).reshape(NT)
+    stuck = np.asarray(stuck, float).reshape(NT)
+    xref = np.asarray(xref, float).reshape(9, N + 1)
+    cbar, A, Bg, Ubar = linearize(cfg, x0, ub, stuck, warmU)
+    act = np.flatnonzero(ub > 0)
+    na = act.size
+    n = N * na
+    Da = cfg.D[:, act]
+    # Bbar row-blocks: G[k] = d c_k / d U_act  (13 x n), k = 0..N
+    G = np.zeros((N + 1, 13, n))
+    for k in range(N):
+        G[k + 1] = A[k] @ G[k]
+        G[k + 1][:, k * na:(k + 1) * na] = Bg[k] @ Da
+    Qm = np.diag(cfg.Q)
+    H = np.zeros((n, n))
+    g = np.zeros(n)
+    for k in range(1, N + 1):
+        W = cfg.P if k == N else Qm
+        E = G[k][0:9]
+        e = cbar[k][0:9] - xref[:, k]
+        H += 2 * E.T @ W @ E
+        g += 2 * E.T @ W @ e
+    Rm = np.diag(cfg.R)
+    fv = np.concatenate([cfg.f_virt, np.zeros(3)])
+    for k in range(N):
+        ur = np.zeros(6)
+        if uref is not None:
+            u_r = np.asarray(uref, float).reshape(6, N + 1)[:, k]
+            ur = np.concatenate([rm.rot(cbar[k][9:13]).T @ u_r[0:3], u_r[3:6]])
+        ut = cfg.D @ (Ubar[k] + stuck) - ur - fv
+        sl = slice(k * na, (k + 1) * na)
+        H[sl, sl] += 2 * (Da.T @ Rm @ Da + cfg.rho * np.eye(na))
+        g[sl] += 2 * (Da.T @ Rm @ ut + cfg.rho * Ubar[k][act])
+    return dict(H=H, g=g, Ubar=Ubar[:, act].reshape(-1), ub=np.tile(ub[act], N), act=act,
+                n=n, na=na, cbar=cbar, A=A, Bg=Bg)
+
+
+def ipm_box(H, g, lo, hi, iters=12, dtype=np.float64, x_init=None, polish=False, trace=None,
+            mu_stop=None):
+    """Fixed-iteration Mehrotra predictor-corrector for
+         min 1/2 d'H d + g'd   s.t.  lo <= d <= hi      (lo < hi componentwise)
+    Slacks s_l = d - lo, s_u = hi - d are carried as state and updated by s += a*ds (never
+    recomputed by subtraction: that cancels catastrophically in fp32); the gradient H d + g
+    is carried the same way through  H dd = rhs - Sig dd  (no H matvec after the start).
+    `dtype` lets tests emulate the kernel's fp32 arithmetic.  This is the algorithm the HIP
+    kernel mirrors step for step (fault-tolerant-mpc_amd/csrc/ftmpc_kernels.hip).
+    Returns (d, z_l, z_u, iterations_run).
+    """
+    T = dtype
+    H = H.astype(T)
+    g = g.astype(T)
+    lo = lo.astype(T)
+    hi = hi.astype(T)
+    n = g.size
+    d = ((lo + hi) * T(0.5)) if x_init is None else x_init.astype(T)
+    sl = d - lo
+    su = hi - d
+    grad = H @ d + g
+    # duals: start on the central path at mu0, scaled by the gradient
+    mu0 = max(T(np.abs(grad).max()) * T((hi - lo).max()) * T(0.25), T(1e-3))
+    zl = mu0 / sl
+    zu = mu0 / su
+    tau = T(0.995)
+    if mu_stop is None:
+        mu_stop = 1e-13 if T is np.float64 else 1e-8
+    mu_stop = T(mu_stop)
+    nit = 0
+    for it in range(iters):
+        mu = (sl @ zl + su @ zu) / T(2 * n)
+        if not (mu >= mu_stop):
+            break
+        nit += 1
+        rd = grad - zl + zu
+        Sig = zl / sl + zu / su
+        M = H + np.diag(Sig)
+        L = np.linalg.cholesky(M) if T is np.float64 else _chol(M)
+        # predictor (sigma = 0): rhs = -rd - zl + zu = -grad
+        da = _solve(L, -grad)
+        dzl_a = -zl - zl * da / sl
+        dzu_a = -zu + zu * da / su
+        ap = min(T(1), _max_step(sl, da, su))
+        ad = min(T(1), _max_step_dual(zl, dzl_a, zu, dzu_a))
+        mu_aff = ((sl + ap * da) @ (zl + ad * dzl_a) + (su - ap * da) @ (zu + ad * dzu_a)) / T(2 * n)
+        sigma = min(max((mu_aff / mu) ** 3, T(0)), T(1))
+        # corrector
+        rcl = sl * zl + da * dzl_a - sigma * mu
+        rcu = su * zu - da * dzu_a - sigma * mu
+        rhs = -rd - rcl / sl + rcu / su
+        dd = _solve(L, rhs)
+        dzl = (-rcl - zl * dd) / sl
+        dzu = (-rcu + zu * dd) / su
+        ap = min(T(1), tau * _max_step(sl, dd, su))
+        ad = min(T(1), tau * _max_step_dual(zl, dzl, zu, dzu))
+        d = d + ap * dd
+        sl = sl + ap * dd
+        su = su - ap * dd
+        grad = grad + ap * (rhs - Sig * dd)
+        zl = zl + ad * dzl
+        zu = zu + ad * dzu
+        if trace is not None:
+            trace.append((float(mu), float(np.abs(rd).max()), float(ap), float(ad)))
+    # report each coordinate from its nearer bound (the slack there is the accurate quantity)
+    d = np.where(sl < su, lo + sl, hi - su)
+    if polish:
+        d = polish_active_set(H, g, lo, hi, d, sl, su, zl, zu, T)
+    return d, zl, zu, nit
+
+
+def _chol(M):
+    """Cholesky in the working precision (fp32 emulation: plain right-looking loop)."""
+    T = M.dtype.type
+    n = M.shape[0]
+    L = np.tril(M).copy()
+    for j in range(n):
+        L[j, j] = np.sqrt(L[j, j])
+        L[j + 1:, j] = L[j + 1:, j] / L[j, j]
+        L[j + 1:, j + 1:] -= np.tril(np.outer(L[j + 1:, j], L[j + 1:, j])).astype(M.dtype)
+    return L
+
+
+def _solve(L, b):
+    import scipy.linalg as sla
+    y = sla.solve_triangular(L, b, lower=True, check_finite=False).astype(L.dtype)
+    return sla.solve_triangular(L.T, y, lower=False, check_finite=False).astype(L.dtype)
+
+
+def _max_step(sl, dd, su):
+    T = sl.dtype.type
+    a = T(1e30)
+    neg = dd < 0
+    if neg.any():
+        a = min(a, (-sl[neg] / dd[neg]).min())
+    pos = dd > 0
+    if pos.any():
+        a = min(a, (su[pos] / dd[pos]).min())
+    return min(a, T(1e30))
+
+
+def _max_step_dual(zl, dzl, zu, dzu):
+    T = zl.dtype.type
+    a = T(1e30)
+    m = dzl < 0
+    if m.any():
+        a = min(a, (-zl[m] / dzl[m]).min())
+    m = dzu < 0
+    if m.any():
+        a = min(a, (-zu[m] / dzu[m]).min())
+    return a
+
+
+def polish_active_set(H, g, lo, hi, d, sl, su, zl, zu, T=np.float64):
+    """Active-set polish: pin variables whose dual dominates its slack, solve the free block."""
+    at_lo = zl > sl
+    at_hi = zu > su
+    free = ~(at_lo | at_hi)
+    x = np.where(at_lo, lo, np.where(at_hi, hi, d)).astype(T)
+    if free.any():
+        Hff = H[np.ix_(free, free)].astype(np.float64)
+        rhs = -(g[free].astype(np.float64) + H[np.ix_(free, ~free)].astype(np.float64) @ x[~free].astype(np.float64))
+        x[free] = np.linalg.solve(Hff, rhs).astype(T)
+        x = np.clip(x, lo, hi)
+    return x
+
+
+def solve_exact(H, g, lo, hi):
+    """Independent exact solution: bounded least squares on the Cholesky factor
+    (SURVEY.md section 8(c)): 1/2 d'Hd + g'd = 1/2 |L' d + L^-1 g|^2 + const."""
+    from scipy.optimize import lsq_linear
+    import scipy.linalg as sla
+    L = np.linalg.cholesky(H)
+    b = -sla.solve_triangular(L, g, lower=True)
+    res = lsq_linear(L.T, b, bounds=(lo, hi), method="bvls", tol=1e-15, max_iter=20000)
+    return res.x
+
+
+def kkt_residual(H, g, lo, hi, d):
+    """max-norm of the projected-gradient optimality measure."""
+    grad = H @ d + g
+    pg = d - np.clip(d - grad, lo, hi)
+    return np.abs(pg).max()
+
+
+def solve_instance(cfg: QPConfig, x0, ub, stuck, xref, uref=None, warmU=None, dtype=np.float64,
+                   iters=None, exact=False, polish=False):
+    """Full oracle step.  Returns (u0 (NT,), U (N,NT), qp dict)."""
+    qp = build_qp(cfg, x0, ub, stuck, xref, uref, warmU)
+    lo = -qp["Ubar"]
+    hi = qp["ub"] - qp["Ubar"]
+    if exact:
+        d = solve_exact(qp["H"], qp["g"], lo, hi)
+    else:
+        d, _, _, _ = ipm_box(qp["H"], qp["g"], lo, hi, iters or cfg.iters, dtype, polish=polish)
+    U = np.zeros((cfg.N, cfg.NT))
+    U[:, qp["act"]] = (qp["Ubar"] + d.astype(float)).reshape(cfg.N, qp["na"])
+    return U[0].copy(), U, qp
+
+
+# --------------------------------------------------------------------------------------
+# synthetic instance generator; kept bit-identical
+# to ft_mpc_amd.batch.make_synthetic_batch (tests compare the two)
+# --------------------------------------------------------------------------------------
+def make_batch(B, N, NT, nfault, seed, f_max=rm.F_MAX):
+    rng = np.random.default_rng(seed)
+    x0 = np.zeros((B, 13))
+    x0[:, 0:3] = rng.uniform(-2, 2, (B, 3))
+    x0[:, 3:6] = rng.uniform(-0.5, 0.5, (B, 3))
+    q = rng.standard_normal((B, 4))
+    x0[:, 6:10] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    x0[:, 10:13] = rm.OMEGA_DES + rng.uniform(-0.2, 0.2, (B, 3))
+    ub = np.full((B, NT), f_max)
+    stuck = np.zeros((B, NT))
+    if nfault > 0:
+        keys = rng.random((B, NT))
+        idx = np.argsort(keys, axis=1)[:, :nfault]
+        inten = rng.uniform(0, 1, (B, nfault))
+        rows = np.arange(B)[:, None]
+        ub[rows, idx] = 0.0
+        stuck[rows, idx] = inten * f_max
+    xref = np.zeros((9, N + 1))
+    xref[6:9, :] = rm.OMEGA_DES.reshape(3, 1)
+    return x0, ub, stuck, xref

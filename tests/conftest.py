@@ -1,0 +1,29 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "fault-tolerant-mpc_amd"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def gpu_mpc_factory():
+    """Creates BatchedMPC handles (HIP library) and closes them at session end."""
+    import ft_mpc_amd
+    made = []
+
+    def make(**kw):
+        m = ft_mpc_amd.BatchedMPC(**kw)
+        made.append(m)
+        return m
+
+    yield make
+    for m in made:
+        m.close()

@@ -1,0 +1,132 @@
+"""ctypes wrapper of oracle/ftmpc_oracle.c (TEST INFRASTRUCTURE ONLY, see refmath.py header)."""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+from . import refmath as rm
+
+_HERE = Path(__file__).resolve().parent
+_SO = _HERE / "libftmpc_oracle.so"
+MAX_NT = 16
+
+
+class oracle_config(C.Structure):
+    _fields_ = [("N", C.c_int32), ("NT", C.c_int32), ("max_iters", C.c_int32), ("reserved", C.c_int32),
+                ("dt", C.c_double), ("mass", C.c_double), ("J", C.c_double * 9),
+                ("D", C.c_double * (6 * MAX_NT)), ("Q", C.c_double * 9), ("R", C.c_double * 6),
+                ("P", C.c_double * 81), ("r", C.c_double * 3), ("f_virt", C.c_double * 3),
+                ("rho", C.c_double), ("mu_stop", C.c_double)]
+
+
+def build():
+    subprocess.run(["make", "-C", str(_HERE)], check=True, stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not _SO.exists():
+            build()
+        _lib = C.CDLL(str(_SO))
+    return _lib
+
+
+def make_config(qcfg, max_iters=40, mu_stop=1e-13):
+    """qcfg: oracle.qp_oracle.QPConfig"""
+    c = oracle_config()
+    c.N, c.NT, c.max_iters = qcfg.N, qcfg.NT, max_iters
+    c.dt, c.mass, c.rho, c.mu_stop = qcfg.dt, qcfg.mass, qcfg.rho, mu_stop
+    c.J[:] = list(np.asarray(qcfg.J, float).reshape(9))
+    flat = np.zeros(6 * MAX_NT)
+    flat[:6 * qcfg.NT] = np.asarray(qcfg.D, float).reshape(-1)
+    c.D[:] = list(flat)
+    c.Q[:] = list(qcfg.Q)
+    c.R[:] = list(qcfg.R)
+    c.P[:] = list(np.asarray(qcfg.P, float).reshape(81))
+    c.r[:] = list(qcfg.r)
+    c.f_virt[:] = list(qcfg.f_virt)
+    return c
+
+
+def _p(a, t=C.c_double):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+def solve_batch(qcfg, x0, ub, stuck, xref, uref=None, warmU=None, max_iters=40, mu_stop=1e-13, nthreads=1,
+                return_U=True):
+    """Exact (tightly converged float64 IPM) solution of the QP-spec for a batch.
+    xref: 9x(N+1) array (shared) or [B, 9(N+1)] column-major-flattened per instance."""
+    N, NT = qcfg.N, qcfg.NT
+    x0 = np.ascontiguousarray(x0, float).reshape(-1, 13)
+    B = x0.shape[0]
+    ub = np.ascontiguousarray(ub, float).reshape(B, NT)
+    stuck = np.ascontiguousarray(stuck, float).reshape(B, NT)
+    xr = np.asarray(xref, float)
+    if xr.shape == (9, N + 1):
+        xr = np.ascontiguousarray(xr.reshape(-1, order="F"))
+        xs = 0
+    else:
+        xr = np.ascontiguousarray(xr).reshape(B, -1)
+        xs = xr.shape[1]
+    ur, us = None, 0
+    if uref is not None:
+        ur = np.asarray(uref, float)
+        if ur.shape == (6, N + 1):
+            ur = np.ascontiguousarray(ur.reshape(-1, order="F"))
+        else:
+            ur = np.ascontiguousarray(ur).reshape(B, -1)
+            us = ur.shape[1]
+    warm = None if warmU is None else np.ascontiguousarray(warmU, float).reshape(B, N * NT)
+    u0 = np.zeros((B, NT))
+    U = np.zeros((B, N, NT)) if return_U else None
+    status = np.zeros(B, np.int32)
+    iters = np.zeros(B, np.int32)
+    c = make_config(qcfg, max_iters, mu_stop)
+    f = lib().ftmpc_oracle_solve_batch
+    f.restype = C.c_int
+    f.argtypes = [C.POINTER(oracle_config), C.c_int64] + [C.POINTER(C.c_double)] * 4 + [C.c_int64, C.POINTER(C.c_double),
+                  C.c_int64] + [C.POINTER(C.c_double)] * 3 + [C.POINTER(C.c_int32)] * 2 + [C.c_int32]
+    rc = f(C.byref(c), B, _p(x0), _p(ub), _p(stuck), _p(xr), xs, _p(ur), us, _p(warm), _p(u0), _p(U),
+           _p(status, C.c_int32), _p(iters, C.c_int32), int(nthreads))
+    if rc != 0:
+        raise RuntimeError(f"ftmpc_oracle_solve_batch rc={rc}")
+    return dict(u0=u0, U=U, status=status, iters=iters)
+
+
+def build_qp(qcfg, x0, ub, stuck, xref, uref=None, warmU=None):
+    N, NT = qcfg.N, qcfg.NT
+    nm = N * NT
+    H = np.zeros(nm * nm)
+    g = np.zeros(nm)
+    lo = np.zeros(nm)
+    hi = np.zeros(nm)
+    xr = np.ascontiguousarray(np.asarray(xref, float).reshape(9, N + 1).reshape(-1, order="F"))
+    ur = None if uref is None else np.ascontiguousarray(np.asarray(uref, float).reshape(6, N + 1).reshape(-1, order="F"))
+    warm = None if warmU is None else np.ascontiguousarray(warmU, float).reshape(-1)
+    c = make_config(qcfg)
+    f = lib().ftmpc_oracle_build_qp
+    f.restype = C.c_int
+    f.argtypes = [C.POINTER(oracle_config)] + [C.POINTER(C.c_double)] * 10
+    n = f(C.byref(c), _p(np.ascontiguousarray(x0, float)), _p(np.ascontiguousarray(ub, float)),
+          _p(np.ascontiguousarray(stuck, float)), _p(xr), _p(ur), _p(warm), _p(H), _p(g), _p(lo), _p(hi))
+    return H[:n * n].reshape(n, n).copy(), g[:n].copy(), lo[:n].copy(), hi[:n].copy()
+
+
+def plant_step(qcfg, x, u, ub, stuck):
+    c = make_config(qcfg)
+    xn = np.zeros(13)
+    f = lib().ftmpc_oracle_plant_step
+    f.restype = C.c_int
+    f.argtypes = [C.POINTER(oracle_config)] + [C.POINTER(C.c_double)] * 5
+    a = lambda v: np.ascontiguousarray(v, float)
+    xx, uu, bb, ss = a(x), a(u), a(ub), a(stuck)
+    f(C.byref(c), _p(xx), _p(uu), _p(bb), _p(ss), _p(xn))
+    return xn

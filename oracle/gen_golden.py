@@ -1,0 +1,155 @@
+"""Generates tests/golden/*.npz.  Run from the repo root in the BUILD container (needs
+/root/reference):   python -m oracle.gen_golden
+
+Two kinds of fixtures:
+ (1) REFERENCE-DERIVED (pin the oracle): produced by importing the reference modules that
+     import here (ft_mpc.util.get_trajectory, ft_mpc.util.broken_thruster -- plain numpy/scipy)
+     and by reading the reference's DATA files (ft_mpc/config/terminal.yaml,
+     ft_mpc/config/reactive.yaml, data/InertialProperties.md's D table, util/animate.py's thruster
+     geometry table as numbers).  The reference controller itself cannot be imported
+     (casadi/cvxpy/polytope missing: ordinary ModuleNotFoundError).
+ (2) ORACLE-DERIVED (pin the GPU path on the box, where /root/reference does not exist): seeded
+     instances of every BASELINE config with the exact QP solution from scipy BVLS.
+"""
+from __future__ import annotations
+
+import re
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+REF = Path("/root/reference")
+OUT = ROOT / "tests" / "golden"
+
+
+def reference_fixtures():
+    sys.path.insert(0, str(REF))
+    from ft_mpc.util.get_trajectory import load_trajectory  # importable: numpy/scipy/yaml only
+    from ft_mpc.util.broken_thruster import BrokenThruster
+    import yaml
+    from scipy.spatial.transform import Rotation as R
+
+    out = {}
+    # --- trajectories (get_trajectory.py:43-184), dt = 0.1 ---
+    hov = load_trajectory("hover", 0.1, 30)
+    out["hover_shape"] = np.array(hov.shape)
+    out["hover_cols"] = hov[:, [0, 1, 1500, 2999]]
+    h123 = load_trajectory("hover_1_2_3", 0.1, 5)
+    out["hover123_shape"] = np.array(h123.shape)
+    out["hover123_col"] = h123[:, 7]
+    circ = load_trajectory("circle_r_0.65_sPerFullCircle_40", 0.1, 30)
+    out["circle_shape"] = np.array(circ.shape)
+    out["circle_cols"] = circ[:, :64]
+    out["circle_sum"] = np.array([circ.sum(), np.abs(circ).sum()])
+    # --- fault record (broken_thruster.py) ---
+    bt = BrokenThruster(10, 1.0)
+    out["bt"] = np.array([bt.index, bt.intensity])
+    # --- sim.py:49-54 initial condition ---
+    out["ic_quat"] = R.from_euler("zyx", [50, 30, -10], degrees=True).as_quat()
+    # --- reactive.yaml (data) ---
+    ry = yaml.safe_load(open(REF / "ft_mpc/config/reactive.yaml"))
+    sp = ry["tuning"]["spiraling"]
+    out["yaml_dt"] = np.array([ry["time_step"]])
+    out["yaml_horizon"] = np.array([sp["horizon"]])
+    out["yaml_Q"] = np.array(sp[sp["param_set"]]["Q"], float)
+    out["yaml_R"] = np.array(sp[sp["param_set"]]["R"], float)
+    out["yaml_faults"] = np.array([[f["act_id"], f["intensity"], f["start_time"]] for f in ry["actuator_failures"]], float)
+    # --- terminal.yaml (data): cost evaluated with sympy only, set as numbers ---
+    from oracle import refmath as rm
+    cost, P, A, b = rm.parse_terminal_yaml(open(REF / "ft_mpc/config/terminal.yaml").read())
+    pts = np.array([[0] * 9, [0.1] * 9, [.5, -.2, .1, .05, 0, -.05, .1, -.1, .05]], float)
+    out["term_points"] = pts
+    out["term_cost"] = np.array([cost(p) for p in pts])
+    out["term_P"] = P
+    out["term_A"] = A
+    out["term_b"] = b
+    # --- D, three ways: the markdown table (data/InertialProperties.md:30-41) and r x F from
+    #     the geometry table of util/animate.py:66-110 (numbers transcribed by regex, not code) ---
+    md = (REF / "data/InertialProperties.md").read_text()
+    blk = md[md.index("### 3D Spacecraft"):]
+    body = blk[blk.index("smallmatrix}") + 12: blk.index(r"\end{smallmatrix}")]
+    sym = {"a": 0.12, "b": 0.09, "c": 0.05}
+    Dmd = []
+    for line in body.splitlines():
+        ent = [e.strip() for e in line.replace("\\", " ").split("&")]
+        if len(ent) != 16:
+            continue
+        row = []
+        for e in ent:
+            sgn = -1.0 if e.startswith("-") else 1.0
+            key = e.lstrip("-").strip()
+            row.append(sgn * sym[key] if key in sym else float(e))
+        Dmd.append(row)
+    out["D_md"] = np.array(Dmd, float)
+    an = (REF / "ft_mpc/util/animate.py").read_text()
+    dvals = {k: float(v) for k, v in re.findall(r"^\s*(d[1-4]) = ([\d.]+)", an, re.M)}
+
+    def table(name):
+        body = an[an.index(name + " = {"):]
+        body = body[:body.index("}")]
+        res = []
+        for m in re.finditer(r"\d+:\s*\(([^)]*)\)", body):
+            vals = []
+            for tok in m.group(1).split(","):
+                tok = tok.strip()
+                sgn = -1.0 if tok.startswith("-") else 1.0
+                tok = tok.lstrip("-").strip()
+                vals.append(sgn * (dvals[tok] if tok in dvals else float(tok)))
+            res.append(vals)
+        return np.array(res, float)
+
+    pos, dirs = table("thruster_positions"), table("thruster_directions")
+    Dg = np.zeros((6, 16))
+    for i in range(16):
+        f = -dirs[i]  # exhaust direction -> thrust on the body
+        Dg[0:3, i] = f
+        Dg[3:6, i] = np.cross(pos[i], f)
+    out["D_geom"] = Dg
+    np.savez_compressed(OUT / "reference_pins.npz", **out)
+    print("reference_pins.npz:", {k: v.shape for k, v in out.items()})
+
+
+def qp_fixtures():
+    from oracle import qp_oracle as qo
+    from oracle import refmath as rm
+
+    specs = {
+        # name: (N, NT, nfault, seed, count, warm, uref)
+        "cfg2_single_fault": (20, 8, 1, 1002, 16, False, False),
+        "cfg3_double_fault": (20, 8, 2, 1003, 24, False, False),
+        "cfg3_warm_uref": (20, 8, 2, 1013, 8, True, True),
+        "nominal_nt8": (20, 8, 0, 1001, 8, False, False),
+        "short_horizon": (5, 8, 2, 1021, 8, False, False),
+    }
+    for name, (N, NT, nf, seed, cnt, warm, uref) in specs.items():
+        cfg = qo.QPConfig(N=N, NT=NT)
+        x0, ub, stuck, xref = qo.make_batch(cnt, N, NT, nf, seed)
+        rng = np.random.default_rng(seed + 7)
+        W = rng.uniform(-0.3, 3.7, (cnt, N, NT)) if warm else None
+        ur = None
+        if uref:
+            # a circle-like reference window (get_trajectory.py:125-141 shape) for xref/uref
+            traj = rm.circle_trajectory(0.1, 5, radius=0.65, s_per_circle=40.0)
+            xr_all, ur_all = rm.assign_trajectory(traj, N)
+            xref, ur = rm.trajectory_window(xr_all, ur_all, 1.0, N)
+        U = np.zeros((cnt, N, NT))
+        u0 = np.zeros((cnt, NT))
+        kkt = np.zeros(cnt)
+        for b in range(cnt):
+            u0[b], U[b], qp = qo.solve_instance(cfg, x0[b], ub[b], stuck[b], xref, uref=ur,
+                                                warmU=None if W is None else W[b], exact=True)
+            d = U[b][:, qp["act"]].reshape(-1) - qp["Ubar"]
+            kkt[b] = qo.kkt_residual(qp["H"], qp["g"], -qp["Ubar"], qp["ub"] - qp["Ubar"], d)
+        assert kkt.max() < 1e-9, kkt
+        np.savez_compressed(OUT / f"qp_{name}.npz", N=N, NT=NT, x0=x0, ub=ub, stuck=stuck, xref=xref,
+                            uref=np.zeros(0) if ur is None else ur, warm=np.zeros(0) if W is None else W,
+                            U=U, u0=u0, kkt=kkt, D=cfg.D, rho=cfg.rho)
+        print(f"qp_{name}.npz  kkt max {kkt.max():.1e}")
+
+
+if __name__ == "__main__":
+    OUT.mkdir(parents=True, exist_ok=True)
+    reference_fixtures()
+    qp_fixtures()

@@ -49,7 +49,7 @@ class QPConfig:
     r: np.ndarray = field(default_factory=rm.spiral_r)
     f_virt: np.ndarray = field(default_factory=lambda: rm.F_VIRT.copy())
     rho: float = 0.05
-    iters: int = 12
+    iters: int = 16
 
     def __post_init__(self):
         if self.D is None:
@@ -121,16 +121,19 @@ def build_qp(cfg: QPConfig, x0, ub, stuck, xref, uref=None, warmU=None):
                 n=n, na=na, cbar=cbar, A=A, Bg=Bg)
 
 
-def ipm_box(H, g, lo, hi, iters=12, dtype=np.float64, x_init=None, polish=False, trace=None,
-            mu_stop=None):
-    """Fixed-iteration Mehrotra predictor-corrector for
+def ipm_box(H, g, lo, hi, iters=16, dtype=np.float64, polish=False, trace=None, mu_stop=None):
+    """Mehrotra predictor-corrector IPM with an iteration cap for
          min 1/2 d'H d + g'd   s.t.  lo <= d <= hi      (lo < hi componentwise)
-    Slacks s_l = d - lo, s_u = hi - d are carried as state and updated by s += a*ds (never
-    recomputed by subtraction: that cancels catastrophically in fp32); the gradient H d + g
-    is carried the same way through  H dd = rhs - Sig dd  (no H matvec after the start).
-    `dtype` lets tests emulate the kernel's fp32 arithmetic.  This is the algorithm the HIP
-    kernel mirrors step for step (fault-tolerant-mpc_amd/csrc/ftmpc_kernels.hip).
-    Returns (d, z_l, z_u, iterations_run).
+    This is the algorithm the HIP kernel (fault-tolerant-mpc_amd/csrc/ftmpc_solve.hip) and the C
+    oracle (oracle/ftmpc_oracle.c) run, step for step:
+      * start at the box centre, duals on the central path at mu0 = max(|grad|_inf * width / 4, 1e-3)
+      * slacks s_l = d - lo, s_u = hi - d are carried as state (s += a*ds), never recomputed by
+        subtraction; d is read back from the slack of the nearer bound
+      * the gradient H d + g is re-evaluated every iteration with float64 accumulation (in the
+        fp32 kernel this is what bounds the final error by the fp32 representation of H, g)
+      * one Cholesky of H + diag(z_l/s_l + z_u/s_u) per iteration, two solves
+      * stop when the mean complementarity falls below mu_stop
+    `dtype=np.float32` emulates the kernel's arithmetic.  Returns (d, z_l, z_u, iterations).
     """
     T = dtype
     H = H.astype(T)
@@ -138,22 +141,25 @@ def ipm_box(H, g, lo, hi, iters=12, dtype=np.float64, x_init=None, polish=False,
     lo = lo.astype(T)
     hi = hi.astype(T)
     n = g.size
-    d = ((lo + hi) * T(0.5)) if x_init is None else x_init.astype(T)
-    sl = d - lo
-    su = hi - d
-    grad = H @ d + g
-    # duals: start on the central path at mu0, scaled by the gradient
-    mu0 = max(T(np.abs(grad).max()) * T((hi - lo).max()) * T(0.25), T(1e-3))
-    zl = mu0 / sl
-    zu = mu0 / su
-    tau = T(0.995)
+    H64 = H.astype(np.float64)
+    g64 = g.astype(np.float64)
+    sl = (hi - lo) * T(0.5)
+    su = sl.copy()
     if mu_stop is None:
-        mu_stop = 1e-13 if T is np.float64 else 1e-8
+        mu_stop = 1e-13 if T is np.float64 else 1e-10
     mu_stop = T(mu_stop)
+    tau = T(0.995)
     nit = 0
-    for it in range(iters):
+    zl = zu = None
+    for it in range(iters + 1):
+        d = np.where(sl < su, lo + sl, hi - su)
+        grad = (H64 @ d.astype(np.float64) + g64).astype(T)
+        if zl is None:
+            mu0 = max(T(np.abs(grad).max()) * T((hi - lo).max()) * T(0.25), T(1e-3))
+            zl = mu0 / sl
+            zu = mu0 / su
         mu = (sl @ zl + su @ zu) / T(2 * n)
-        if not (mu >= mu_stop):
+        if not (mu >= mu_stop) or it == iters:
             break
         nit += 1
         rd = grad - zl + zu
@@ -177,15 +183,12 @@ def ipm_box(H, g, lo, hi, iters=12, dtype=np.float64, x_init=None, polish=False,
         dzu = (-rcu + zu * dd) / su
         ap = min(T(1), tau * _max_step(sl, dd, su))
         ad = min(T(1), tau * _max_step_dual(zl, dzl, zu, dzu))
-        d = d + ap * dd
         sl = sl + ap * dd
         su = su - ap * dd
-        grad = grad + ap * (rhs - Sig * dd)
         zl = zl + ad * dzl
         zu = zu + ad * dzu
         if trace is not None:
             trace.append((float(mu), float(np.abs(rd).max()), float(ap), float(ad)))
-    # report each coordinate from its nearer bound (the slack there is the accurate quantity)
     d = np.where(sl < su, lo + sl, hi - su)
     if polish:
         d = polish_active_set(H, g, lo, hi, d, sl, su, zl, zu, T)

@@ -1,0 +1,94 @@
+"""CPU: the QP-spec oracle (numpy restatement, C port) against an independent exact solver
+(scipy BVLS) and against the committed golden QP fixtures."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from oracle import qp_oracle as qo
+from oracle import refmath as rm
+
+GOLD = Path(__file__).parent / "golden"
+
+
+def _load(name):
+    d = np.load(GOLD / f"qp_{name}.npz")
+    ur = d["uref"] if d["uref"].size else None
+    W = d["warm"] if d["warm"].size else None
+    return d, ur, W
+
+
+@pytest.mark.parametrize("name", ["cfg2_single_fault", "cfg3_double_fault", "cfg3_warm_uref", "nominal_nt8", "short_horizon"])
+def test_c_oracle_reproduces_golden(name):
+    d, ur, W = _load(name)
+    cfg = qo.QPConfig(N=int(d["N"]), NT=int(d["NT"]))
+    assert np.array_equal(cfg.D, d["D"]) and cfg.rho == float(d["rho"])
+    out = co.solve_batch(cfg, d["x0"], d["ub"], d["stuck"], d["xref"], uref=ur, warmU=W, nthreads=4)
+    assert (out["status"] == 0).all()
+    assert np.abs(out["U"] - d["U"]).max() < 5e-7     # BVLS (1e-15 tol) vs IPM at mu 1e-13
+    assert np.abs(out["u0"] - d["u0"]).max() < 5e-7
+    assert (out["U"][d["ub"][:, None, :].repeat(cfg.N, 1) == 0] == 0).all()
+
+
+def test_numpy_and_c_build_agree_and_are_spd():
+    cfg = qo.QPConfig(N=20, NT=8)
+    x0, ub, stuck, xref = qo.make_batch(4, 20, 8, 2, 77)
+    for b in range(4):
+        qp = qo.build_qp(cfg, x0[b], ub[b], stuck[b], xref)
+        H, g, lo, hi = co.build_qp(cfg, x0[b], ub[b], stuck[b], xref)
+        assert np.abs(H - qp["H"]).max() < 1e-10 * np.abs(H).max()
+        assert np.abs(g - qp["g"]).max() < 1e-10 * max(1, np.abs(g).max())
+        assert np.allclose(H, H.T) and np.linalg.eigvalsh(H).min() >= 2 * cfg.rho * (1 - 1e-9)
+        assert np.array_equal(lo, -qp["Ubar"]) and np.array_equal(hi, qp["ub"] - qp["Ubar"])
+
+
+def test_condensed_model_is_the_linearisation_of_the_rollout():
+    """c_hat = c_bar + Bbar (U - Ubar) must match the nonlinear rollout to second order."""
+    cfg = qo.QPConfig(N=8, NT=8)
+    x0, ub, stuck, xref = qo.make_batch(1, 8, 8, 1, 5)
+    rng = np.random.default_rng(0)
+    W = rng.uniform(0.5, 2.5, (8, 8))
+    cbar, A, Bg, Ubar = qo.linearize(cfg, x0[0], ub[0], stuck[0], W)
+    dU = 1e-4 * rng.standard_normal((8, 8)) * (ub[0] > 0)
+    c2, *_ = qo.linearize(cfg, x0[0], ub[0], stuck[0], Ubar + dU)
+    d = np.zeros(13)
+    for k in range(8):
+        d = A[k] @ d + Bg[k] @ (cfg.D @ dU[k])
+        assert np.abs((c2[k + 1] - cbar[k + 1]) - d).max() < 5e-7
+
+
+def test_ipm_mirror_fp64_equals_bvls_and_fp32_is_within_tolerance():
+    cfg = qo.QPConfig(N=20, NT=8)
+    x0, ub, stuck, xref = qo.make_batch(6, 20, 8, 2, 1003)
+    for b in range(6):
+        qp = qo.build_qp(cfg, x0[b], ub[b], stuck[b], xref)
+        lo, hi = -qp["Ubar"], qp["ub"] - qp["Ubar"]
+        dx = qo.solve_exact(qp["H"], qp["g"], lo, hi)
+        assert qo.kkt_residual(qp["H"], qp["g"], lo, hi, dx) < 1e-9
+        d64, _, _, n64 = qo.ipm_box(qp["H"], qp["g"], lo, hi, iters=40)
+        assert np.abs(d64 - dx).max() < 1e-6
+        d32, _, _, n32 = qo.ipm_box(qp["H"], qp["g"], lo, hi, iters=16, dtype=np.float32)
+        na = qp["na"]
+        assert np.abs(d32 - dx)[:na].max() / rm.F_MAX < 1e-4   # the kernel's arithmetic, stage-0 command
+        assert n32 <= 16
+
+
+def test_no_active_thruster_and_all_faulted_edge_cases():
+    cfg = qo.QPConfig(N=5, NT=8)
+    x0, ub, stuck, xref = qo.make_batch(2, 5, 8, 0, 3)
+    ub[0, :] = 0.0                      # every thruster broken: nothing to optimise
+    stuck[0, :] = 1.0
+    out = co.solve_batch(cfg, x0, ub, stuck, xref)
+    assert (out["u0"][0] == 0).all() and out["iters"][0] == 0 and out["status"][0] == 0
+    assert out["status"][1] == 0 and out["u0"][1].max() <= 3.4 + 1e-12 and out["u0"][1].min() >= 0
+
+
+def test_plant_step_matches_numpy_restatement():
+    cfg = qo.QPConfig(N=5, NT=16)
+    rng = np.random.default_rng(9)
+    fs = rm.FaultState(16).set_fault(10, 1.0).set_fault(11, 0.3)
+    x = rng.standard_normal(13)
+    u = rng.uniform(0, 3.4, 16)
+    ref = rm.rk4(lambda s: rm.plant_dx_dt(s, u, cfg.D, fs.stuck, fs.ub), x)
+    assert np.allclose(co.plant_step(cfg, x, u, fs.ub, fs.stuck), ref, atol=1e-13)

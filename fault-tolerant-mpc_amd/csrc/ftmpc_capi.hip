@@ -53,8 +53,9 @@ struct ftmpc_handle {
     float *d_dbgH = nullptr, *d_dbgv = nullptr;
     // profiling
     bool profiling = false;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // start/stop per kernel slot
     bool ev_valid = false;
+    bool ev_used[4] = {false, false, false, false};
 };
 
 namespace {
@@ -172,12 +173,13 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
     lp.warmU = warmU;
     lp.rec = h->rec;
     const int lin_blocks = (int)((B + 63) / 64);
+    for (bool& u : h->ev_used) u = false;
     if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[0], s));
     hipLaunchKernelGGL(ftmpc::ftmpc_linearize_kernel<float>, dim3(lin_blocks), dim3(64), 0, s, h->dc, lp);
     HIP_TRY(h, hipGetLastError());
     if (h->profiling) {
         HIP_TRY(h, hipEventRecord(h->ev[1], s));
-        HIP_TRY(h, hipEventRecord(h->ev[2], s));
+        h->ev_used[0] = true;
     }
     SolveParams sp;
     sp.B = B;
@@ -194,8 +196,13 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
         sp.nb_lo = 0;
         sp.nb_hi_owner = (h->nb_max <= 8) ? 1 : 0;
         const int grid = (int)std::min<int64_t>(B, h->grid8);
+        if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[2], s));
         hipLaunchKernelGGL(ftmpc::ftmpc_solve_f32_kernel<8>, dim3(grid), dim3(64), 0, s, h->dc, sp);
         HIP_TRY(h, hipGetLastError());
+        if (h->profiling) {
+            HIP_TRY(h, hipEventRecord(h->ev[3], s));
+            h->ev_used[1] = true;
+        }
     }
     if (h->nb_max > 8) {
         sp.hscratch = h->hs10;
@@ -203,13 +210,15 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
         sp.nb_lo = 8;
         sp.nb_hi_owner = 1;
         const int grid = (int)std::min<int64_t>(B, h->grid10);
+        if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[4], s));
         hipLaunchKernelGGL(ftmpc::ftmpc_solve_f32_kernel<10>, dim3(grid), dim3(64), 0, s, h->dc, sp);
         HIP_TRY(h, hipGetLastError());
+        if (h->profiling) {
+            HIP_TRY(h, hipEventRecord(h->ev[5], s));
+            h->ev_used[2] = true;
+        }
     }
-    if (h->profiling) {
-        HIP_TRY(h, hipEventRecord(h->ev[3], s));
-        h->ev_valid = true;
-    }
+    if (h->profiling) h->ev_valid = true;
     return FTMPC_OK;
 }
 
@@ -311,7 +320,7 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
         delete h;
         return fail(nullptr, FTMPC_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
-    for (int i = 0; i < 4; ++i) (void)hipEventCreate(&h->ev[i]);
+    for (int i = 0; i < 8; ++i) (void)hipEventCreate(&h->ev[i]);
     // persistent grids: resident workgroups per CU from the occupancy query (LDS-bound)
     int per8 = 0, per10 = 0;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per8, ftmpc::ftmpc_solve_f32_kernel<8>, 64, 0);
@@ -338,7 +347,7 @@ int ftmpc_destroy(ftmpc_handle* h) {
                     h->d_status, h->d_iters, h->hs8, h->hs10, h->d_dbgH, h->d_dbgv};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 8; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -465,19 +474,22 @@ int ftmpc_set_profiling(ftmpc_handle* h, int32_t enabled) {
     return FTMPC_OK;
 }
 
-int ftmpc_last_kernel_ms(ftmpc_handle* h, float ms[2]) {
+int ftmpc_last_kernel_ms(ftmpc_handle* h, float ms[4]) {
     if (!h || !ms) return FTMPC_ERR_ARG;
     if (!h->ev_valid) return fail(h, FTMPC_ERR_ARG, "no profiled solve recorded");
-    HIP_TRY(h, hipEventSynchronize(h->ev[3]));
-    HIP_TRY(h, hipEventElapsedTime(&ms[0], h->ev[0], h->ev[1]));
-    HIP_TRY(h, hipEventElapsedTime(&ms[1], h->ev[2], h->ev[3]));
+    for (int k = 0; k < 4; ++k) {
+        ms[k] = 0.f;
+        if (!h->ev_used[k]) continue;
+        HIP_TRY(h, hipEventSynchronize(h->ev[2 * k + 1]));
+        HIP_TRY(h, hipEventElapsedTime(&ms[k], h->ev[2 * k], h->ev[2 * k + 1]));
+    }
     return FTMPC_OK;
 }
 
-const char* ftmpc_solve_kernel_name(const ftmpc_handle* h) {
-    if (!h) return "";
-    return h->nb_max > 8 ? "ftmpc_solve_f32_kernel<10>" : "ftmpc_solve_f32_kernel<8>";
-}
+static const char* const k_kernel_names[4] = {"ftmpc_linearize_kernel", "ftmpc_solve_f32_kernel<8>",
+                                              "ftmpc_solve_f32_kernel<10>", "ftmpc_solve_f64_kernel"};
+
+const char* ftmpc_kernel_name(int32_t slot) { return (slot >= 0 && slot < 4) ? k_kernel_names[slot] : ""; }
 
 int ftmpc_debug_build_qp(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, const double* stuck,
                          const double* xref, int64_t xref_stride, const double* uref, int64_t uref_stride,

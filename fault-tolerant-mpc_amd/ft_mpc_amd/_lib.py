@@ -20,7 +20,7 @@ MAX_NT = 16
 SYMBOLS = (
     "ftmpc_default_config", "ftmpc_create", "ftmpc_destroy", "ftmpc_last_error", "ftmpc_reserve",
     "ftmpc_solve_batch", "ftmpc_solve_batch_device", "ftmpc_shift_warm", "ftmpc_set_profiling",
-    "ftmpc_last_kernel_ms", "ftmpc_solve_kernel_name", "ftmpc_debug_build_qp", "ftmpc_version",
+    "ftmpc_last_kernel_ms", "ftmpc_kernel_name", "ftmpc_debug_build_qp", "ftmpc_version",
 )
 
 
@@ -80,13 +80,13 @@ def load_library() -> C.CDLL:
     lib.ftmpc_shift_warm.argtypes = [C.c_int64, C.c_int32, C.c_int32, dp]
     lib.ftmpc_set_profiling.argtypes = [vp, C.c_int32]
     lib.ftmpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
-    lib.ftmpc_solve_kernel_name.argtypes = [vp]
-    lib.ftmpc_solve_kernel_name.restype = C.c_char_p
+    lib.ftmpc_kernel_name.argtypes = [C.c_int32]
+    lib.ftmpc_kernel_name.restype = C.c_char_p
     lib.ftmpc_debug_build_qp.argtypes = [vp, C.c_int64, dp, dp, dp, dp, C.c_int64, dp, C.c_int64, dp, C.c_int64,
                                          dp, C.c_int64, dp, dp, dp, ip]
     lib.ftmpc_version.restype = C.c_int32
     for name in SYMBOLS:
-        if name not in ("ftmpc_last_error", "ftmpc_solve_kernel_name", "ftmpc_version"):
+        if name not in ("ftmpc_last_error", "ftmpc_kernel_name", "ftmpc_version"):
             getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib

@@ -108,9 +108,8 @@ class BatchedMPC:
     def reserve(self, max_batch: int):
         self._check(self.lib.ftmpc_reserve(self._h, int(max_batch)))
 
-    @property
-    def kernel_name(self) -> str:
-        return self.lib.ftmpc_solve_kernel_name(self._h).decode()
+    def kernel_name(self, slot: int) -> str:
+        return self.lib.ftmpc_kernel_name(int(slot)).decode()
 
     # -- host-buffer path ---------------------------------------------------------------
     def _refs(self, B, xref, uref):
@@ -158,9 +157,10 @@ class BatchedMPC:
         self._check(self.lib.ftmpc_set_profiling(self._h, 1 if on else 0))
 
     def last_kernel_ms(self):
-        ms = (C.c_float * 2)()
+        """{kernel name: device ms} of the last profiled solve (kernels that were launched)."""
+        ms = (C.c_float * 4)()
         self._check(self.lib.ftmpc_last_kernel_ms(self._h, ms))
-        return float(ms[0]), float(ms[1])
+        return {self.kernel_name(k): float(ms[k]) for k in range(4) if ms[k] > 0}
 
     # -- test hook ----------------------------------------------------------------------
     def debug_build_qp(self, x0, ub, stuck, xref, inst, uref=None, warmU=None):

@@ -140,12 +140,13 @@ int ftmpc_solve_batch_device(ftmpc_handle* h, int64_t B,
 int ftmpc_shift_warm(int64_t B, int32_t N, int32_t NT, double* warmU);
 
 /* Per-kernel device timing of the LAST solve call, measured with hipEvents on the launch
- * stream when enabled.  ms[0] = linearise kernel, ms[1] = condense+IPM kernel. */
+ * stream when enabled.  ms[slot] is the duration of kernel slot `slot` (0 when that kernel was
+ * not launched); ftmpc_kernel_name(slot) is the kernel's name as it appears in rocprofv3
+ * traces:  0 linearise, 1 condense+IPM fp32 (n<=128), 2 condense+IPM fp32 (n<=160),
+ * 3 condense+IPM fp64 (general n). */
 int ftmpc_set_profiling(ftmpc_handle* h, int32_t enabled);
-int ftmpc_last_kernel_ms(ftmpc_handle* h, float ms[2]);
-
-/* Name of the dominant kernel as it appears in rocprofv3 traces for this handle's shape. */
-const char* ftmpc_solve_kernel_name(const ftmpc_handle* h);
+int ftmpc_last_kernel_ms(ftmpc_handle* h, float ms[4]);
+const char* ftmpc_kernel_name(int32_t slot);
 
 /*
  * Test hook: runs the build for instance `inst` of a host batch and returns the condensed

@@ -22,10 +22,12 @@
 // single translation unit: the kernels are compiled together with their launcher
 #include "ftmpc_linearize.hip"
 #include "ftmpc_solve.hip"
+#include "ftmpc_solve_f64.hip"
 
 using ftmpc::DeviceConsts;
 using ftmpc::LinParams;
 using ftmpc::SolveParams;
+using ftmpc::Solve64Params;
 
 static thread_local std::string g_create_error;
 
@@ -49,6 +51,13 @@ struct ftmpc_handle {
     float* hs8 = nullptr;
     float* hs10 = nullptr;
     int grid8 = 0, grid10 = 0;
+    // float64 general-size path
+    bool use_f64 = false;
+    int npad_max = 0;
+    int grid64 = 0;
+    int64_t tile_doubles = 0, e_doubles = 0;
+    double *Hs = nullptr, *Ls = nullptr, *Eall = nullptr;
+    double *d_dbgH64 = nullptr, *d_dbgv64 = nullptr;
     // debug
     float *d_dbgH = nullptr, *d_dbgv = nullptr;
     // profiling
@@ -111,6 +120,7 @@ int build_consts(const ftmpc_config& c, DeviceConsts& d, std::string& why) {
     d.N = c.N;
     d.NT = c.NT;
     d.max_iters = c.max_iters > 0 ? c.max_iters : 16;
+    if ((c.dtype == FTMPC_DTYPE_F64 || c.N * c.NT > 160) && c.max_iters <= 0) d.max_iters = 30;
     d.dt = c.dt;
     d.inv_mass = 1.0 / c.mass;
     std::memcpy(d.J, c.J, sizeof(d.J));
@@ -144,7 +154,7 @@ int build_consts(const ftmpc_config& c, DeviceConsts& d, std::string& why) {
     for (int i = 0; i < 9; ++i)
         for (int j = 0; j < 9; ++j) d.LPt[9 * i + j] = s2 * L[9 * j + i];  // sqrt(2) L'
     d.rho = c.rho;
-    d.mu_stop = c.mu_stop > 0 ? c.mu_stop : 1e-10;
+    d.mu_stop = c.mu_stop > 0 ? c.mu_stop : ((c.dtype == FTMPC_DTYPE_F64 || c.N * c.NT > 160) ? 1e-13 : 1e-10);
     return FTMPC_OK;
 }
 
@@ -175,7 +185,10 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
     const int lin_blocks = (int)((B + 63) / 64);
     for (bool& u : h->ev_used) u = false;
     if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[0], s));
-    hipLaunchKernelGGL(ftmpc::ftmpc_linearize_kernel<float>, dim3(lin_blocks), dim3(64), 0, s, h->dc, lp);
+    if (h->use_f64)
+        hipLaunchKernelGGL(ftmpc::ftmpc_linearize_kernel<double>, dim3(lin_blocks), dim3(64), 0, s, h->dc, lp);
+    else
+        hipLaunchKernelGGL(ftmpc::ftmpc_linearize_kernel<float>, dim3(lin_blocks), dim3(64), 0, s, h->dc, lp);
     HIP_TRY(h, hipGetLastError());
     if (h->profiling) {
         HIP_TRY(h, hipEventRecord(h->ev[1], s));
@@ -189,6 +202,31 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
     sp.dbg_inst = dbg_inst;
     sp.dbg_H = h->d_dbgH;
     sp.dbg_vec = h->d_dbgv;
+    if (h->use_f64) {
+        Solve64Params q;
+        sp.hscratch = nullptr;
+        sp.tile_words = 0;
+        sp.nb_lo = 0;
+        sp.nb_hi_owner = 1;
+        q.base = sp;
+        q.Hs = h->Hs; q.Ls = h->Ls; q.Eall = h->Eall;
+        q.tile_doubles = h->tile_doubles;
+        q.e_doubles = h->e_doubles;
+        q.npad_max = h->npad_max;
+        q.nb_lo = 0;
+        q.dbg_H = h->d_dbgH64;
+        q.dbg_vec = h->d_dbgv64;
+        const int grid = (int)std::min<int64_t>(B, h->grid64);
+        if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[6], s));
+        hipLaunchKernelGGL(ftmpc::ftmpc_solve_f64_kernel, dim3(grid), dim3(ftmpc::f64k::WG), 0, s, h->dc, q);
+        HIP_TRY(h, hipGetLastError());
+        if (h->profiling) {
+            HIP_TRY(h, hipEventRecord(h->ev[7], s));
+            h->ev_used[3] = true;
+            h->ev_valid = true;
+        }
+        return FTMPC_OK;
+    }
     // NB = 8 instantiation: instances with at most 128 active variables (and the empty ones)
     {
         sp.hscratch = h->hs8;
@@ -257,7 +295,7 @@ int ftmpc_default_config(ftmpc_config* cfg, int32_t N, int32_t NT) {
     cfg->f_virt[1] = 3.5;
     cfg->r[1] = 3.5 / (cfg->mass * 0.6 * 0.6);
     cfg->rho = 0.05;
-    cfg->mu_stop = 1e-10;
+    cfg->mu_stop = 0.0;  /* library default by dtype */
     if (NT == 16) {
         // sys_model.py:73-123 restated from the thruster geometry
         const double d1 = 0.12, d2 = 0.09, d3 = 0.05;
@@ -293,8 +331,8 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
         return fail(nullptr, FTMPC_ERR_HIP, "hipGetDeviceProperties failed");
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(nullptr, FTMPC_ERR_NODEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
-    if (cfg->dtype != FTMPC_DTYPE_F32)
-        return fail(nullptr, FTMPC_ERR_ARG, "only FTMPC_DTYPE_F32 is implemented in this build");
+    if (cfg->dtype != FTMPC_DTYPE_F32 && cfg->dtype != FTMPC_DTYPE_F64)
+        return fail(nullptr, FTMPC_ERR_ARG, "dtype must be FTMPC_DTYPE_F32 or FTMPC_DTYPE_F64");
     ftmpc_handle* h = new (std::nothrow) ftmpc_handle();
     if (!h) return fail(nullptr, FTMPC_ERR_ALLOC, "out of host memory");
     h->cfg = *cfg;
@@ -305,10 +343,14 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
         return fail(nullptr, rc, why);
     }
     h->nb_max = (cfg->N * cfg->NT + 15) / 16;
-    if (h->nb_max > 10) {
+    if (cfg->N * cfg->NT > ftmpc::f64k::NMAX) {
         delete h;
-        return fail(nullptr, FTMPC_ERR_ARG, "N*NT > 160 is not supported by the LDS-resident solve kernel in this build");
+        return fail(nullptr, FTMPC_ERR_ARG, "N*NT > 1024 is not supported");
     }
+    // fp32 LDS-resident kernels cover n <= 160; larger problems and dtype F64 use the float64
+    // workgroup-per-instance kernel
+    h->use_f64 = (cfg->dtype == FTMPC_DTYPE_F64) || h->nb_max > 10;
+    h->npad_max = 16 * h->nb_max;
     h->device = cfg->device_id;
     h->num_cu = prop.multiProcessorCount;
     if (hipSetDevice(h->device) != hipSuccess) {
@@ -329,9 +371,25 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
     if (per10 < 1) per10 = 1;
     h->grid8 = h->num_cu * per8;
     h->grid10 = h->num_cu * per10;
-    if (grow(h, &h->hs8, (int64_t)h->grid8 * tiles_of(8) * 256) != FTMPC_OK ||
-        (h->nb_max > 8 && grow(h, &h->hs10, (int64_t)h->grid10 * tiles_of(10) * 256) != FTMPC_OK) ||
-        grow(h, &h->d_dbgH, 160 * 160) != FTMPC_OK || grow(h, &h->d_dbgv, 3 * 160 + 4) != FTMPC_OK) {
+    int per64 = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per64, ftmpc::ftmpc_solve_f64_kernel, ftmpc::f64k::WG, 0);
+    if (per64 < 1) per64 = 1;
+    if (per64 > 2) per64 = 2;
+    h->grid64 = h->num_cu * per64;
+    h->tile_doubles = (int64_t)tiles_of(h->nb_max) * 256;
+    h->e_doubles = (int64_t)cfg->N * 9 * h->npad_max;
+    bool bad = false;
+    if (h->use_f64) {
+        bad = grow(h, &h->Hs, h->grid64 * h->tile_doubles) != FTMPC_OK || grow(h, &h->Ls, h->grid64 * h->tile_doubles) != FTMPC_OK ||
+              grow(h, &h->Eall, h->grid64 * h->e_doubles) != FTMPC_OK ||
+              grow(h, &h->d_dbgH64, (int64_t)h->npad_max * h->npad_max) != FTMPC_OK ||
+              grow(h, &h->d_dbgv64, 3 * (int64_t)h->npad_max + 4) != FTMPC_OK;
+    } else {
+        bad = grow(h, &h->hs8, (int64_t)h->grid8 * tiles_of(8) * 256) != FTMPC_OK ||
+              (h->nb_max > 8 && grow(h, &h->hs10, (int64_t)h->grid10 * tiles_of(10) * 256) != FTMPC_OK) ||
+              grow(h, &h->d_dbgH, 160 * 160) != FTMPC_OK || grow(h, &h->d_dbgv, 3 * 160 + 4) != FTMPC_OK;
+    }
+    if (bad) {
         g_create_error = h->err;
         ftmpc_destroy(h);
         return FTMPC_ERR_ALLOC;
@@ -344,7 +402,7 @@ int ftmpc_destroy(ftmpc_handle* h) {
     if (!h) return FTMPC_OK;
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->rec, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, h->d_uref, h->d_warm, h->d_u0, h->d_U,
-                    h->d_status, h->d_iters, h->hs8, h->hs10, h->d_dbgH, h->d_dbgv};
+                    h->d_status, h->d_iters, h->hs8, h->hs10, h->d_dbgH, h->d_dbgv, h->Hs, h->Ls, h->Eall, h->d_dbgH64, h->d_dbgv64};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < 8; ++i)
@@ -365,7 +423,7 @@ int ftmpc_reserve(ftmpc_handle* h, int64_t max_batch) {
     float* recf = nullptr;
     if (h->rec) (void)hipFree(h->rec);
     h->rec = nullptr;
-    int rc = grow(h, &recf, B * N * ftmpc::REC_STRIDE);
+    int rc = grow(h, &recf, B * N * ftmpc::REC_STRIDE * (h->use_f64 ? 2 : 1));
     if (rc != FTMPC_OK) return rc;
     h->rec = recf;
     if ((rc = grow(h, &h->d_x0, B * 13)) != FTMPC_OK) return rc;
@@ -507,10 +565,28 @@ int ftmpc_debug_build_qp(ftmpc_handle* h, int64_t B, const double* x0, const dou
     HIP_TRY(h, hipMemcpyAsync(h->d_stuck, stuck, B * NT * sizeof(double), hipMemcpyHostToDevice, s));
     if ((rc = stage_refs(h, B, xref, xref_stride, uref, uref_stride)) != FTMPC_OK) return rc;
     if (warmU) HIP_TRY(h, hipMemcpyAsync(h->d_warm, warmU, B * N * NT * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(h, hipMemsetAsync(h->d_dbgv, 0, (3 * 160 + 4) * sizeof(float), s));
+    if (!h->use_f64) HIP_TRY(h, hipMemsetAsync(h->d_dbgv, 0, (3 * 160 + 4) * sizeof(float), s));
     rc = enqueue(h, B, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, xref_stride, uref ? h->d_uref : nullptr, uref_stride,
                  warmU ? h->d_warm : nullptr, h->d_u0, nullptr, h->d_status, h->d_iters, s, inst);
     if (rc != FTMPC_OK) return rc;
+    if (h->use_f64) {
+        const int64_t pm = h->npad_max;
+        std::vector<double> Hd((size_t)(pm * pm)), vd((size_t)(3 * pm + 4));
+        HIP_TRY(h, hipMemcpyAsync(Hd.data(), h->d_dbgH64, Hd.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipMemcpyAsync(vd.data(), h->d_dbgv64, vd.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+        const int n = (int)vd[3 * pm], npad = (int)vd[3 * pm + 1];
+        if (n <= 0) return fail(h, FTMPC_ERR_ARG, "instance has no active thruster or was not dumped");
+        if ((int64_t)n * n > H_cap) return fail(h, FTMPC_ERR_ARG, "H buffer too small");
+        for (int i = 0; i < n; ++i) {
+            for (int j = 0; j < n; ++j) H[(int64_t)i * n + j] = Hd[(size_t)i * npad + j];
+            g[i] = vd[i];
+            lo[i] = vd[pm + i];
+            hi[i] = vd[2 * pm + i];
+        }
+        *n_out = n;
+        return FTMPC_OK;
+    }
     std::vector<float> Hf(160 * 160), vf(3 * 160 + 4);
     HIP_TRY(h, hipMemcpyAsync(Hf.data(), h->d_dbgH, Hf.size() * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipMemcpyAsync(vf.data(), h->d_dbgv, vf.size() * sizeof(float), hipMemcpyDeviceToHost, s));

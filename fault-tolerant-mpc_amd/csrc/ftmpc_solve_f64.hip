@@ -1,0 +1,672 @@
+// ftmpc_solve_f64.hip -- kernel 3: condensed-QP build + primal-dual IPM in float64 for ANY
+// problem size (n = N * #healthy thrusters up to 1024), e.g. the reference's own 16-thruster
+// vehicle at its shipped horizon (N=15: n=240) and BASELINE config 5 (N=40, NT=16, "fp64 KKT").
+//
+// The KKT matrix no longer fits LDS (n=640 fp64: 1.6 MB), so ONE WORKGROUP (4 wavefronts) owns
+// an instance and its 16x16-tiled Hessian / factor live in a per-workgroup global slot (L2 /
+// Infinity-Cache resident; MI355X has 288 GB of HBM so slots are simply preallocated per
+// resident workgroup).  Same algorithm as ftmpc_solve.hip / oracle/qp_oracle.py:ipm_box:
+//   1. condense: one column of G per THREAD, E_k = sqrt(2 W_k) G_k[0:9] panels -> global
+//   2. H tiles = sum_k E_k' E_k on v_mfma_f64_16x16x4_f64, tiles distributed over the waves
+//   3. Mehrotra IPM: left-looking blocked Cholesky (tile GEMMs on f64 MFMA, diagonal tiles
+//      factorised + inverted in registers), blocked triangular solves, float64 throughout.
+// Reference path replaced: ft_mpc/controllers/spiraling_mpc.py:87-238,319-354 (NLP + IPOPT) and
+// controllers/tools/control_allocator.py:65-94 (see DESIGN.md QP-spec).
+#include <hip/hip_runtime.h>
+
+#include "ftmpc_common.h"
+
+namespace ftmpc {
+
+namespace f64k {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WG = 256;       // threads per workgroup
+constexpr int NWAVE = 4;
+constexpr int NVT = 4;        // columns per thread (n <= 1024)
+constexpr int NMAX = WG * NVT;
+
+// operand layout of a 16x16 tile in global memory: the four k-steps a lane needs are contiguous
+__device__ __forceinline__ int t64off(int r, int c) { return 16 * r + 4 * (c & 3) + (c >> 2); }
+__device__ __forceinline__ int v64pos(int c) { return (c & 3) * 4 + (c >> 2); }
+__device__ __forceinline__ int t64idx(int I, int J) { return (I * (I + 1)) / 2 + J; }
+
+__device__ __forceinline__ double readlane_d(double x, int l) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double quad_sum64(double x) {
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    return x;
+}
+__device__ __forceinline__ f64x4 mfma(double a, double b, f64x4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// workgroup reductions through LDS (red: NWAVE doubles)
+__device__ __forceinline__ double wg_sum(double x, double* red, int tid) {
+    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = x;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ double wg_min(double x, double* red, int tid) {
+    for (int m = 32; m >= 1; m >>= 1) x = fmin(x, __shfl_xor(x, m, 64));
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = x;
+    __syncthreads();
+    return fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+}
+__device__ __forceinline__ double wg_max(double x, double* red, int tid) {
+    for (int m = 32; m >= 1; m >>= 1) x = fmax(x, __shfl_xor(x, m, 64));
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = x;
+    __syncthreads();
+    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// 16x16 Cholesky + inverse in registers (one row per lane, see ftmpc_solve.hip potrf_inv16)
+__device__ __forceinline__ bool potrf_inv16_f64(const double* S, int li, double w[16]) {
+    double a[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = S[li * 17 + k];
+    double invs[16];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double djj = readlane_d(a[j], j);
+        ok = ok && (djj > 0.0);
+        const double inv = 1.0 / sqrt(djj);
+        invs[j] = inv;
+        a[j] *= inv;
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) a[k] -= a[j] * readlane_d(a[j], k);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        double s = (i == li) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= readlane_d(a[k], i) * w[k];
+        w[i] = s * invs[i];
+    }
+    return ok;
+}
+
+__device__ __forceinline__ f64x4 ld4(const double* p) { return *reinterpret_cast<const f64x4*>(p); }
+
+}  // namespace f64k
+
+struct Solve64Params {
+    SolveParams base;     // rec is double here; hscratch unused
+    double* Hs;           // [grid][tile_doubles]   Hessian tiles
+    double* Ls;           // [grid][tile_doubles]   KKT factor tiles
+    double* Eall;         // [grid][N*9*npad_max]   E panels of every stage
+    int64_t tile_doubles;
+    int64_t e_doubles;
+    int32_t npad_max;
+    int32_t nb_lo;        // instances with ceil(n/16) <= nb_lo belong to the fp32 kernels
+    double* dbg_H;        // [npad*npad] or nullptr
+    double* dbg_vec;      // [3*npad_max + 4]
+};
+
+__global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const DeviceConsts C, const Solve64Params Q) {
+    using namespace f64k;
+    const SolveParams& P = Q.base;
+    __shared__ double recbuf[REC_STRIDE];
+    __shared__ double dv[NMAX];        // d (permuted per 16-block) for the gradient mat-vec
+    __shared__ double xv[NMAX];        // rhs / solution of the KKT solves (permuted)
+    __shared__ double part[NWAVE * 16];
+    __shared__ double Sbuf[16 * 17];
+    __shared__ double red[NWAVE];
+    __shared__ float s_Da[6 * MAX_NT];
+    __shared__ double s_MR[MAX_NT * MAX_NT];
+    __shared__ unsigned char s_stg[NMAX], s_thr[NMAX];
+    __shared__ int s_act[MAX_NT];
+    __shared__ int s_flag;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int N = C.N, NT = C.NT;
+    const double rho = C.rho;
+
+    double* Hs = Q.Hs + (int64_t)blockIdx.x * Q.tile_doubles;
+    double* Ls = Q.Ls + (int64_t)blockIdx.x * Q.tile_doubles;
+    double* Eall = Q.Eall + (int64_t)blockIdx.x * Q.e_doubles;
+
+    for (int64_t inst = blockIdx.x; inst < P.B; inst += gridDim.x) {
+        __syncthreads();
+        // ---------------- prologue ----------------
+        if (tid == 0) {
+            int na0 = 0;
+            for (int i = 0; i < NT; ++i)
+                if (P.ub[inst * NT + i] > 0.0) s_act[na0++] = i;
+            s_flag = na0;
+        }
+        __syncthreads();
+        const int na = s_flag;
+        const int n = N * na;
+        const int nb = (n + 15) >> 4;
+        const int npad = nb * 16;
+        if (nb <= Q.nb_lo && na != 0) continue;   // the fp32 LDS kernels own this instance
+        if (na == 0 && Q.nb_lo != 0) continue;    // ... including the empty ones
+        if (na == 0 || npad > Q.npad_max) {
+            for (int i = tid; i < NT; i += WG) P.out_u0[inst * NT + i] = 0.0;
+            if (P.out_U)
+                for (int i = tid; i < N * NT; i += WG) P.out_U[inst * (int64_t)N * NT + i] = 0.0;
+            if (tid == 0) {
+                if (P.status) P.status[inst] = (na == 0) ? 0 : 2;
+                if (P.iters) P.iters[inst] = 0;
+            }
+            continue;
+        }
+        if (tid < 6 * MAX_NT) {
+            const int g = tid / MAX_NT, a = tid % MAX_NT;
+            s_Da[tid] = (a < na) ? (float)C.D[g * MAX_NT + s_act[a]] : 0.f;
+        }
+        for (int e = tid; e < npad; e += WG) {
+            const int s = e / na;
+            s_stg[e] = (unsigned char)(e < n ? s : 255);
+            s_thr[e] = (unsigned char)(e < n ? e - s * na : 255);
+        }
+        __syncthreads();
+        if (tid < na * na) {
+            const int a = tid / na, b = tid % na;
+            double t = 0.0;
+            for (int g = 0; g < 6; ++g) t += C.D[g * MAX_NT + s_act[a]] * C.R[g] * C.D[g * MAX_NT + s_act[b]];
+            s_MR[a * MAX_NT + b] = 2.0 * (t + (a == b ? rho : 0.0));
+        }
+        const double* recg = reinterpret_cast<const double*>(P.rec) + inst * (int64_t)N * REC_STRIDE;
+
+        int kcol[NVT], acol[NVT];
+        double ubar[NVT], ubv[NVT], gacc[NVT];
+        double G[13][NVT];
+#pragma unroll
+        for (int v = 0; v < NVT; ++v) {
+            const int e = v * WG + tid;
+            kcol[v] = (e < npad) ? s_stg[e] : 255;
+            acol[v] = (e < npad) ? s_thr[e] : 255;
+            ubar[v] = 0.0;
+            ubv[v] = 1.0;
+            gacc[v] = 0.0;
+            if (kcol[v] != 255) {
+                const int t = s_act[acol[v]];
+                ubv[v] = P.ub[inst * NT + t];
+                if (P.warmU) ubar[v] = fmin(fmax(P.warmU[(inst * N + kcol[v]) * NT + t], 0.0), ubv[v]);
+            }
+#pragma unroll
+            for (int r = 0; r < 13; ++r) G[r][v] = 0.0;
+        }
+
+        // ---------------- phase 1: condense, E panels of every stage -> global ----------------
+        for (int k = 0; k < N; ++k) {
+            __syncthreads();
+            if (tid < REC_STRIDE) recbuf[tid] = recg[k * REC_STRIDE + tid];
+            __syncthreads();
+            const double* rb = recbuf;
+            const bool terminal = (k + 1 == N);
+#pragma unroll
+            for (int v = 0; v < NVT; ++v) {
+                const int e = v * WG + tid;
+                if (e >= npad) continue;
+                if (kcol[v] < k) {
+                    double p[3], vv[3], w[3], q[4];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        p[a] = G[a][v] + C.dt * G[3 + a][v];
+                        vv[a] = G[3 + a][v];
+                        w[a] = 0.0;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            p[a] += rb[REC_APW + 3 * a + c] * G[6 + c][v];
+                            vv[a] += rb[REC_AVW + 3 * a + c] * G[6 + c][v];
+                            w[a] += rb[REC_AWW + 3 * a + c] * G[6 + c][v];
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            p[a] += rb[REC_APQ + 4 * a + c] * G[9 + c][v];
+                            vv[a] += rb[REC_AVQ + 4 * a + c] * G[9 + c][v];
+                        }
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        q[a] = 0.0;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) q[a] += rb[REC_AQW + 3 * a + c] * G[6 + c][v];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) q[a] += rb[REC_AQQ + 4 * a + c] * G[9 + c][v];
+                    }
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        G[a][v] = p[a];
+                        G[3 + a][v] = vv[a];
+                        G[6 + a][v] = w[a];
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) G[9 + a][v] = q[a];
+                } else if (kcol[v] == k) {
+                    double F[3], T[3];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        F[a] = C.D[a * MAX_NT + s_act[acol[v]]];
+                        T[a] = C.D[(3 + a) * MAX_NT + s_act[acol[v]]];
+                    }
+                    double gr = 0.0;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) gr += F[a] * rb[REC_RUT + a] + T[a] * rb[REC_RUT + 3 + a];
+                    gacc[v] += gr;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        double sp = 0.0, sv = 0.0, sw = 0.0;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            sp += rb[REC_BPF + 3 * a + c] * F[c] + rb[REC_BPT + 3 * a + c] * T[c];
+                            sv += rb[REC_BVF + 3 * a + c] * F[c] + rb[REC_BVT + 3 * a + c] * T[c];
+                            sw += rb[REC_BWT + 3 * a + c] * T[c];
+                        }
+                        G[a][v] = sp;
+                        G[3 + a][v] = sv;
+                        G[6 + a][v] = sw;
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        double sq = 0.0;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) sq += rb[REC_BQT + 3 * a + c] * T[c];
+                        G[9 + a][v] = sq;
+                    }
+                }
+                double gs = 0.0;
+#pragma unroll
+                for (int r = 0; r < 9; ++r) gs += G[r][v] * rb[REC_WE + r];
+                gacc[v] += gs;
+                double* Ek = Eall + (int64_t)k * 9 * npad;
+                if (!terminal) {
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) Ek[r * npad + e] = C.sq2Q[r] * G[r][v];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) {
+                        double s = 0.0;
+#pragma unroll
+                        for (int c = r; c < 9; ++c) s += C.LPt[9 * r + c] * G[c][v];
+                        Ek[r * npad + e] = s;
+                    }
+                }
+            }
+        }
+        __syncthreads();  // E panels visible to the whole workgroup
+
+        // ---------------- phase 2: H tiles on f64 MFMA (tiles round-robin over the waves) ----------------
+        const int ntl = (nb * (nb + 1)) / 2;
+        for (int t = wave; t < ntl; t += NWAVE) {
+            int I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+            while (t64idx(I + 1, 0) <= t) ++I;
+            while (t64idx(I, 0) > t) --I;
+            const int J = t - t64idx(I, 0);
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+            const int kstart = (16 * I) / na < N ? (16 * I) / na : N;
+            for (int k = kstart; k < N; ++k) {
+                const double* Ek = Eall + (int64_t)k * 9 * npad;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const int r = 4 * s + lq;
+                    const double a = (r < 9) ? Ek[r * npad + 16 * I + li] : 0.0;
+                    const double b = (r < 9) ? Ek[r * npad + 16 * J + li] : 0.0;
+                    acc = mfma(a, b, acc);
+                }
+            }
+            // + 2 (Da' R Da + rho I) on same-stage pairs; unit diagonal on the padding
+            const int e2 = 16 * J + li;
+            const int s2 = s_stg[e2], a2 = s_thr[e2];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = lq + 4 * rr;      // f64 MFMA C/D layout: row = (lane>>4) + 4*reg
+                const int e1 = 16 * I + row;
+                const int s1 = s_stg[e1], a1 = s_thr[e1];
+                double add = 0.0;
+                if (s1 != 255 && s1 == s2) add = s_MR[a1 * MAX_NT + a2];
+                if (s1 == 255 && e1 == e2) add = 1.0;
+                Hs[(int64_t)t * 256 + t64off(row, li)] = acc[rr] + add;
+            }
+        }
+        __syncthreads();
+        if (P.dbg_inst == inst && Q.dbg_H) {
+            for (int t = wave; t < ntl; t += NWAVE) {
+                int I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+                while (t64idx(I + 1, 0) <= t) ++I;
+                while (t64idx(I, 0) > t) --I;
+                const int J = t - t64idx(I, 0);
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int row = lq + 4 * rr;
+                    const int e1 = 16 * I + row, e2 = 16 * J + li;
+                    const double h = Hs[(int64_t)t * 256 + t64off(row, li)];
+                    if (I != J || e1 >= e2) {
+                        Q.dbg_H[(int64_t)e1 * npad + e2] = h;
+                        Q.dbg_H[(int64_t)e2 * npad + e1] = h;
+                    }
+                }
+            }
+        }
+
+        double gv[NVT], lo[NVT], hi[NVT], sl[NVT], su[NVT], zl[NVT], zu[NVT], grad[NVT];
+        bool valid[NVT];
+#pragma unroll
+        for (int v = 0; v < NVT; ++v) {
+            valid[v] = kcol[v] != 255;
+            gv[v] = valid[v] ? 2.0 * (gacc[v] + rho * ubar[v]) : 0.0;
+            lo[v] = -ubar[v];
+            hi[v] = ubv[v] - ubar[v];
+            sl[v] = su[v] = 0.5 * ubv[v];
+            grad[v] = 0.0;
+            zl[v] = zu[v] = 0.0;
+            if (P.dbg_inst == inst && Q.dbg_vec) {
+                const int e = v * WG + tid;
+                if (e < npad) {
+                    Q.dbg_vec[e] = gv[v];
+                    Q.dbg_vec[Q.npad_max + e] = lo[v];
+                    Q.dbg_vec[2 * Q.npad_max + e] = hi[v];
+                }
+                if (tid == 0 && v == 0) {
+                    Q.dbg_vec[3 * Q.npad_max] = (double)n;
+                    Q.dbg_vec[3 * Q.npad_max + 1] = (double)npad;
+                }
+            }
+        }
+
+        // ---------------- interior-point iterations ----------------
+        int status = 1, nit = 0;
+        bool first = true;
+        const double inv2n = 1.0 / (double)(2 * n);
+        for (int it = 0; it <= C.max_iters; ++it) {
+            __syncthreads();
+#pragma unroll
+            for (int v = 0; v < NVT; ++v) {
+                const int e = v * WG + tid;
+                if (e < npad) dv[16 * (e >> 4) + v64pos(e & 15)] = valid[v] ? ((sl[v] < su[v]) ? lo[v] + sl[v] : hi[v] - su[v]) : 0.0;
+            }
+            __syncthreads();
+            // gradient H d + g: block rows round-robin over the waves, result via xv
+            for (int I = wave; I < nb; I += NWAVE) {
+                double a = 0.0;
+                for (int J = 0; J < nb; ++J) {
+                    if (J <= I) {
+                        const f64x4 t4 = ld4(Hs + (int64_t)t64idx(I, J) * 256 + 16 * li + 4 * lq);
+                        const double* d4 = dv + 16 * J + 4 * lq;
+                        a += t4.x * d4[0] + t4.y * d4[1] + t4.z * d4[2] + t4.w * d4[3];
+                    } else {
+                        const double* t = Hs + (int64_t)t64idx(J, I) * 256;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) a += t[t64off(4 * lq + rr, li)] * dv[16 * J + rr * 4 + lq];
+                    }
+                }
+                a = quad_sum64(a);
+                if (lq == 0) xv[16 * I + li] = a;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int v = 0; v < NVT; ++v) {
+                const int e = v * WG + tid;
+                grad[v] = (e < npad && valid[v]) ? xv[e] + gv[v] : 0.0;
+            }
+            if (first) {
+                double gm = 0.0, wm = 0.0;
+#pragma unroll
+                for (int v = 0; v < NVT; ++v)
+                    if (valid[v]) {
+                        gm = fmax(gm, fabs(grad[v]));
+                        wm = fmax(wm, ubv[v]);
+                    }
+                gm = wg_max(gm, red, tid);
+                wm = wg_max(wm, red, tid);
+                const double mu0 = fmax(0.25 * gm * wm, 1e-3);
+#pragma unroll
+                for (int v = 0; v < NVT; ++v) {
+                    zl[v] = valid[v] ? mu0 / sl[v] : 0.0;
+                    zu[v] = valid[v] ? mu0 / su[v] : 0.0;
+                }
+                first = false;
+            }
+            double t = 0.0;
+#pragma unroll
+            for (int v = 0; v < NVT; ++v)
+                if (valid[v]) t += sl[v] * zl[v] + su[v] * zu[v];
+            const double mu = wg_sum(t, red, tid) * inv2n;
+            if (!(mu >= C.mu_stop)) {
+                status = (mu == mu) ? 0 : 2;
+                break;
+            }
+            if (it == C.max_iters) break;
+            ++nit;
+            // KKT matrix into the factor slot: L <- H, diagonal += Sigma
+            __syncthreads();
+            for (int64_t i = tid; i < (int64_t)ntl * 64; i += WG)
+                *reinterpret_cast<f64x4*>(Ls + 4 * i) = ld4(Hs + 4 * i);
+            __syncthreads();
+            double Sig[NVT];
+#pragma unroll
+            for (int v = 0; v < NVT; ++v) {
+                Sig[v] = valid[v] ? zl[v] / sl[v] + zu[v] / su[v] : 0.0;
+                const int e = v * WG + tid;
+                if (e < npad) {
+                    const int I = e >> 4, r = e & 15;
+                    Ls[(int64_t)t64idx(I, I) * 256 + t64off(r, r)] += Sig[v];
+                }
+            }
+            __syncthreads();
+            // ---- blocked left-looking Cholesky; block rows round-robin over the waves ----
+            if (tid == 0) s_flag = 1;
+            for (int J = 0; J < nb; ++J) {
+                __syncthreads();
+                for (int I = J + wave; I < nb; I += NWAVE) {
+                    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+                    const double* rowI = Ls + (int64_t)t64idx(I, 0) * 256 + 16 * li + 4 * lq;
+                    const double* rowJ = Ls + (int64_t)t64idx(J, 0) * 256 + 16 * li + 4 * lq;
+                    int K = 0;
+                    for (; K + 1 < J; K += 2) {   // two tile pairs in flight
+                        const f64x4 a0 = ld4(rowI + K * 256), b0 = ld4(rowJ + K * 256);
+                        const f64x4 a1 = ld4(rowI + (K + 1) * 256), b1 = ld4(rowJ + (K + 1) * 256);
+                        acc = mfma(a0.x, b0.x, acc); acc = mfma(a0.y, b0.y, acc);
+                        acc = mfma(a0.z, b0.z, acc); acc = mfma(a0.w, b0.w, acc);
+                        acc = mfma(a1.x, b1.x, acc); acc = mfma(a1.y, b1.y, acc);
+                        acc = mfma(a1.z, b1.z, acc); acc = mfma(a1.w, b1.w, acc);
+                    }
+                    for (; K < J; ++K) {
+                        const f64x4 a0 = ld4(rowI + K * 256), b0 = ld4(rowJ + K * 256);
+                        acc = mfma(a0.x, b0.x, acc); acc = mfma(a0.y, b0.y, acc);
+                        acc = mfma(a0.z, b0.z, acc); acc = mfma(a0.w, b0.w, acc);
+                    }
+                    double* tij = Ls + (int64_t)t64idx(I, J) * 256;
+                    double c[4];
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) c[rr] = tij[t64off(lq + 4 * rr, li)] - acc[rr];
+                    if (I == J) {   // wave 0 only (I = J + wave)
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) Sbuf[(lq + 4 * rr) * 17 + li] = c[rr];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        double w[16];
+                        const bool ok = potrf_inv16_f64(Sbuf, li, w);
+                        if (!ok && lane == 0) s_flag = 0;
+                        if (lq == 0) {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) tij[t64off(i, li)] = w[i];
+                        }
+                    } else {
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) tij[t64off(lq + 4 * rr, li)] = c[rr];
+                    }
+                }
+                __syncthreads();
+                const f64x4 w4 = ld4(Ls + (int64_t)t64idx(J, J) * 256 + 16 * li + 4 * lq);
+                for (int I = J + wave; I < nb; I += NWAVE) {   // same wave that produced C_IJ
+                    if (I == J) continue;
+                    double* tij = Ls + (int64_t)t64idx(I, J) * 256;
+                    const f64x4 a4 = ld4(tij + 16 * li + 4 * lq);
+                    f64x4 x = {0.0, 0.0, 0.0, 0.0};
+                    x = mfma(a4.x, w4.x, x); x = mfma(a4.y, w4.y, x);
+                    x = mfma(a4.z, w4.z, x); x = mfma(a4.w, w4.w, x);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    __builtin_amdgcn_wave_barrier();   // the whole wave has read C_IJ before it is overwritten
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) tij[t64off(lq + 4 * rr, li)] = x[rr];
+                }
+            }
+            __syncthreads();
+            if (s_flag == 0) {
+                status = 2;
+                break;
+            }
+
+            // ---- two KKT solves ----
+            auto solve = [&]() {
+                const int myp = v64pos(li);
+                for (int J = 0; J < nb; ++J) {   // forward
+                    double p = 0.0;
+                    for (int K = wave; K < J; K += NWAVE) {
+                        const f64x4 t4 = ld4(Ls + (int64_t)t64idx(J, K) * 256 + 16 * li + 4 * lq);
+                        const double* y4 = xv + 16 * K + 4 * lq;
+                        p += t4.x * y4[0] + t4.y * y4[1] + t4.z * y4[2] + t4.w * y4[3];
+                    }
+                    p = quad_sum64(p);
+                    if (lq == 0) part[wave * 16 + li] = p;
+                    __syncthreads();
+                    if (wave == 0) {
+                        const double r = xv[16 * J + myp] - (part[li] + part[16 + li] + part[32 + li] + part[48 + li]);
+                        const f64x4 w4 = ld4(Ls + (int64_t)t64idx(J, J) * 256 + 16 * li + 4 * lq);
+                        double y = w4.x * __shfl(r, lq, 64) + w4.y * __shfl(r, 4 + lq, 64) + w4.z * __shfl(r, 8 + lq, 64) +
+                                   w4.w * __shfl(r, 12 + lq, 64);
+                        y = quad_sum64(y);
+                        if (lq == 0) xv[16 * J + myp] = y;
+                    }
+                    __syncthreads();
+                }
+                for (int J = nb - 1; J >= 0; --J) {   // backward
+                    double p = 0.0;
+                    for (int I = J + 1 + wave; I < nb; I += NWAVE) {
+                        const double* t = Ls + (int64_t)t64idx(I, J) * 256;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) p += t[t64off(4 * lq + rr, li)] * xv[16 * I + rr * 4 + lq];
+                    }
+                    p = quad_sum64(p);
+                    if (lq == 0) part[wave * 16 + li] = p;
+                    __syncthreads();
+                    if (wave == 0) {
+                        const double r = xv[16 * J + myp] - (part[li] + part[16 + li] + part[32 + li] + part[48 + li]);
+                        const double* t = Ls + (int64_t)t64idx(J, J) * 256;
+                        double x = 0.0;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) x += t[t64off(4 * lq + rr, li)] * __shfl(r, 4 * lq + rr, 64);
+                        x = quad_sum64(x);
+                        if (lq == 0) xv[16 * J + myp] = x;
+                    }
+                    __syncthreads();
+                }
+            };
+#pragma unroll
+            for (int v = 0; v < NVT; ++v) {
+                const int e = v * WG + tid;
+                if (e < npad) xv[16 * (e >> 4) + v64pos(e & 15)] = -grad[v];
+            }
+            __syncthreads();
+            solve();
+            double da[NVT], dzl_a[NVT], dzu_a[NVT];
+            double ap = 1.0, ad = 1.0;
+#pragma unroll
+            for (int v = 0; v < NVT; ++v) {
+                const int e = v * WG + tid;
+                da[v] = (e < npad && valid[v]) ? xv[16 * (e >> 4) + v64pos(e & 15)] : 0.0;
+                dzl_a[v] = dzu_a[v] = 0.0;
+                if (valid[v]) {
+                    dzl_a[v] = -zl[v] - zl[v] * da[v] / sl[v];
+                    dzu_a[v] = -zu[v] + zu[v] * da[v] / su[v];
+                    if (da[v] < 0.0) ap = fmin(ap, -sl[v] / da[v]);
+                    if (da[v] > 0.0) ap = fmin(ap, su[v] / da[v]);
+                    if (dzl_a[v] < 0.0) ad = fmin(ad, -zl[v] / dzl_a[v]);
+                    if (dzu_a[v] < 0.0) ad = fmin(ad, -zu[v] / dzu_a[v]);
+                }
+            }
+            ap = wg_min(ap, red, tid);
+            ad = wg_min(ad, red, tid);
+            t = 0.0;
+#pragma unroll
+            for (int v = 0; v < NVT; ++v)
+                if (valid[v]) t += (sl[v] + ap * da[v]) * (zl[v] + ad * dzl_a[v]) + (su[v] - ap * da[v]) * (zu[v] + ad * dzu_a[v]);
+            const double mu_aff = wg_sum(t, red, tid) * inv2n;
+            double sigma = mu_aff / mu;
+            sigma = fmin(fmax(sigma * sigma * sigma, 0.0), 1.0);
+            double rcl[NVT], rcu[NVT];
+            __syncthreads();
+#pragma unroll
+            for (int v = 0; v < NVT; ++v) {
+                rcl[v] = rcu[v] = 0.0;
+                double rhs = 0.0;
+                if (valid[v]) {
+                    rcl[v] = sl[v] * zl[v] + da[v] * dzl_a[v] - sigma * mu;
+                    rcu[v] = su[v] * zu[v] - da[v] * dzu_a[v] - sigma * mu;
+                    rhs = -(grad[v] - zl[v] + zu[v]) - rcl[v] / sl[v] + rcu[v] / su[v];
+                }
+                const int e = v * WG + tid;
+                if (e < npad) xv[16 * (e >> 4) + v64pos(e & 15)] = rhs;
+            }
+            __syncthreads();
+            solve();
+            double dd[NVT], dzl[NVT], dzu[NVT];
+            ap = 1e300;
+            ad = 1e300;
+#pragma unroll
+            for (int v = 0; v < NVT; ++v) {
+                const int e = v * WG + tid;
+                dd[v] = (e < npad && valid[v]) ? xv[16 * (e >> 4) + v64pos(e & 15)] : 0.0;
+                dzl[v] = dzu[v] = 0.0;
+                if (valid[v]) {
+                    dzl[v] = (-rcl[v] - zl[v] * dd[v]) / sl[v];
+                    dzu[v] = (-rcu[v] + zu[v] * dd[v]) / su[v];
+                    if (dd[v] < 0.0) ap = fmin(ap, -sl[v] / dd[v]);
+                    if (dd[v] > 0.0) ap = fmin(ap, su[v] / dd[v]);
+                    if (dzl[v] < 0.0) ad = fmin(ad, -zl[v] / dzl[v]);
+                    if (dzu[v] < 0.0) ad = fmin(ad, -zu[v] / dzu[v]);
+                }
+            }
+            ap = fmin(1.0, 0.995 * wg_min(ap, red, tid));
+            ad = fmin(1.0, 0.995 * wg_min(ad, red, tid));
+#pragma unroll
+            for (int v = 0; v < NVT; ++v)
+                if (valid[v]) {
+                    sl[v] += ap * dd[v];
+                    su[v] -= ap * dd[v];
+                    zl[v] += ad * dzl[v];
+                    zu[v] += ad * dzu[v];
+                }
+        }
+
+        // ---------------- outputs ----------------
+        __syncthreads();
+        double* ubuf = dv;  // N*NT <= 1024 doubles
+        for (int i = tid; i < N * NT; i += WG) ubuf[i] = 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < NVT; ++v)
+            if (valid[v]) {
+                double u = (sl[v] < su[v]) ? sl[v] : ubv[v] - su[v];
+                if (status == 2) u = ubar[v];
+                ubuf[kcol[v] * NT + s_act[acol[v]]] = u;
+            }
+        __syncthreads();
+        if (tid < NT) P.out_u0[inst * NT + tid] = ubuf[tid];
+        if (P.out_U)
+            for (int i = tid; i < N * NT; i += WG) P.out_U[inst * (int64_t)N * NT + i] = ubuf[i];
+        if (tid == 0) {
+            if (P.status) P.status[inst] = status;
+            if (P.iters) P.iters[inst] = nit;
+        }
+    }
+}
+
+}  // namespace ftmpc

@@ -33,8 +33,9 @@ class MPCConfig:
     f_virt: np.ndarray = field(default_factory=lambda: np.array([0.0, 3.5, 0.0]))
     rho: float = 0.05
     max_iters: int = 16
-    mu_stop: float = 1e-10
+    mu_stop: float = 0.0          # <= 0: library default (1e-10 for f32, 1e-13 for f64)
     device_id: int = 0
+    dtype: str = "f32"            # arithmetic of the KKT/IPM solve: "f32" | "f64" (N*NT > 160 always runs f64)
 
 
 def _ptr(a, ct=C.c_double):
@@ -62,6 +63,9 @@ class BatchedMPC:
             raise _lib.FtmpcError(rc, "bad N/NT")
         c.dt, c.mass, c.rho, c.mu_stop = cfg.dt, cfg.mass, cfg.rho, cfg.mu_stop
         c.max_iters, c.device_id = cfg.max_iters, cfg.device_id
+        if cfg.dtype not in ("f32", "f64"):
+            raise ValueError("dtype must be 'f32' or 'f64'")
+        c.dtype = 1 if cfg.dtype == "f64" else 0
         c.J[:] = list(_f64(cfg.J, 9))
         D = cfg.D
         if D is None:

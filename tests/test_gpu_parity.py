@@ -6,6 +6,7 @@ same seeded inputs.  Tolerances:
 import numpy as np
 import pytest
 
+from oracle import c_oracle as co
 from oracle import qp_oracle as qo
 from oracle import refmath as rm
 
@@ -50,3 +51,92 @@ def test_u0_matches_exact_solution(gpu_mpc_factory, nfault, B):
     assert err.max() <= 1e-4, err
     assert (out["u0"][ub == 0] == 0).all()
     assert out["iters"].max() <= 16
+
+
+# ---------------------------------------------------------------------------------------------
+# float64 general-size kernel (reference 16-thruster vehicle, long horizons)
+# ---------------------------------------------------------------------------------------------
+def _faults16(B, pattern):
+    ub = np.full((B, 16), F_MAX)
+    stuck = np.zeros((B, 16))
+    for i, a in pattern:
+        ub[:, i] = 0.0
+        stuck[:, i] = a * F_MAX
+    return ub, stuck
+
+
+@pytest.mark.parametrize("N,pattern", [(15, [(10, 1.0), (11, 1.0)]), (15, []), (20, [(0, 0.5)])])
+def test_f64_kernel_reference_vehicle(gpu_mpc_factory, N, pattern):
+    """NT=16 (the reference's D, sys_model.py:73-123); N=15 with thrusters 10,11 stuck fully on is the
+    shipped reactive.yaml scenario.  float64 path: u0 and U within 1e-7 f_max of the exact solution."""
+    B = 6
+    mpc = gpu_mpc_factory(N=N, NT=16, max_iters=40)
+    x0, _, _, xref = qo.make_batch(B, N, 16, 0, 3000 + N)
+    ub, stuck = _faults16(B, pattern)
+    cfg = _cfg(N, 16)
+    H, g, lo, hi = mpc.debug_build_qp(x0, ub, stuck, xref.reshape(-1, order="F"), 2)
+    qp = qo.build_qp(cfg, x0[2], ub[2], stuck[2], xref)
+    assert np.abs(H - qp["H"]).max() <= 1e-11 * np.abs(qp["H"]).max()
+    assert np.abs(g - qp["g"]).max() <= 1e-11 * max(1.0, np.abs(qp["g"]).max())
+    out = mpc.solve(x0, ub, stuck, xref.reshape(-1, order="F"), return_U=True)
+    ref = co.solve_batch(cfg, x0, ub, stuck, xref, nthreads=4, max_iters=60)
+    assert (out["status"] == 0).all(), out["status"]
+    assert np.abs(out["u0"] - ref["u0"]).max() / F_MAX < 1e-7
+    assert np.abs(out["U"] - ref["U"]).max() / F_MAX < 1e-6
+
+
+def test_f64_kernel_config5_shape(gpu_mpc_factory):
+    """BASELINE config 5 shape: N=40, 16 thrusters, two random faults, fp64 KKT (n = 560)."""
+    N, NT, B = 40, 16, 6
+    mpc = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40)
+    x0, ub, stuck, xref = qo.make_batch(B, N, NT, 2, 1005)
+    out = mpc.solve(x0, ub, stuck, xref.reshape(-1, order="F"), return_U=True)
+    ref = co.solve_batch(_cfg(N, NT), x0, ub, stuck, xref, nthreads=6, max_iters=60)
+    assert (out["status"] == 0).all(), out["status"]
+    assert np.abs(out["u0"] - ref["u0"]).max() / F_MAX < 1e-7
+    assert np.abs(out["U"] - ref["U"]).max() / F_MAX < 1e-6
+
+
+def test_f64_dtype_on_small_problem_and_warm_start(gpu_mpc_factory):
+    """dtype='f64' routes n<=160 problems through the float64 kernel too; warm start + uref."""
+    d = np.load(__import__("pathlib").Path(__file__).parent / "golden" / "qp_cfg3_warm_uref.npz")
+    N, NT = int(d["N"]), int(d["NT"])
+    mpc = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40)
+    W = np.ascontiguousarray(d["warm"])
+    out = mpc.solve(d["x0"], d["ub"], d["stuck"], d["xref"].reshape(-1, order="F"),
+                    uref=d["uref"].reshape(-1, order="F"), warmU=W, return_U=True)
+    assert (out["status"] == 0).all()
+    assert np.abs(out["U"] - d["U"]).max() / F_MAX < 1e-6
+    assert np.abs(W - d["U"]).max() / F_MAX < 1e-6      # warm buffer updated in place with U*
+
+
+@pytest.mark.parametrize("name", ["cfg2_single_fault", "cfg3_double_fault", "cfg3_warm_uref", "nominal_nt8", "short_horizon"])
+def test_f32_kernels_against_golden(gpu_mpc_factory, name):
+    """fp32 LDS kernels on the committed golden QP fixtures (exact BVLS solutions), including the
+    warm-start + uref window and a short horizon; u0 <= 1e-4 f_max."""
+    d = np.load(__import__("pathlib").Path(__file__).parent / "golden" / f"qp_{name}.npz")
+    N, NT = int(d["N"]), int(d["NT"])
+    mpc = gpu_mpc_factory(N=N, NT=NT)
+    ur = d["uref"].reshape(-1, order="F") if d["uref"].size else None
+    W = np.ascontiguousarray(d["warm"]).copy() if d["warm"].size else None
+    out = mpc.solve(d["x0"], d["ub"], d["stuck"], d["xref"].reshape(-1, order="F"), uref=ur, warmU=W, return_U=True)
+    assert (out["status"] == 0).all()
+    assert np.abs(out["u0"] - d["u0"]).max() / F_MAX <= 1e-4
+    assert np.abs(out["U"] - d["U"]).max() / F_MAX <= 2e-3
+    assert (out["U"][np.repeat(d["ub"][:, None, :], N, 1) == 0] == 0).all()
+
+
+def test_mixed_fault_counts_and_empty_instances(gpu_mpc_factory):
+    """One batch mixing 0/1/2/8 broken thrusters: routed between the NB=8 and NB=10 instantiations."""
+    N, NT, B = 20, 8, 32
+    mpc = gpu_mpc_factory(N=N, NT=NT)
+    x0, ub, stuck, xref = qo.make_batch(B, N, NT, 2, 77)
+    ub[0:8] = F_MAX; stuck[0:8] = 0.0                      # nominal
+    ub[8:16, 1:] = F_MAX; stuck[8:16, 1:] = 0.0            # exactly thruster 0 broken
+    ub[8:16, 0] = 0.0; stuck[8:16, 0] = 1.7
+    ub[31, :] = 0.0; stuck[31, :] = 0.5                    # nothing left to command
+    out = mpc.solve(x0, ub, stuck, xref.reshape(-1, order="F"))
+    ref = co.solve_batch(_cfg(N, NT), x0, ub, stuck, xref, nthreads=4)
+    assert (out["status"] == 0).all()
+    assert np.abs(out["u0"] - ref["u0"]).max() / F_MAX <= 1e-4
+    assert (out["u0"][31] == 0).all() and out["iters"][31] == 0

@@ -1,0 +1,75 @@
+"""GPU: BASELINE config 1 plumbing -- the examples/sim.py closed loop (16 thrusters, N=15, hover,
+IC of the reference's examples/sim.py:49-54) with the MPC step on the MI355X, against the same loop
+driven by the float64 C oracle.  float64 kernel: states agree to 1e-6 over 40 steps."""
+import numpy as np
+import pytest
+
+from ft_mpc_amd.controllers.spiraling_mpc import SpiralingController
+from ft_mpc_amd.models.spiral_model import SpiralModel
+from ft_mpc_amd.models.sys_model import SystemModel
+from ft_mpc_amd.simulation.sim_env import SimulationEnvironment
+from ft_mpc_amd.util.broken_thruster import BrokenThruster
+from ft_mpc_amd.util.controller_debug import ControllerDebug
+from oracle import c_oracle as co
+from oracle import qp_oracle as qo
+
+pytestmark = pytest.mark.gpu
+PARAMS = {"horizon": 15, "param_set": "P1", "P1": {"Q": [1, 1, 1, 1, 1, 1, 2, 2, 2], "R": [0.1, 0.1, 0.1, 0.01, 0.01, 0.01]},
+          "max_iters": 40}
+IC = dict(position=[1, 0, 1], velocity=[1, 0.5, 0],
+          orientation=[0.03266701292872763, 0.26925564114813405, 0.3862204035220014, 0.8816280768439285],
+          angular_velocity=[0.3, 0.8, -0.1])
+
+
+class OracleController:
+    """Same seam, same warm-start policy, solve by oracle/ftmpc_oracle.c."""
+
+    def __init__(self, model, N):
+        self.model, self.N, self.prev = model, N, None
+        self.cfg = qo.QPConfig(N=N, NT=16)
+        self.xref = np.zeros((9, N + 1))
+        self.xref[8] = 0.6
+
+    def get_control(self, x, t):
+        warm = None if self.prev is None else np.vstack([self.prev[1:], np.zeros((1, 16))])[None]
+        out = co.solve_batch(self.cfg, x[None], self.model.u_ub_physical[None], self.model.faulty_force.reshape(1, -1),
+                             self.xref, uref=np.zeros((6, self.N + 1)), warmU=warm, max_iters=60)
+        self.prev = out["U"][0]
+        return out["u0"][0]
+
+
+@pytest.mark.parametrize("faults", [[], [(10, 1.0), (11, 1.0)]])
+def test_closed_loop_matches_oracle_loop(faults):
+    def build():
+        m = SystemModel(0.1)
+        for i, a in faults:
+            m.set_fault(BrokenThruster(i, a))
+        return m
+    m1, m2 = build(), build()
+    hist = ControllerDebug()
+    ctrl = SpiralingController(SpiralModel.from_system_model(m1), PARAMS, hist, quiet=True)
+    ctrl.load_trajectory("hover", 30)
+    env1 = SimulationEnvironment(m1, ctrl, seed=7)
+    env2 = SimulationEnvironment(m2, OracleController(m2, 15), seed=7)
+    for e in (env1, env2):
+        e.set_initial_state(**IC)
+    c_start = SpiralModel.from_system_model(m1).robot_to_center(env1.state)
+    for _ in range(40):
+        env1.step()
+        env2.step()
+        assert np.abs(env1.state - env2.state).max() < 1e-6
+    assert len(hist.history) == 40 and hist.inputs().shape == (40, 16)
+    assert (hist.inputs() >= -1e-9).all() and (hist.inputs() <= 3.4 + 1e-9).all()
+    assert (hist.inputs()[:, [i for i, _ in faults]] == 0).all()
+    c_end = SpiralModel.from_system_model(m1).robot_to_center(env1.state)
+    assert np.linalg.norm(c_end[3:6]) < np.linalg.norm(c_start[3:6])     # the orbit centre is being braked
+
+
+def test_solve_mpc_signature():
+    m = SystemModel(0.1)
+    sm = SpiralModel.from_system_model(m)
+    ctrl = SpiralingController(sm, PARAMS, None, quiet=True)
+    ctrl.load_trajectory("hover_0_0_0", 5)
+    x = np.array([1, 0, 1, 1, .5, 0, *IC["orientation"], .3, .8, -.1], float)
+    xs, us, dt, cost, status = ctrl.solve_mpc(sm.robot_to_center(x))
+    assert len(xs) == 16 and len(us) == 15 and us[0].shape == (16,) and status == "Solve_Succeeded" and cost > 0 and dt > 0

@@ -387,7 +387,7 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
     } else {
         bad = grow(h, &h->hs8, (int64_t)h->grid8 * tiles_of(8) * 256) != FTMPC_OK ||
               (h->nb_max > 8 && grow(h, &h->hs10, (int64_t)h->grid10 * tiles_of(10) * 256) != FTMPC_OK) ||
-              grow(h, &h->d_dbgH, 160 * 160) != FTMPC_OK || grow(h, &h->d_dbgv, 3 * 160 + 4) != FTMPC_OK;
+              grow(h, &h->d_dbgH, 4096 * 24 + 160 * 160) != FTMPC_OK || grow(h, &h->d_dbgv, 3 * 160 + 4) != FTMPC_OK;
     }
     if (bad) {
         g_create_error = h->err;
@@ -603,5 +603,16 @@ int ftmpc_debug_build_qp(ftmpc_handle* h, int64_t B, const double* x0, const dou
     *n_out = n;
     return FTMPC_OK;
 }
+
+#ifdef FTMPC_STAMPS
+/* diagnostic build only: copies the per-instance phase cycle totals (12 u64 per instance, first
+ * `count` <= 4096 instances) of the last fp32 solve */
+int ftmpc_debug_read_stamps(ftmpc_handle* h, int64_t count, unsigned long long* out) {
+    if (!h || !out || count < 0 || count > 4096 || !h->d_dbgH) return FTMPC_ERR_ARG;
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(out, h->d_dbgH, (size_t)count * 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return FTMPC_OK;
+}
+#endif
 
 }  // extern "C"

@@ -59,20 +59,34 @@ __device__ __forceinline__ float wave_max(float x) {
     for (int m = 32; m >= 1; m >>= 1) x = fmaxf(x, __shfl_xor(x, m, 64));
     return x;
 }
-__device__ __forceinline__ float quad_sum(float x) {  // sum over the 4 lanes sharing lane&15
-    x += __shfl_xor(x, 16, 64);
-    x += __shfl_xor(x, 32, 64);
-    return x;
-}
-__device__ __forceinline__ double quad_sum_d(double x) {
-    x += __shfl_xor(x, 16, 64);
-    x += __shfl_xor(x, 32, 64);
-    return x;
-}
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// Diagnostic build only (-DFTMPC_STAMPS, never the shipped library): per-phase cycle totals
+// of each instance's wave, written to SolveParams::dbg_H (reused as a u64 buffer).
+#ifdef FTMPC_STAMPS
+#define STAMP_DECL unsigned long long st_t0, st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define STAMP_START() st_t0 = stamp_now()
+#define STAMP(i)                                  \
+    do {                                          \
+        const unsigned long long st_t1 = stamp_now(); \
+        st_acc[i] += st_t1 - st_t0;               \
+        st_t0 = st_t1;                            \
+    } while (0)
+#else
+#define STAMP_DECL
+#define STAMP_START()
+#define STAMP(i)
+#endif
 
 template <int NB>
 struct Shape {
@@ -80,97 +94,220 @@ struct Shape {
     static constexpr int NV = (NPAD + 63) / 64;
     static constexpr int NTILES = NB * (NB + 1) / 2;
     static constexpr int ESTR = (NPAD % 32 == 16) ? NPAD : NPAD + 16;  // ebuf row stride
-    static constexpr int WORK = (2 * NPAD > 288) ? 2 * NPAD : 288;     // dvp|xvp, aliased by the potrf scratch
+    static constexpr int WORK = 2 * NPAD;                               // dvp | xvp
 };
 
-// ---- 16x16 Cholesky + inverse of the diagonal tile, in registers --------------------------
-// Lane l works on row (l&15) of the symmetric tile staged row-major (stride 17) in S; the four
-// 16-lane groups do identical work.  On return w[i] = (L^-1)[i][l&15] (column l&15 of the
-// inverse).  Returns false if a pivot is not positive.
-__device__ __forceinline__ bool potrf_inv16(const float* S, int li, float w[16]) {
-    float a[16];
+// ---- cross-lane primitives on the accumulator layout -------------------------------------
+// Accumulator ("C") layout of a 16x16 tile: lane (q = lane>>4, col = lane&15) holds rows 4q..4q+3 of
+// column col in 4 registers.  A 16-lane DPP row is one row-group q.
+template <int N>
+__device__ __forceinline__ float row_bcast(float x) {  // lane N of every 16-lane row -> whole row
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x150 + N, 0xf, 0xf, false));
+}
+// value of row-group QS (lanes 16QS..16QS+15) broadcast to all four row-groups, lane position kept:
+// v_permlane16_swap duplicates within halves, v_permlane32_swap across halves (gfx950)
+// The swap instructions exchange halves of TWO registers; both operands must be distinct
+// registers even when they carry the same value, hence the opaque copy.
+__device__ __forceinline__ unsigned opaque_copy(unsigned u) {
+    unsigned v = u;
+    asm volatile("" : "+v"(v));
+    return v;
+}
+template <int QS>
+__device__ __forceinline__ float group_bcast(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r16 = __builtin_amdgcn_permlane16_swap(u, opaque_copy(u), false, false);   // [r0,r0,r2,r2] , [r1,r1,r3,r3]
+    const unsigned y = (QS & 1) ? r16[1] : r16[0];
+    const auto r32 = __builtin_amdgcn_permlane32_swap(y, opaque_copy(y), false, false);   // [y0,y1,y0,y1] , [y2,y3,y2,y3]
+    return __builtin_bit_cast(float, (QS & 2) ? r32[1] : r32[0]);
+}
+// Both results of one swap are needed for the quad sums; hipcc (ROCm 7.2) folds r[0] + r[1] of
+// the builtin into r[0] + r[0], so the swap is issued through inline asm here (the s_nop covers
+// the VALU-write -> permlane-read hazard that the compiler would otherwise pad).
+__device__ __forceinline__ void swap32(unsigned& a, unsigned& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+// sum over the four lanes that share lane&15 (one per row-group), result in all of them
+__device__ __forceinline__ float quad_sum(float x) {
+    unsigned a = __builtin_bit_cast(unsigned, x), b = a;
+    swap32(a, b);                                                   // a = [r0,r1,r0,r1], b = [r2,r3,r2,r3]
+    const float s = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+    unsigned c = __builtin_bit_cast(unsigned, s), d = c;
+    swap16(c, d);                                                   // c = [s0,s0,s2,s2], d = [s1,s1,s3,s3]
+    return __builtin_bit_cast(float, c) + __builtin_bit_cast(float, d);
+}
+__device__ __forceinline__ double quad_sum_d(double x) {
+    const unsigned long long bits = __builtin_bit_cast(unsigned long long, x);
+    unsigned la = (unsigned)bits, lb = la, ha = (unsigned)(bits >> 32), hb = ha;
+    swap32(la, lb);
+    swap32(ha, hb);
+    const double s = __builtin_bit_cast(double, ((unsigned long long)ha << 32) | la) +
+                     __builtin_bit_cast(double, ((unsigned long long)hb << 32) | lb);
+    const unsigned long long sb = __builtin_bit_cast(unsigned long long, s);
+    unsigned lc = (unsigned)sb, ld = lc, hc = (unsigned)(sb >> 32), hd = hc;
+    swap16(lc, ld);
+    swap16(hc, hd);
+    return __builtin_bit_cast(double, ((unsigned long long)hc << 32) | lc) +
+           __builtin_bit_cast(double, ((unsigned long long)hd << 32) | ld);
+}
+
+// ---- 16x16 Cholesky + inverse of the diagonal tile, in the accumulator layout ---------------
+// c[rr] = A[4q+rr][col] (full symmetric tile) on entry; on exit w[rr] = (L^-1)[4q+rr][col].
+// Step j: pivot by v_readlane, row j to every row-group by permlane swaps, column j within each
+// row-group by DPP row_newbcast; every lane updates its own 4 elements (no LDS, no barrier).
+template <int J>
+__device__ __forceinline__ void potrf_step(float (&c)[4], float (&invs)[16], bool& ok, int q, int col) {
+    constexpr int QJ = J >> 2, RJ = J & 3;
+    const float d = readlane_f(c[RJ], 16 * QJ + J);
+    ok = ok && (d > 0.0f);
+    const float inv = __builtin_amdgcn_rsqf(d);
+    invs[J] = inv;
+    const float lcol = group_bcast<QJ>(c[RJ]) * inv;   // L[col][J]   (A[J][col] = A[col][J])
 #pragma unroll
-    for (int k = 0; k < 16; ++k) a[k] = S[li * 17 + k];
+    for (int rr = 0; rr < 4; ++rr) {
+        const int row = 4 * q + rr;
+        const float lrow = row_bcast<J>(c[rr]) * inv;    // L[row][J]
+        const float upd = c[rr] - lrow * lcol;
+        c[rr] = (col > J) ? ((row > J) ? upd : c[rr]) : ((col == J && row >= J) ? lrow : c[rr]);
+    }
+}
+template <int K>
+__device__ __forceinline__ void inv_block(const float (&c)[4], const float (&invs)[16], float (&acc)[4], float (&w)[4],
+                                          int q, int col) {
+    // rows 4K..4K+3 (meaningful in row-group K): forward substitution inside the 4x4 diagonal block
+    float wk[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        float s = ((col == 4 * K + rr) ? 1.0f : 0.0f) - acc[rr];
+        if (rr > 0) s -= row_bcast<4 * K + 0>(c[rr]) * wk[0];
+        if (rr > 1) s -= row_bcast<4 * K + 1>(c[rr]) * wk[1];
+        if (rr > 2) s -= row_bcast<4 * K + 2>(c[rr]) * wk[2];
+        wk[rr] = s * invs[4 * K + rr];
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) w[rr] = (q == K) ? wk[rr] : w[rr];
+    if (K < 3) {
+        // block row K of the inverse to every row-group, then acc += L[.,4K..4K+3] W_K
+        float wb[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) wb[kk] = group_bcast<K>(wk[kk]);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            acc[rr] += row_bcast<4 * K + 0>(c[rr]) * wb[0];
+            acc[rr] += row_bcast<4 * K + 1>(c[rr]) * wb[1];
+            acc[rr] += row_bcast<4 * K + 2>(c[rr]) * wb[2];
+            acc[rr] += row_bcast<4 * K + 3>(c[rr]) * wb[3];
+        }
+    }
+}
+__device__ __forceinline__ bool potrf_inv16(float (&c)[4], float (&w)[4], int lane) {
+    const int q = lane >> 4, col = lane & 15;
     float invs[16];
     bool ok = true;
+    potrf_step<0>(c, invs, ok, q, col);  potrf_step<1>(c, invs, ok, q, col);
+    potrf_step<2>(c, invs, ok, q, col);  potrf_step<3>(c, invs, ok, q, col);
+    potrf_step<4>(c, invs, ok, q, col);  potrf_step<5>(c, invs, ok, q, col);
+    potrf_step<6>(c, invs, ok, q, col);  potrf_step<7>(c, invs, ok, q, col);
+    potrf_step<8>(c, invs, ok, q, col);  potrf_step<9>(c, invs, ok, q, col);
+    potrf_step<10>(c, invs, ok, q, col); potrf_step<11>(c, invs, ok, q, col);
+    potrf_step<12>(c, invs, ok, q, col); potrf_step<13>(c, invs, ok, q, col);
+    potrf_step<14>(c, invs, ok, q, col); potrf_step<15>(c, invs, ok, q, col);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const float djj = readlane_f(a[j], j);
-        ok = ok && (djj > 0.0f);
-        const float inv = 1.0f / sqrtf(djj);
-        invs[j] = inv;
-        a[j] *= inv;
-#pragma unroll
-        for (int k = j + 1; k < 16; ++k) a[k] -= a[j] * readlane_f(a[j], k);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        float s = (i == li) ? 1.0f : 0.0f;
-#pragma unroll
-        for (int k = 0; k < i; ++k) s -= readlane_f(a[k], i) * w[k];
-        w[i] = s * invs[i];
-    }
+    for (int rr = 0; rr < 4; ++rr) w[rr] = 0.f;
+    inv_block<0>(c, invs, acc, w, q, col);
+    inv_block<1>(c, invs, acc, w, q, col);
+    inv_block<2>(c, invs, acc, w, q, col);
+    inv_block<3>(c, invs, acc, w, q, col);
     return ok;
 }
 
 // ---- blocked Cholesky of the nb x nb tile matrix in LDS (lower, in place) -----------------
 // After return: off-diagonal tiles hold L_IJ, diagonal tiles hold W_J = L_JJ^-1.
+// Each tile of block column J is produced TRANSPOSED in the accumulator,
+//     C_IJ' = M_IJ' - sum_K L_JK L_IK',
+// so that the triangular solve  L_IJ' = W_J C_IJ'  takes the accumulator directly as the MFMA B
+// operand (k runs over its row index: register s of row-group q' is k = 4q'+s) -- no LDS round trip.
 template <int NB>
-__device__ __forceinline__ bool chol_tiles(float* tiles, float* S, int nb, int lane) {
+__device__ __forceinline__ bool chol_tiles(float* tiles, int nb, int lane) {
     const int li = lane & 15, lq = lane >> 4;
     const int opoff = chunk_off(li, lq);
+    int toT[4];   // word of element (row li, col 4lq+rr): transposed access of a tile
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) toT[rr] = toff(li, 4 * lq + rr);
     bool ok = true;
     for (int J = 0; J < nb; ++J) {
-        // B operands of block row J (tiles (J,K), K<J)
         f32x4 bJ[NB - 1];
 #pragma unroll
         for (int K = 0; K < NB - 1; ++K)
             if (K < J) bJ[K] = lds4(tiles + tidx(J, K) * 256 + opoff);
-        for (int I = J; I < nb; ++I) {
+        // ---- diagonal tile: factorise + invert in registers ----
+        float* tjj = tiles + tidx(J, J) * 256;
+        {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const float* rowI = tiles + tidx(I, 0) * 256;
 #pragma unroll
             for (int K = 0; K < NB - 1; ++K)
                 if (K < J) {
-                    const f32x4 a4 = lds4(rowI + K * 256 + opoff);
-                    acc = mfma4(a4.x, bJ[K].x, acc);
-                    acc = mfma4(a4.y, bJ[K].y, acc);
-                    acc = mfma4(a4.z, bJ[K].z, acc);
-                    acc = mfma4(a4.w, bJ[K].w, acc);
+                    acc = mfma4(bJ[K].x, bJ[K].x, acc);
+                    acc = mfma4(bJ[K].y, bJ[K].y, acc);
+                    acc = mfma4(bJ[K].z, bJ[K].z, acc);
+                    acc = mfma4(bJ[K].w, bJ[K].w, acc);
                 }
-            float* tij = tiles + tidx(I, J) * 256;
-            float c[4];
+            float c[4], w[4];
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) c[rr] = tij[toff(4 * lq + rr, li)] - acc[rr];
-            if (I == J) {
+            for (int rr = 0; rr < 4; ++rr) c[rr] = tjj[toff(4 * lq + rr, li)] - acc[rr];
+            ok = potrf_inv16(c, w, lane) && ok;
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) S[(4 * lq + rr) * 17 + li] = c[rr];
-                __syncthreads();
-                float w[16];
-                ok = potrf_inv16(S, li, w) && ok;
-                if (lq == 0) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) tij[toff(i, li)] = w[i];
-                }
-            } else {
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) tij[toff(4 * lq + rr, li)] = c[rr];
-            }
+            for (int rr = 0; rr < 4; ++rr) tjj[toff(4 * lq + rr, li)] = w[rr];
         }
         __syncthreads();
-        // TRSM: L_IJ = C_IJ W_J'   (X[i][j] = sum_k C[i][k] W[j][k])
-        const f32x4 w4 = lds4(tiles + tidx(J, J) * 256 + opoff);
-        for (int I = J + 1; I < nb; ++I) {
-            float* tij = tiles + tidx(I, J) * 256;
-            const f32x4 a4 = lds4(tij + opoff);
-            f32x4 x = {0.f, 0.f, 0.f, 0.f};
-            x = mfma4(a4.x, w4.x, x);
-            x = mfma4(a4.y, w4.y, x);
-            x = mfma4(a4.z, w4.z, x);
-            x = mfma4(a4.w, w4.w, x);
-            __syncthreads();  // every lane has read C_IJ before anyone overwrites it
+        // A operand of the solve: W[li][4lq+s], s = 0..3
+        float wa[4];
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) tij[toff(4 * lq + rr, li)] = x[rr];
+        for (int s = 0; s < 4; ++s) wa[s] = tjj[toT[s]];
+        // ---- off-diagonal tiles, two at a time (independent MFMA chains) ----
+        for (int I = J + 1; I < nb; I += 2) {
+            const bool two = (I + 1 < nb);
+            const float* rowA = tiles + tidx(I, 0) * 256;
+            const float* rowB = tiles + tidx(two ? I + 1 : I, 0) * 256;
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int K = 0; K < NB - 1; ++K)
+                if (K < J) {
+                    const f32x4 tA = lds4(rowA + K * 256 + opoff);
+                    const f32x4 tB = lds4(rowB + K * 256 + opoff);
+                    a0 = mfma4(bJ[K].x, tA.x, a0);
+                    a1 = mfma4(bJ[K].x, tB.x, a1);
+                    a0 = mfma4(bJ[K].y, tA.y, a0);
+                    a1 = mfma4(bJ[K].y, tB.y, a1);
+                    a0 = mfma4(bJ[K].z, tA.z, a0);
+                    a1 = mfma4(bJ[K].z, tB.z, a1);
+                    a0 = mfma4(bJ[K].w, tA.w, a0);
+                    a1 = mfma4(bJ[K].w, tB.w, a1);
+                }
+            float* tA = tiles + tidx(I, J) * 256;
+            float* tB = tiles + tidx(two ? I + 1 : I, J) * 256;
+            float c0[4], c1[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                c0[rr] = tA[toT[rr]] - a0[rr];
+                c1[rr] = tB[toT[rr]] - a1[rr];
+            }
+            f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                x0 = mfma4(wa[s], c0[s], x0);
+                x1 = mfma4(wa[s], c1[s], x1);
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) tA[toT[rr]] = x0[rr];
+            if (two) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) tB[toT[rr]] = x1[rr];
+            }
         }
         __syncthreads();
     }
@@ -197,7 +334,6 @@ __device__ __forceinline__ void solve_tiles(const float* tiles, float* xvp, int 
         float y = w4.x * __shfl(r, lq, 64) + w4.y * __shfl(r, 4 + lq, 64) + w4.z * __shfl(r, 8 + lq, 64) +
                   w4.w * __shfl(r, 12 + lq, 64);
         y = quad_sum(y);
-        __syncthreads();
         if (lq == 0) xvp[16 * J + myp] = y;
         __syncthreads();
     }
@@ -216,7 +352,6 @@ __device__ __forceinline__ void solve_tiles(const float* tiles, float* xvp, int 
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) x += t[toff(4 * lq + rr, li)] * __shfl(r, 4 * lq + rr, 64);
         x = quad_sum(x);
-        __syncthreads();
         if (lq == 0) xvp[16 * J + myp] = x;
         __syncthreads();
     }
@@ -237,7 +372,6 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
     float* const ebuf = tiles;       // build phase only
     float* const dvp = work;         // d, permuted layout (gradient mat-vec)
     float* const xvp = work + NPAD;  // rhs / solution of the KKT solves
-    float* const S = work;           // potrf scratch (dvp/xvp are dead while factorising)
 
     const int lane = threadIdx.x;
     const int li = lane & 15, lq = lane >> 4;
@@ -249,6 +383,8 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
     for (int g = 0; g < 6; ++g) Rf[g] = (float)C.R[g];
 
     for (int64_t inst = blockIdx.x; inst < P.B; inst += gridDim.x) {
+        STAMP_DECL;
+        STAMP_START();
         __syncthreads();
         // ---------------- prologue: active thrusters, index tables ----------------
         double ub_l = 0.0;
@@ -316,6 +452,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
 #pragma unroll
         for (int t = 0; t < NTILES; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+        STAMP(0);
         // ---------------- build: stage loop ----------------
         for (int k = 0; k < N; ++k) {
             float* rb = recbuf + (k & 1) * REC_STRIDE;
@@ -418,6 +555,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 }
             }
             __syncthreads();
+            STAMP(1);
             // MFMA contraction: acc(I,J) += E_I' E_J over the 12 (9 used) rows
             const int Imax = ((k + 1) * na - 1) >> 4;
             float op[NB][3];
@@ -437,6 +575,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                     }
                 }
             __syncthreads();
+            STAMP(2);
         }
 
         // ---------------- finalise H: + 2 (Da' R Da + rho I) per stage block, unit pad diagonal ----
@@ -465,20 +604,8 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                     }
                 }
             }
-        // H -> LDS tiles (operand layout), then -> this workgroup's global slot
-#pragma unroll
-        for (int I = 0; I < NB; ++I)
-            if (I < nb) {
-#pragma unroll
-                for (int J = 0; J <= I; ++J) {
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) tiles[((I * (I + 1)) / 2 + J) * 256 + toff(4 * lq + rr, li)] = acc[(I * (I + 1)) / 2 + J][rr];
-                }
-            }
-        __syncthreads();
         const int ntl = (nb * (nb + 1)) / 2;
-        float* hslot = P.hscratch + (int64_t)blockIdx.x * P.tile_words;
-        for (int i = lane; i < ntl * 64; i += 64) *reinterpret_cast<f32x4*>(hslot + 4 * i) = lds4(tiles + 4 * i);
+        (void)ntl;
 
         // g, bounds, start point
         float gv[NV], lo[NV], hi[NV], sl[NV], su[NV], zl[NV], zu[NV], grad[NV];
@@ -523,12 +650,24 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
             }
         }
 
+        STAMP(3);
         // ---------------- interior-point iterations ----------------
         int status = 1, nit = 0;
         bool first = true;
         const float inv2n = 1.0f / (float)(2 * n);
         for (int it = 0; it <= C.max_iters; ++it) {
-            // d (permuted) -> LDS, gradient  H d + g  with float64 accumulation
+            // H (register-resident accumulator tiles) -> LDS tiles; d (permuted) -> LDS
+            __syncthreads();
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+                if (I < nb) {
+#pragma unroll
+                    for (int J = 0; J <= I; ++J) {
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) tiles[((I * (I + 1)) / 2 + J) * 256 + toff(4 * lq + rr, li)] = acc[(I * (I + 1)) / 2 + J][rr];
+                    }
+                }
+            // gradient  H d + g  with float64 accumulation
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int e = v * 64 + lane;
@@ -555,6 +694,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                     a = quad_sum_d(a);
                     if (lq == (I & 3)) grad[I >> 2] = valid[I >> 2] ? (float)(a + (double)gv[I >> 2]) : 0.f;
                 }
+            STAMP(4);
             // complementarity
             float t = 0.f;
             if (first) {
@@ -597,7 +737,9 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 }
             }
             __syncthreads();
-            const bool ok = chol_tiles<NB>(tiles, S, nb, lane);
+            STAMP(7);
+            const bool ok = chol_tiles<NB>(tiles, nb, lane);
+            STAMP(5);
             if (__builtin_amdgcn_readfirstlane(!ok)) {
                 status = 2;
                 break;
@@ -609,7 +751,9 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 if (e < npad) xvp[16 * (e >> 4) + vpos(e & 15)] = -grad[v];
             }
             __syncthreads();
+            STAMP(7);
             solve_tiles(tiles, xvp, nb, lane);
+            STAMP(6);
             float da[NV], dzl_a[NV], dzu_a[NV];
             float ap = 1.f, ad = 1.f;
 #pragma unroll
@@ -650,7 +794,9 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 if (e < npad) xvp[16 * (e >> 4) + vpos(e & 15)] = rhs[v];
             }
             __syncthreads();
+            STAMP(7);
             solve_tiles(tiles, xvp, nb, lane);
+            STAMP(6);
             float dd[NV], dzl[NV], dzu[NV];
             ap = 1e30f;
             ad = 1e30f;
@@ -678,10 +824,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                     zl[v] += ad * dzl[v];
                     zu[v] += ad * dzu[v];
                 }
-            // re-stage H for the next gradient / factorisation
-            __syncthreads();
-            for (int i = lane; i < ntl * 64; i += 64) *reinterpret_cast<f32x4*>(tiles + 4 * i) = *reinterpret_cast<const f32x4*>(hslot + 4 * i);
-            __syncthreads();
+            STAMP(7);
         }
 
         // ---------------- outputs ----------------
@@ -704,6 +847,13 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
             if (P.status) P.status[inst] = status;
             if (P.iters) P.iters[inst] = nit;
         }
+        STAMP(9);
+#ifdef FTMPC_STAMPS
+        if (lane == 0 && inst < 4096) {
+            unsigned long long* sb = reinterpret_cast<unsigned long long*>(P.dbg_H) + inst * 12;
+            for (int i = 0; i < 12; ++i) sb[i] = st_acc[i];
+        }
+#endif
     }
 }
 

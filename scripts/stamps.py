@@ -1,0 +1,22 @@
+"""Diagnostic: per-phase cycle shares of the fp32 solve kernel (stamps build, see csrc/Makefile)."""
+import sys, ctypes as C
+sys.path.insert(0,'/root/repo/fault-tolerant-mpc_amd'); sys.path.insert(0,'/root/repo')
+import numpy as np
+from ft_mpc_amd import _lib
+_lib._SO = _lib._HERE / "libftmpc_hip_stamps.so"
+import ft_mpc_amd
+B=int(sys.argv[1]) if len(sys.argv)>1 else 4096
+nf=int(sys.argv[2]) if len(sys.argv)>2 else 2
+N,NT=20,8
+mpc=ft_mpc_amd.BatchedMPC(N=N,NT=NT)
+x0,ub,stuck,xref=ft_mpc_amd.make_synthetic_batch(B,N,NT,nf,1003)
+out=mpc.solve(x0,ub,stuck,xref.reshape(-1,order='F'))
+cnt=min(B,4096)
+buf=np.zeros((cnt,12),np.uint64)
+f=mpc.lib.ftmpc_debug_read_stamps; f.argtypes=[C.c_void_p,C.c_int64,C.c_void_p]
+assert f(mpc._h,cnt,buf.ctypes.data_as(C.c_void_p))==0
+names=["prologue","build:propagate","build:mfma","finalize+store","matvec","chol","solves(2)","elementwise","reload H","output","",""]
+m=buf.astype(np.float64).mean(axis=0); tot=m.sum()
+print("iters mean %.2f   total cycles/QP %.0f"%(out['iters'].mean(),tot))
+for n_,v in zip(names,m):
+    if n_: print("  %-18s %10.0f  %5.1f%%   per-iter %8.0f"%(n_,v,100*v/tot,v/out['iters'].mean()))

@@ -1,0 +1,54 @@
+// Diagnostic: exercises the cross-lane primitives and the in-register 16x16 potrf+inverse on the GPU.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cmath>
+#include <vector>
+#include "../fault-tolerant-mpc_amd/csrc/ftmpc_solve.hip"
+namespace ftmpc {
+__global__ void k_prims(float* out) {
+    const int lane = threadIdx.x;
+    float x = (float)lane;
+    out[0 * 64 + lane] = group_bcast<0>(x);
+    out[1 * 64 + lane] = group_bcast<1>(x);
+    out[2 * 64 + lane] = group_bcast<2>(x);
+    out[3 * 64 + lane] = group_bcast<3>(x);
+    out[4 * 64 + lane] = row_bcast<5>(x);
+    out[5 * 64 + lane] = quad_sum(x);
+    out[6 * 64 + lane] = (float)quad_sum_d((double)x);
+}
+__global__ void k_potrf(const float* A, float* W, float* Lout, int* okout) {
+    const int lane = threadIdx.x, q = lane >> 4, col = lane & 15;
+    float c[4], w[4];
+    for (int rr = 0; rr < 4; ++rr) c[rr] = A[(4 * q + rr) * 16 + col];
+    bool ok = potrf_inv16(c, w, lane);
+    for (int rr = 0; rr < 4; ++rr) { W[(4 * q + rr) * 16 + col] = w[rr]; Lout[(4 * q + rr) * 16 + col] = c[rr]; }
+    if (lane == 0) *okout = ok;
+}
+}
+int main() {
+    float* d; hipMalloc(&d, 7 * 64 * 4);
+    hipLaunchKernelGGL(ftmpc::k_prims, dim3(1), dim3(64), 0, 0, d);
+    std::vector<float> h(7 * 64); hipMemcpy(h.data(), d, h.size() * 4, hipMemcpyDeviceToHost);
+    const char* names[7] = {"gb0", "gb1", "gb2", "gb3", "rb5", "qsum", "qsumd"};
+    for (int t = 0; t < 7; ++t) { printf("%s:", names[t]); for (int l = 0; l < 64; l += 1) if (l % 16 < 2 || l%16==5) printf(" [%d]=%g", l, h[t * 64 + l]); printf("\n"); }
+    // potrf
+    std::vector<float> A(256), B(256);
+    srand(1);
+    for (auto& v : B) v = (rand() % 1000) / 1000.0f - 0.5f;
+    for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) { float s = 0; for (int k = 0; k < 16; ++k) s += B[i * 16 + k] * B[j * 16 + k]; A[i * 16 + j] = s + (i == j ? 1.0f : 0.f); }
+    float *dA, *dW, *dL; int* dok; hipMalloc(&dA, 1024); hipMalloc(&dW, 1024); hipMalloc(&dL, 1024); hipMalloc(&dok, 4);
+    hipMemcpy(dA, A.data(), 1024, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(ftmpc::k_potrf, dim3(1), dim3(64), 0, 0, dA, dW, dL, dok);
+    std::vector<float> W(256), L(256); int ok; hipMemcpy(W.data(), dW, 1024, hipMemcpyDeviceToHost); hipMemcpy(L.data(), dL, 1024, hipMemcpyDeviceToHost); hipMemcpy(&ok, dok, 4, hipMemcpyDeviceToHost);
+    // reference cholesky
+    std::vector<double> Lr(256, 0.0);
+    for (int j = 0; j < 16; ++j) { double d0 = A[j * 16 + j]; for (int k = 0; k < j; ++k) d0 -= Lr[j * 16 + k] * Lr[j * 16 + k]; Lr[j * 16 + j] = sqrt(d0); for (int i = j + 1; i < 16; ++i) { double s = A[i * 16 + j]; for (int k = 0; k < j; ++k) s -= Lr[i * 16 + k] * Lr[j * 16 + k]; Lr[i * 16 + j] = s / Lr[j * 16 + j]; } }
+    double eL = 0, eW = 0;
+    for (int i = 0; i < 16; ++i) for (int j = 0; j <= i; ++j) eL = fmax(eL, fabs(L[i * 16 + j] - Lr[i * 16 + j]));
+    // W*L should be identity (lower)
+    for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) { double s = 0; for (int k = 0; k < 16; ++k) s += (double)W[i * 16 + k] * Lr[k * 16 + j]; eW = fmax(eW, fabs(s - (i == j))); }
+    printf("potrf ok=%d  max|L-Lref|=%.3e  max|W*L-I|=%.3e\n", ok, eL, eW);
+    double up = 0; for (int i = 0; i < 16; ++i) for (int j = i + 1; j < 16; ++j) up = fmax(up, fabs(W[i * 16 + j]));
+    printf("max upper(W)=%.3e\n", up);
+    return 0;
+}

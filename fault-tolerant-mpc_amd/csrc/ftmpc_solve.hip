@@ -247,18 +247,18 @@ __device__ __forceinline__ bool chol_tiles(float* tiles, int nb, int lane) {
         // ---- diagonal tile: factorise + invert in registers ----
         float* tjj = tiles + tidx(J, J) * 256;
         {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int K = 0; K < NB - 1; ++K)
                 if (K < J) {
                     acc = mfma4(bJ[K].x, bJ[K].x, acc);
-                    acc = mfma4(bJ[K].y, bJ[K].y, acc);
+                    acc2 = mfma4(bJ[K].y, bJ[K].y, acc2);
                     acc = mfma4(bJ[K].z, bJ[K].z, acc);
-                    acc = mfma4(bJ[K].w, bJ[K].w, acc);
+                    acc2 = mfma4(bJ[K].w, bJ[K].w, acc2);
                 }
             float c[4], w[4];
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) c[rr] = tjj[toff(4 * lq + rr, li)] - acc[rr];
+            for (int rr = 0; rr < 4; ++rr) c[rr] = tjj[toff(4 * lq + rr, li)] - (acc[rr] + acc2[rr]);
             ok = potrf_inv16(c, w, lane) && ok;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) tjj[toff(4 * lq + rr, li)] = w[rr];
@@ -315,6 +315,7 @@ __device__ __forceinline__ bool chol_tiles(float* tiles, int nb, int lane) {
 }
 
 // ---- solve (L L') x = b with the factor of chol_tiles; b/x live in the permuted LDS vector --
+template <int NB>
 __device__ __forceinline__ void solve_tiles(const float* tiles, float* xvp, int nb, int lane) {
     const int li = lane & 15, lq = lane >> 4;
     const int opoff = chunk_off(li, lq);
@@ -357,6 +358,160 @@ __device__ __forceinline__ void solve_tiles(const float* tiles, float* xvp, int 
     }
 }
 
+// =============================================================================================
+// Register-resident factorisation (NB = 8: n <= 128).  The factor never touches LDS: every tile
+// lives in 4 VGPRs per lane in the accumulator layout, and every tile product is
+//     mm_tn(X, Y) = X' Y      (k = row index of both accumulator tiles: register s of
+//                              row-group q' is k = 4q'+s, so both MFMA operands ARE registers)
+// Kept per tile pair I > J:  T_IJ = L_IJ'  and  Ln_IJ = L_IJ ; per diagonal block W_J = L_JJ^-1
+// (Ln slot) and Wt_J = W_J' (T slot).  With vectors held as accumulator "column tiles"
+// (lane (q, n): v[4q+rr], replicated over n) the triangular solves are MFMA chains as well:
+//     forward   y_J = Wt_J' (b_J - sum_K T_JK' y_K)        backward  x_J = W_J' (y_J - sum_I Ln_IJ' x_I)
+// H stays in LDS untouched (read for the gradient and as the start of each factorisation).
+// =============================================================================================
+__device__ __forceinline__ f32x4 mm_tn(const f32x4& X, const f32x4& Y, f32x4 acc) {
+    acc = mfma4(X.x, Y.x, acc);
+    acc = mfma4(X.y, Y.y, acc);
+    acc = mfma4(X.z, Y.z, acc);
+    acc = mfma4(X.w, Y.w, acc);
+    return acc;
+}
+
+// Out-of-line so that the eight diagonal blocks of the unrolled factorisation share one copy of the
+// ~850-instruction routine (instruction-cache footprint).  A non-positive pivot poisons the result
+// with NaN, which the caller detects.
+__device__ __forceinline__ f32x4 potrf_inv16_call(f32x4 cin, int lane) {
+    float c[4] = {cin.x, cin.y, cin.z, cin.w}, w[4];
+    const bool ok = potrf_inv16(c, w, lane);
+    const float poison = ok ? 0.f : __builtin_nanf("");
+    const f32x4 r = {w[0] + poison, w[1] + poison, w[2] + poison, w[3] + poison};
+    return r;
+}
+
+// sum over the 16 lanes of a DPP row, result in every lane of the row
+__device__ __forceinline__ float row_sum16(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));  // row_ror:8
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xf, 0xf, false));  // row_ror:4
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x122, 0xf, 0xf, false));  // row_ror:2
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xf, 0xf, false));  // row_ror:1
+    return x;
+}
+
+// one block column of the register-resident factorisation (template recursion instead of a
+// `#pragma unroll` loop: the barrier inside would otherwise block the unroller and push the
+// tile arrays into scratch).  T[tidx(I,J)] = L_IJ' for I > J, T[tidx(J,J)] = W_J', Wd[J] = W_J.
+template <int NB, int J>
+__device__ __forceinline__ void chol_reg_col(const float* tiles, const float* sigv, float* S, int nb, int lane,
+                                             const int (&toT)[4], const int (&toC)[4], bool& ok,
+                                             f32x4 (&T)[NB * (NB + 1) / 2], f32x4 (&Wd)[NB]) {
+    const int li = lane & 15, lq = lane >> 4;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    {
+        const float* tjj = tiles + tidx(J, J) * 256;
+        f32x4 a0 = zero, a1 = zero;
+#pragma unroll
+        for (int K = 0; K < J; ++K) {
+            if (K & 1) a1 = mm_tn(T[tidx(J, K)], T[tidx(J, K)], a1);
+            else a0 = mm_tn(T[tidx(J, K)], T[tidx(J, K)], a0);
+        }
+        const float sg = sigv[16 * J + li];
+        f32x4 cd;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) cd[rr] = tjj[toC[rr]] + ((4 * lq + rr == li) ? sg : 0.f) - (a0[rr] + a1[rr]);
+        const f32x4 w = potrf_inv16_call(cd, lane);
+        ok = ok && (w.x == w.x);
+        Wd[J] = w;
+        // Wt = W' through a 16x17 LDS scratch
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) S[(4 * lq + rr) * 17 + li] = w[rr];
+        __syncthreads();
+        f32x4 wt;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) wt[rr] = S[li * 17 + 4 * lq + rr];
+        T[tidx(J, J)] = wt;
+#pragma unroll
+        for (int I = J + 1; I < NB; ++I) {
+            {
+                f32x4 b0 = zero, b1 = zero;
+#pragma unroll
+                for (int K = 0; K < J; ++K) {
+                    if (K & 1) b1 = mm_tn(T[tidx(J, K)], T[tidx(I, K)], b1);
+                    else b0 = mm_tn(T[tidx(J, K)], T[tidx(I, K)], b0);
+                }
+                const float* tij = tiles + tidx(I, J) * 256;
+                f32x4 ct;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) ct[rr] = tij[toT[rr]] - (b0[rr] + b1[rr]);
+                T[tidx(I, J)] = mm_tn(wt, ct, zero);    // L_IJ' = W_J C_IJ'
+            }
+        }
+    }
+    if constexpr (J + 1 < NB) chol_reg_col<NB, J + 1>(tiles, sigv, S, nb, lane, toT, toC, ok, T, Wd);
+}
+
+template <int NB>
+__device__ __forceinline__ bool chol_reg(const float* tiles, const float* sigv, float* S, int nb, int lane,
+                                         f32x4 (&T)[NB * (NB + 1) / 2], f32x4 (&Wd)[NB]) {
+    const int li = lane & 15, lq = lane >> 4;
+    int toT[4], toC[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        toT[rr] = toff(li, 4 * lq + rr);   // element (row li, col 4lq+rr): transposed read
+        toC[rr] = toff(4 * lq + rr, li);   // element (row 4lq+rr, col li)
+    }
+    bool ok = true;
+    chol_reg_col<NB, 0>(tiles, sigv, S, nb, lane, toT, toC, ok, T, Wd);
+    return __all(ok);
+}
+
+// xv: LDS vector in natural order; in: right-hand side, out: solution.
+//   forward  (MFMA):        y_J = W_J (b_J - sum_{K<J} L_JK y_K)      vectors as accumulator column tiles
+//   backward (VALU + DPP):  r_J = y_J - sum_{I>J} L_IJ' x_I           with x_I as a per-lane row value
+//                           x_J' = r_J' W_J  (MFMA: mm_tn(R, W_J) replicates x_J[col] over the rows)
+template <int NB>
+__device__ __forceinline__ void solve_reg(const f32x4 (&T)[NB * (NB + 1) / 2], const f32x4 (&Wd)[NB],
+                                          float* xv, int nb, int lane) {
+    const int li = lane & 15, lq = lane >> 4;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 Y[NB];
+#pragma unroll
+    for (int J = 0; J < NB; ++J) {
+        Y[J] = zero;
+        {
+            const f32x4 b = lds4(xv + 16 * J + 4 * lq);
+            f32x4 a0 = zero, a1 = zero;
+#pragma unroll
+            for (int K = 0; K < J; ++K) {
+                if (K & 1) a1 = mm_tn(T[tidx(J, K)], Y[K], a1);
+                else a0 = mm_tn(T[tidx(J, K)], Y[K], a0);
+            }
+            const f32x4 r = b - (a0 + a1);
+            Y[J] = mm_tn(T[tidx(J, J)], r, zero);
+        }
+    }
+    __syncthreads();
+    float xr[NB];
+#pragma unroll
+    for (int J = NB - 1; J >= 0; --J) {
+        xr[J] = 0.f;
+        {
+            f32x4 a = zero;
+#pragma unroll
+            for (int I = J + 1; I < NB; ++I) {
+                a += T[tidx(I, J)] * xr[I];
+            }
+            f32x4 r;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) r[rr] = Y[J][rr] - row_sum16(a[rr]);
+            const f32x4 xrow = mm_tn(r, Wd[J], zero);
+            xr[J] = xrow.x;
+            if (lq == 0) xv[16 * J + li] = xr[J];
+        }
+    }
+    __syncthreads();
+}
+
 }  // namespace
 
 template <int NB>
@@ -369,6 +524,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
     __shared__ __attribute__((aligned(16))) float s_Da[6 * MAX_NT];
     __shared__ unsigned char s_stg[NPAD], s_thr[NPAD];
     __shared__ int s_act[MAX_NT];
+    constexpr bool REG = (NB == 8);   // register-resident factorisation (see chol_reg)
     float* const ebuf = tiles;       // build phase only
     float* const dvp = work;         // d, permuted layout (gradient mat-vec)
     float* const xvp = work + NPAD;  // rhs / solution of the KKT solves
@@ -394,6 +550,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
         const int n = N * na;
         const int nb = (n + 15) >> 4;
         const int npad = nb * 16;
+        (void)npad;
         if (nb <= P.nb_lo && !(na == 0 && P.nb_lo == 0)) continue;  // another instantiation's instance
         if (nb > NB && P.nb_hi_owner == 0) continue;
         if (na == 0 || nb > NB) {  // nothing to optimise / shape not supported by any instantiation
@@ -406,6 +563,10 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
             }
             continue;
         }
+        // the register-resident path always runs the full NB x NB tile grid (identity padding blocks),
+        // which keeps its factorisation free of data-dependent branches
+        const int nbr = REG ? NB : nb;
+        const int npadr = 16 * nbr;
         const int myrank = __popcll(amask & ((1ull << lane) - 1ull));
         if (lane < NT && ub_l > 0.0) s_act[myrank] = lane;
         __syncthreads();
@@ -413,7 +574,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
 #pragma unroll
             for (int g = 0; g < 6; ++g) s_Da[g * MAX_NT + lane] = (float)C.D[g * MAX_NT + s_act[lane]];
         }
-        for (int e = lane; e < npad; e += 64) {
+        for (int e = lane; e < npadr; e += 64) {
             const int s = e / na;
             s_stg[e] = (unsigned char)(e < n ? s : 255);
             s_thr[e] = (unsigned char)(e < n ? e - s * na : 255);
@@ -432,8 +593,8 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int e = v * 64 + lane;
-            kcol[v] = (e < npad) ? s_stg[e] : 255;
-            acol[v] = (e < npad) ? s_thr[e] : 255;
+            kcol[v] = (e < npadr) ? s_stg[e] : 255;
+            acol[v] = (e < npadr) ? s_thr[e] : 255;
             ubar[v] = 0.f;
             ubv[v] = 1.f;
             gacc[v] = 0.f;
@@ -539,7 +700,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 gacc[v] += gs;
                 // E = sqrt(2 W) G9  -> LDS
                 const int e = v * 64 + lane;
-                if (e < npad) {
+                if (e < npadr) {
                     if (!terminal) {
 #pragma unroll
                         for (int r = 0; r < 9; ++r) ebuf[r * ESTR + e] = (float)C.sq2Q[r] * G[r][v];
@@ -581,7 +742,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
         // ---------------- finalise H: + 2 (Da' R Da + rho I) per stage block, unit pad diagonal ----
 #pragma unroll
         for (int I = 0; I < NB; ++I)
-            if (I < nb) {
+            if (I < nbr) {
 #pragma unroll
                 for (int dJ = 0; dJ < 2; ++dJ) {
                     const int J = I - 1 + dJ;
@@ -604,8 +765,20 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                     }
                 }
             }
-        const int ntl = (nb * (nb + 1)) / 2;
-        (void)ntl;
+        if constexpr (REG) {
+            // H -> LDS once; it is never overwritten (the factor lives in registers)
+            __syncthreads();
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+                if (I < nbr) {
+#pragma unroll
+                    for (int J = 0; J <= I; ++J) {
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) tiles[((I * (I + 1)) / 2 + J) * 256 + toff(4 * lq + rr, li)] = acc[(I * (I + 1)) / 2 + J][rr];
+                    }
+                }
+            __syncthreads();
+        }
 
         // g, bounds, start point
         float gv[NV], lo[NV], hi[NV], sl[NV], su[NV], zl[NV], zu[NV], grad[NV];
@@ -621,7 +794,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
         if (P.dbg_inst == inst) {  // test hook: dump the QP this wave is about to solve
 #pragma unroll
             for (int I = 0; I < NB; ++I)
-                if (I < nb) {
+                if (I < nbr) {
 #pragma unroll
                     for (int J = 0; J <= I; ++J) {
 #pragma unroll
@@ -629,8 +802,8 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                             const int e1 = 16 * I + 4 * lq + rr, e2 = 16 * J + li;
                             const float h = acc[(I * (I + 1)) / 2 + J][rr];
                             if (I != J || e1 >= e2) {
-                                P.dbg_H[(int64_t)e1 * npad + e2] = h;
-                                P.dbg_H[(int64_t)e2 * npad + e1] = h;
+                                P.dbg_H[(int64_t)e1 * npadr + e2] = h;
+                                P.dbg_H[(int64_t)e2 * npadr + e1] = h;
                             }
                         }
                     }
@@ -638,49 +811,52 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int e = v * 64 + lane;
-                if (e < npad) {
+                if (e < npadr) {
                     P.dbg_vec[e] = gv[v];
-                    P.dbg_vec[npad + e] = lo[v];
-                    P.dbg_vec[2 * npad + e] = hi[v];
+                    P.dbg_vec[npadr + e] = lo[v];
+                    P.dbg_vec[2 * npadr + e] = hi[v];
                 }
             }
             if (lane == 0) {
                 P.dbg_vec[480] = (float)n;
-                P.dbg_vec[481] = (float)npad;
+                P.dbg_vec[481] = (float)npadr;
             }
         }
 
         STAMP(3);
         // ---------------- interior-point iterations ----------------
+        f32x4 Tt[REG ? NTILES : 1], Wd[REG ? NB : 1];   // register-resident factor (REG path)
         int status = 1, nit = 0;
         bool first = true;
         const float inv2n = 1.0f / (float)(2 * n);
         for (int it = 0; it <= C.max_iters; ++it) {
             // H (register-resident accumulator tiles) -> LDS tiles; d (permuted) -> LDS
             __syncthreads();
+            if constexpr (!REG) {
 #pragma unroll
             for (int I = 0; I < NB; ++I)
-                if (I < nb) {
+                if (I < nbr) {
 #pragma unroll
                     for (int J = 0; J <= I; ++J) {
 #pragma unroll
                         for (int rr = 0; rr < 4; ++rr) tiles[((I * (I + 1)) / 2 + J) * 256 + toff(4 * lq + rr, li)] = acc[(I * (I + 1)) / 2 + J][rr];
                     }
                 }
+            }
             // gradient  H d + g  with float64 accumulation
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int e = v * 64 + lane;
-                if (e < npad) dvp[16 * (e >> 4) + vpos(e & 15)] = valid[v] ? ((sl[v] < su[v]) ? lo[v] + sl[v] : hi[v] - su[v]) : 0.f;
+                if (e < npadr) dvp[16 * (e >> 4) + vpos(e & 15)] = valid[v] ? ((sl[v] < su[v]) ? lo[v] + sl[v] : hi[v] - su[v]) : 0.f;
             }
             __syncthreads();
 #pragma unroll
             for (int I = 0; I < NB; ++I)
-                if (I < nb) {
+                if (I < nbr) {
                     double a = 0.0;
 #pragma unroll
                     for (int J = 0; J < NB; ++J)
-                        if (J < nb) {
+                        if (J < nbr) {
                             if (J <= I) {
                                 const f32x4 t4 = lds4(tiles + ((I * (I + 1)) / 2 + J) * 256 + chunk_off(li, lq));
                                 const f32x4 d4 = lds4(dvp + 16 * J + 4 * lq);
@@ -727,18 +903,25 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
             ++nit;
             // KKT matrix: H + Sigma on the diagonal
             float Sig[NV];
+            if constexpr (REG) __syncthreads();   // dvp is dead: it becomes the Sigma vector
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 Sig[v] = valid[v] ? zl[v] / sl[v] + zu[v] / su[v] : 0.f;
                 const int e = v * 64 + lane;
-                if (e < npad) {
-                    const int I = e >> 4, r = e & 15;
-                    tiles[((I * (I + 1)) / 2 + I) * 256 + toff(r, r)] += Sig[v];
+                if (e < npadr) {
+                    if constexpr (REG) {
+                        dvp[e] = Sig[v];
+                    } else {
+                        const int I = e >> 4, r = e & 15;
+                        tiles[((I * (I + 1)) / 2 + I) * 256 + toff(r, r)] += Sig[v];
+                    }
                 }
             }
             __syncthreads();
             STAMP(7);
-            const bool ok = chol_tiles<NB>(tiles, nb, lane);
+            bool ok;
+            if constexpr (REG) ok = chol_reg<NB>(tiles, dvp, recbuf, nbr, lane, Tt, Wd);
+            else ok = chol_tiles<NB>(tiles, nbr, lane);
             STAMP(5);
             if (__builtin_amdgcn_readfirstlane(!ok)) {
                 status = 2;
@@ -748,18 +931,19 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int e = v * 64 + lane;
-                if (e < npad) xvp[16 * (e >> 4) + vpos(e & 15)] = -grad[v];
+                if (e < npadr) xvp[REG ? e : 16 * (e >> 4) + vpos(e & 15)] = -grad[v];
             }
             __syncthreads();
             STAMP(7);
-            solve_tiles(tiles, xvp, nb, lane);
+            if constexpr (REG) solve_reg<NB>(Tt, Wd, xvp, nbr, lane);
+            else solve_tiles<NB>(tiles, xvp, nbr, lane);
             STAMP(6);
             float da[NV], dzl_a[NV], dzu_a[NV];
             float ap = 1.f, ad = 1.f;
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int e = v * 64 + lane;
-                da[v] = (e < npad && valid[v]) ? xvp[16 * (e >> 4) + vpos(e & 15)] : 0.f;
+                da[v] = (e < npadr && valid[v]) ? xvp[REG ? e : 16 * (e >> 4) + vpos(e & 15)] : 0.f;
                 dzl_a[v] = dzu_a[v] = 0.f;
                 if (valid[v]) {
                     dzl_a[v] = -zl[v] - zl[v] * da[v] / sl[v];
@@ -791,11 +975,12 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                     rhs[v] = -(grad[v] - zl[v] + zu[v]) - rcl[v] / sl[v] + rcu[v] / su[v];
                 }
                 const int e = v * 64 + lane;
-                if (e < npad) xvp[16 * (e >> 4) + vpos(e & 15)] = rhs[v];
+                if (e < npadr) xvp[REG ? e : 16 * (e >> 4) + vpos(e & 15)] = rhs[v];
             }
             __syncthreads();
             STAMP(7);
-            solve_tiles(tiles, xvp, nb, lane);
+            if constexpr (REG) solve_reg<NB>(Tt, Wd, xvp, nbr, lane);
+            else solve_tiles<NB>(tiles, xvp, nbr, lane);
             STAMP(6);
             float dd[NV], dzl[NV], dzu[NV];
             ap = 1e30f;
@@ -803,7 +988,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int e = v * 64 + lane;
-                dd[v] = (e < npad && valid[v]) ? xvp[16 * (e >> 4) + vpos(e & 15)] : 0.f;
+                dd[v] = (e < npadr && valid[v]) ? xvp[REG ? e : 16 * (e >> 4) + vpos(e & 15)] : 0.f;
                 dzl[v] = dzu[v] = 0.f;
                 if (valid[v]) {
                     dzl[v] = (-rcl[v] - zl[v] * dd[v]) / sl[v];

@@ -414,6 +414,16 @@ __device__ __forceinline__ void chol_reg_col(const float* tiles, const float* si
             if (K & 1) a1 = mm_tn(T[tidx(J, K)], T[tidx(J, K)], a1);
             else a0 = mm_tn(T[tidx(J, K)], T[tidx(J, K)], a0);
         }
+        // off-diagonal Schur accumulations first: they do not depend on the diagonal block, so the
+        // MFMA pipe works through them while the VALU runs the in-register potrf below
+        f32x4 bacc[NB];
+#pragma unroll
+        for (int I = J + 1; I < NB; ++I) bacc[I] = zero;
+#pragma unroll
+        for (int K = 0; K < J; ++K) {
+#pragma unroll
+            for (int I = J + 1; I < NB; ++I) bacc[I] = mm_tn(T[tidx(J, K)], T[tidx(I, K)], bacc[I]);
+        }
         const float sg = sigv[16 * J + li];
         f32x4 cd;
 #pragma unroll
@@ -432,19 +442,11 @@ __device__ __forceinline__ void chol_reg_col(const float* tiles, const float* si
         T[tidx(J, J)] = wt;
 #pragma unroll
         for (int I = J + 1; I < NB; ++I) {
-            {
-                f32x4 b0 = zero, b1 = zero;
+            const float* tij = tiles + tidx(I, J) * 256;
+            f32x4 ct;
 #pragma unroll
-                for (int K = 0; K < J; ++K) {
-                    if (K & 1) b1 = mm_tn(T[tidx(J, K)], T[tidx(I, K)], b1);
-                    else b0 = mm_tn(T[tidx(J, K)], T[tidx(I, K)], b0);
-                }
-                const float* tij = tiles + tidx(I, J) * 256;
-                f32x4 ct;
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) ct[rr] = tij[toT[rr]] - (b0[rr] + b1[rr]);
-                T[tidx(I, J)] = mm_tn(wt, ct, zero);    // L_IJ' = W_J C_IJ'
-            }
+            for (int rr = 0; rr < 4; ++rr) ct[rr] = tij[toT[rr]] - bacc[I][rr];
+            T[tidx(I, J)] = mm_tn(wt, ct, zero);    // L_IJ' = W_J C_IJ'
         }
     }
     if constexpr (J + 1 < NB) chol_reg_col<NB, J + 1>(tiles, sigv, S, nb, lane, toT, toC, ok, T, Wd);
@@ -850,26 +852,40 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 if (e < npadr) dvp[16 * (e >> 4) + vpos(e & 15)] = valid[v] ? ((sl[v] < su[v]) ? lo[v] + sl[v] : hi[v] - su[v]) : 0.f;
             }
             __syncthreads();
+            {
+                // J-outer so that each d chunk is converted to float64 once; per-lane partial sums
+                // a[I] cover (row li of block I) x (this lane's 4 columns of block J)
+                double am[NB];
 #pragma unroll
-            for (int I = 0; I < NB; ++I)
-                if (I < nbr) {
-                    double a = 0.0;
+                for (int I = 0; I < NB; ++I) am[I] = 0.0;
 #pragma unroll
-                    for (int J = 0; J < NB; ++J)
-                        if (J < nbr) {
-                            if (J <= I) {
-                                const f32x4 t4 = lds4(tiles + ((I * (I + 1)) / 2 + J) * 256 + chunk_off(li, lq));
-                                const f32x4 d4 = lds4(dvp + 16 * J + 4 * lq);
-                                a += (double)t4.x * (double)d4.x + (double)t4.y * (double)d4.y + (double)t4.z * (double)d4.z + (double)t4.w * (double)d4.w;
-                            } else {
-                                const float* t = tiles + ((J * (J + 1)) / 2 + I) * 256;
+                for (int J = 0; J < NB; ++J)
+                    if (J < nbr) {
+                        const f32x4 d4 = lds4(dvp + 16 * J + 4 * lq);   // columns {lq,4+lq,8+lq,12+lq} of block J
+                        const double dx = d4.x, dy = d4.y, dz = d4.z, dw = d4.w;
+                        double dt[4];                                  // rows 4lq+rr of block J (transposed use)
 #pragma unroll
-                                for (int rr = 0; rr < 4; ++rr) a += (double)t[toff(4 * lq + rr, li)] * (double)dvp[16 * J + rr * 4 + lq];
+                        for (int rr = 0; rr < 4; ++rr) dt[rr] = (double)dvp[16 * J + rr * 4 + lq];
+#pragma unroll
+                        for (int I = 0; I < NB; ++I)
+                            if (I < nbr) {
+                                if (J <= I) {
+                                    const f32x4 t4 = lds4(tiles + ((I * (I + 1)) / 2 + J) * 256 + chunk_off(li, lq));
+                                    am[I] += (double)t4.x * dx + (double)t4.y * dy + (double)t4.z * dz + (double)t4.w * dw;
+                                } else {
+                                    const float* t = tiles + ((J * (J + 1)) / 2 + I) * 256;
+#pragma unroll
+                                    for (int rr = 0; rr < 4; ++rr) am[I] += (double)t[toff(4 * lq + rr, li)] * dt[rr];
+                                }
                             }
-                        }
-                    a = quad_sum_d(a);
-                    if (lq == (I & 3)) grad[I >> 2] = valid[I >> 2] ? (float)(a + (double)gv[I >> 2]) : 0.f;
-                }
+                    }
+#pragma unroll
+                for (int I = 0; I < NB; ++I)
+                    if (I < nbr) {
+                        const double a = quad_sum_d(am[I]);
+                        if (lq == (I & 3)) grad[I >> 2] = valid[I >> 2] ? (float)(a + (double)gv[I >> 2]) : 0.f;
+                    }
+            }
             STAMP(4);
             // complementarity
             float t = 0.f;
@@ -902,11 +918,13 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
             if (it == C.max_iters) break;
             ++nit;
             // KKT matrix: H + Sigma on the diagonal
-            float Sig[NV];
+            float Sig[NV], rsl[NV], rsu[NV];   // 1/s_l, 1/s_u by v_rcp_f32 (1 ulp; the IPM tolerates it)
             if constexpr (REG) __syncthreads();   // dvp is dead: it becomes the Sigma vector
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                Sig[v] = valid[v] ? zl[v] / sl[v] + zu[v] / su[v] : 0.f;
+                rsl[v] = __builtin_amdgcn_rcpf(sl[v]);
+                rsu[v] = __builtin_amdgcn_rcpf(su[v]);
+                Sig[v] = valid[v] ? zl[v] * rsl[v] + zu[v] * rsu[v] : 0.f;
                 const int e = v * 64 + lane;
                 if (e < npadr) {
                     if constexpr (REG) {
@@ -946,12 +964,13 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 da[v] = (e < npadr && valid[v]) ? xvp[REG ? e : 16 * (e >> 4) + vpos(e & 15)] : 0.f;
                 dzl_a[v] = dzu_a[v] = 0.f;
                 if (valid[v]) {
-                    dzl_a[v] = -zl[v] - zl[v] * da[v] / sl[v];
-                    dzu_a[v] = -zu[v] + zu[v] * da[v] / su[v];
-                    if (da[v] < 0.f) ap = fminf(ap, -sl[v] / da[v]);
-                    if (da[v] > 0.f) ap = fminf(ap, su[v] / da[v]);
-                    if (dzl_a[v] < 0.f) ad = fminf(ad, -zl[v] / dzl_a[v]);
-                    if (dzu_a[v] < 0.f) ad = fminf(ad, -zu[v] / dzu_a[v]);
+                    dzl_a[v] = -zl[v] - zl[v] * da[v] * rsl[v];
+                    dzu_a[v] = -zu[v] + zu[v] * da[v] * rsu[v];
+                    const float rda = __builtin_amdgcn_rcpf(da[v]);
+                    if (da[v] < 0.f) ap = fminf(ap, -sl[v] * rda);
+                    if (da[v] > 0.f) ap = fminf(ap, su[v] * rda);
+                    if (dzl_a[v] < 0.f) ad = fminf(ad, -zl[v] * __builtin_amdgcn_rcpf(dzl_a[v]));
+                    if (dzu_a[v] < 0.f) ad = fminf(ad, -zu[v] * __builtin_amdgcn_rcpf(dzu_a[v]));
                 }
             }
             ap = wave_min(ap);
@@ -972,7 +991,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 if (valid[v]) {
                     rcl[v] = sl[v] * zl[v] + da[v] * dzl_a[v] - sigma * mu;
                     rcu[v] = su[v] * zu[v] - da[v] * dzu_a[v] - sigma * mu;
-                    rhs[v] = -(grad[v] - zl[v] + zu[v]) - rcl[v] / sl[v] + rcu[v] / su[v];
+                    rhs[v] = -(grad[v] - zl[v] + zu[v]) - rcl[v] * rsl[v] + rcu[v] * rsu[v];
                 }
                 const int e = v * 64 + lane;
                 if (e < npadr) xvp[REG ? e : 16 * (e >> 4) + vpos(e & 15)] = rhs[v];
@@ -991,12 +1010,13 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 dd[v] = (e < npadr && valid[v]) ? xvp[REG ? e : 16 * (e >> 4) + vpos(e & 15)] : 0.f;
                 dzl[v] = dzu[v] = 0.f;
                 if (valid[v]) {
-                    dzl[v] = (-rcl[v] - zl[v] * dd[v]) / sl[v];
-                    dzu[v] = (-rcu[v] + zu[v] * dd[v]) / su[v];
-                    if (dd[v] < 0.f) ap = fminf(ap, -sl[v] / dd[v]);
-                    if (dd[v] > 0.f) ap = fminf(ap, su[v] / dd[v]);
-                    if (dzl[v] < 0.f) ad = fminf(ad, -zl[v] / dzl[v]);
-                    if (dzu[v] < 0.f) ad = fminf(ad, -zu[v] / dzu[v]);
+                    dzl[v] = (-rcl[v] - zl[v] * dd[v]) * rsl[v];
+                    dzu[v] = (-rcu[v] + zu[v] * dd[v]) * rsu[v];
+                    const float rdd = __builtin_amdgcn_rcpf(dd[v]);
+                    if (dd[v] < 0.f) ap = fminf(ap, -sl[v] * rdd);
+                    if (dd[v] > 0.f) ap = fminf(ap, su[v] * rdd);
+                    if (dzl[v] < 0.f) ad = fminf(ad, -zl[v] * __builtin_amdgcn_rcpf(dzl[v]));
+                    if (dzu[v] < 0.f) ad = fminf(ad, -zu[v] * __builtin_amdgcn_rcpf(dzu[v]));
                 }
             }
             ap = fminf(1.f, 0.995f * wave_min(ap));

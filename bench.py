@@ -21,6 +21,7 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "fault-tolerant-mpc_amd"))
 
 F32_PEAK_TFLOPS = 157.3  # MI355X fp32 MFMA == fp32 vector peak (MI355X_MICROARCH.md)
+F64_PEAK_TFLOPS = 78.6   # fp64 vector/matrix peak
 
 
 def algorithmic_flops(N, na, iters):
@@ -45,6 +46,7 @@ def main():
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--thrusters", type=int, default=8)
     ap.add_argument("--faults", type=int, default=2)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="arithmetic of the KKT/IPM solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -62,7 +64,7 @@ def main():
     dev = torch.device(f"cuda:{local}")
 
     N, NT, B = args.horizon, args.thrusters, args.batch
-    mpc = ft_mpc_amd.BatchedMPC(N=N, NT=NT, device_id=local)
+    mpc = ft_mpc_amd.BatchedMPC(N=N, NT=NT, device_id=local, dtype=args.dtype)
     x0, ub, stuck, xref = ft_mpc_amd.make_synthetic_batch(B, N, NT, args.faults, 1003 + rank)
     to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     d_x0, d_ub, d_st, d_xr = to(x0), to(ub), to(stuck), to(xref.reshape(-1, order="F"))
@@ -118,18 +120,28 @@ def main():
     if rank == 0:
         value = args.steps * B * world / elapsed
         achieved = flops / (sol_ms * 1e-3) / 1e12
+        peak = F64_PEAK_TFLOPS if (args.dtype == "f64" or N * NT > 160) else F32_PEAK_TFLOPS
+        # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process, so
+        # the committed rocprofv3 --pmc summary of the same command is reported (per launch, with the
+        # gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md); null when no summary matches.
+        traffic, traffic_src = None, None
+        tfile = ROOT / "profiles" / "traffic_latest.json"
+        if tfile.exists():
+            tj = json.loads(tfile.read_text())
+            if tj.get("kernel") == dom and tj.get("batch") == B and tj.get("horizon") == N and tj.get("thrusters") == NT:
+                traffic, traffic_src = tj["bytes_per_launch"], tj["source"]
         line = {
             "metric": "MPC QP steps/s (whole node) at N=20, 8 thrusters, batch 65536",
             "value": value, "unit": "QP-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64" if (args.dtype == "f64" or N * NT > 160) else "f32", "data": "synthetic",
             "config": {"workload": f"batch {B}/GPU, N={N}, {NT} thrusters, random {args.faults}-fault Monte-Carlo, "
                                    f"cold start, hover reference (BASELINE configs[2])",
                        "batch_per_gpu": B, "horizon": N, "thrusters": NT, "faults": args.faults,
                        "ipm_iters_mean": float(iters.mean()), "ipm_iters_max": int(iters.max()),
                        "not_converged": int((status != 0).sum()), "parallelism": f"batch-sharded x{world}, no collective"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F32_PEAK_TFLOPS, "traffic": None,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": dom, "kernel_ms": sol_ms, "other_kernels_ms": {"ftmpc_linearize_kernel": lin_ms, **{k: v for k, v in med.items() if k != dom}},
                          "flops_per_launch": flops},
         }
@@ -137,7 +149,7 @@ def main():
             from oracle import c_oracle, qp_oracle
             cores = os.cpu_count() or 1
             qcfg = qp_oracle.QPConfig(N=N, NT=NT)
-            kw = dict(max_iters=16, mu_stop=1e-10, return_U=False)
+            kw = dict(max_iters=16, mu_stop=1e-10, return_U=False) if peak == F32_PEAK_TFLOPS else dict(max_iters=30, mu_stop=1e-13, return_U=False)
             t1 = time.perf_counter()
             c_oracle.solve_batch(qcfg, x0[:4 * cores], ub[:4 * cores], stuck[:4 * cores], xref, nthreads=cores, **kw)
             pilot = (time.perf_counter() - t1) / (4 * cores)

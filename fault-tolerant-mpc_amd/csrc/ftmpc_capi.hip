@@ -23,6 +23,7 @@
 #include "ftmpc_linearize.hip"
 #include "ftmpc_solve.hip"
 #include "ftmpc_solve_f64.hip"
+#include "ftmpc_sim.hip"
 
 using ftmpc::DeviceConsts;
 using ftmpc::LinParams;
@@ -601,6 +602,81 @@ int ftmpc_debug_build_qp(ftmpc_handle* h, int64_t B, const double* x0, const dou
         hi[i] = vf[2 * npad + i];
     }
     *n_out = n;
+    return FTMPC_OK;
+}
+
+int ftmpc_simulate_batch(ftmpc_handle* h, int64_t B, int32_t T, double* x, const double* ub, const double* stuck,
+                         const double* xref_traj, const double* uref_traj, const double noise[4], uint64_t seed,
+                         double* u_hist, int32_t* not_converged) {
+    if (!h) return FTMPC_ERR_ARG;
+    if (B < 0 || T < 0 || !x || !ub || !stuck || !xref_traj || !noise) return fail(h, FTMPC_ERR_ARG, "null buffer or negative size");
+    if (B == 0 || T == 0) return FTMPC_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ftmpc_reserve(h, B);
+    if (rc != FTMPC_OK) return rc;
+    const int N = h->cfg.N, NT = h->cfg.NT;
+    hipStream_t s = h->stream;
+    const int64_t ncol = (int64_t)T + N;   // windows t .. t+N for t < T
+    double *d_xr = nullptr, *d_ur = nullptr, *d_warmB = nullptr, *d_hist = nullptr;
+    int32_t* d_bad = nullptr;
+    auto cleanup = [&]() {
+        if (d_xr) (void)hipFree(d_xr);
+        if (d_ur) (void)hipFree(d_ur);
+        if (d_warmB) (void)hipFree(d_warmB);
+        if (d_hist) (void)hipFree(d_hist);
+        if (d_bad) (void)hipFree(d_bad);
+    };
+#define SIM_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e__ = (expr);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            cleanup();                                                                     \
+            return fail(h, FTMPC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+        }                                                                                  \
+    } while (0)
+    SIM_TRY(hipMalloc(&d_xr, (size_t)ncol * 9 * sizeof(double)));
+    if (uref_traj) SIM_TRY(hipMalloc(&d_ur, (size_t)ncol * 6 * sizeof(double)));
+    SIM_TRY(hipMalloc(&d_warmB, (size_t)B * N * NT * sizeof(double)));
+    if (u_hist) SIM_TRY(hipMalloc(&d_hist, (size_t)T * B * NT * sizeof(double)));
+    SIM_TRY(hipMalloc(&d_bad, (size_t)T * sizeof(int32_t)));
+    SIM_TRY(hipMemsetAsync(d_bad, 0, (size_t)T * sizeof(int32_t), s));
+    SIM_TRY(hipMemcpyAsync(d_xr, xref_traj, (size_t)ncol * 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    if (uref_traj) SIM_TRY(hipMemcpyAsync(d_ur, uref_traj, (size_t)ncol * 6 * sizeof(double), hipMemcpyHostToDevice, s));
+    SIM_TRY(hipMemcpyAsync(h->d_x0, x, (size_t)B * 13 * sizeof(double), hipMemcpyHostToDevice, s));
+    SIM_TRY(hipMemcpyAsync(h->d_ub, ub, (size_t)B * NT * sizeof(double), hipMemcpyHostToDevice, s));
+    SIM_TRY(hipMemcpyAsync(h->d_stuck, stuck, (size_t)B * NT * sizeof(double), hipMemcpyHostToDevice, s));
+    ftmpc::SimParams sp;
+    sp.B = B;
+    sp.x = h->d_x0;
+    sp.u0 = h->d_u0;
+    sp.ub = h->d_ub;
+    sp.stuck = h->d_stuck;
+    for (int i = 0; i < 4; ++i) sp.noise[i] = noise[i];
+    sp.seed = seed;
+    sp.u_hist = d_hist;
+    sp.status = h->d_status;
+    sp.bad_count = d_bad;
+    const int64_t nw = B * (int64_t)N * NT;
+    for (int t = 0; t < T; ++t) {
+        // window t..t+N of the reference (column-major, so a plain pointer offset); warm start from step 1 on
+        rc = enqueue(h, B, h->d_x0, h->d_ub, h->d_stuck, d_xr + (int64_t)9 * t, 0, uref_traj ? d_ur + (int64_t)6 * t : nullptr, 0,
+                     t > 0 ? d_warmB : nullptr, h->d_u0, h->d_U, h->d_status, h->d_iters, s, -1);
+        if (rc != FTMPC_OK) {
+            cleanup();
+            return rc;
+        }
+        sp.step = t;
+        hipLaunchKernelGGL(ftmpc::ftmpc_plant_step_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, h->dc, sp);
+        hipLaunchKernelGGL(ftmpc::ftmpc_shift_warm_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, B, N, NT,
+                           (const double*)h->d_U, d_warmB);
+        SIM_TRY(hipGetLastError());
+    }
+    SIM_TRY(hipMemcpyAsync(x, h->d_x0, (size_t)B * 13 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (u_hist) SIM_TRY(hipMemcpyAsync(u_hist, d_hist, (size_t)T * B * NT * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (not_converged) SIM_TRY(hipMemcpyAsync(not_converged, d_bad, (size_t)T * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    SIM_TRY(hipStreamSynchronize(s));
+#undef SIM_TRY
+    cleanup();
     return FTMPC_OK;
 }
 

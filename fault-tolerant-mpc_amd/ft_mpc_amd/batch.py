@@ -148,6 +148,34 @@ class BatchedMPC:
                                                _ptr(status, C.c_int32), _ptr(iters, C.c_int32)))
         return dict(u0=u0, U=U, status=status, iters=iters)
 
+    # -- closed loop on the device (SimulationEnvironment.run_simulation, batched) ------------
+    def simulate(self, x0, ub, stuck, xref_traj, T, uref_traj=None, noise=(1e-3, 1e-3, 1e-3, 1e-3), seed=0,
+                 return_inputs=False):
+        """T closed-loop steps (MPC step -> plant RK4 -> noise -> renormalise) without host round trips.
+        xref_traj: 9 x (T+N) (column t..t+N is the window of step t), uref_traj: 6 x (T+N) or None.
+        Returns dict(x [B,13] final states, u [T,B,NT]|None, not_converged [T])."""
+        N, NT = self.cfg.N, self.cfg.NT
+        x = _f64(x0).reshape(-1, 13).copy()
+        B = x.shape[0]
+        ub = _f64(ub, (B, NT))
+        stuck = _f64(stuck, (B, NT))
+        xr = _f64(xref_traj)
+        if xr.shape != (9, T + N):
+            raise ValueError(f"xref_traj must be 9 x (T+N) = 9 x {T + N}")
+        xr = np.ascontiguousarray(xr.reshape(-1, order="F"))
+        ur = None
+        if uref_traj is not None:
+            ur = _f64(uref_traj)
+            if ur.shape != (6, T + N):
+                raise ValueError("uref_traj must be 6 x (T+N)")
+            ur = np.ascontiguousarray(ur.reshape(-1, order="F"))
+        nz = _f64(noise, 4)
+        uh = np.empty((T, B, NT)) if return_inputs else None
+        bad = np.zeros(T, np.int32)
+        self._check(self.lib.ftmpc_simulate_batch(self._h, B, int(T), _ptr(x), _ptr(ub), _ptr(stuck), _ptr(xr), _ptr(ur),
+                                                  _ptr(nz), C.c_uint64(int(seed)), _ptr(uh), _ptr(bad, C.c_int32)))
+        return dict(x=x, u=uh, not_converged=bad)
+
     # -- device-pointer path (HBM-resident inputs; used by bench.py with torch tensors) --
     def solve_device(self, B, x0, ub, stuck, xref, xref_stride, uref, uref_stride, warmU, out_u0, out_U,
                      status, iters, stream=0):

@@ -139,6 +139,25 @@ int ftmpc_solve_batch_device(ftmpc_handle* h, int64_t B,
  * stage (spiraling_mpc.py:327-329). */
 int ftmpc_shift_warm(int64_t B, int32_t N, int32_t NT, double* warmU);
 
+/*
+ * T closed-loop steps for B independent vehicles entirely on the device -- the batched form of
+ * SimulationEnvironment.run_simulation (ft_mpc/simulation/sim_env.py:77-112) around get_control:
+ * per step  u = MPC step (warm-started from the shifted previous solution, spiraling_mpc.py:324-334),
+ * x <- RK4 plant step with u (sys_model.py:138-226), x += U(0, noise) per component (sim_env.py:88-91,
+ * here from a counter-based generator keyed by `seed` instead of the unseeded global RNG), quaternion
+ * renormalised (sim_env.py:93).  HOST buffers; nothing crosses PCIe between steps.
+ *   x            [B*13]  in: initial states, out: final states
+ *   xref_traj    9 x (T+N) column-major, shared by all vehicles: step t tracks columns t..t+N
+ *                (the padded trajectory of assign_trajectory, spiraling_mpc.py:255-286)
+ *   uref_traj    NULL (hover) or 6 x (T+N) column-major
+ *   noise        amplitudes {position, velocity, orientation, angular velocity} (sim_env.py:25-30: 1e-3 each)
+ *   u_hist       NULL or [T*B*NT]: applied thruster commands
+ *   not_converged NULL or [T]: number of instances whose IPM status was not 0 at each step
+ */
+int ftmpc_simulate_batch(ftmpc_handle* h, int64_t B, int32_t T, double* x, const double* ub, const double* stuck,
+                         const double* xref_traj, const double* uref_traj, const double noise[4], uint64_t seed,
+                         double* u_hist, int32_t* not_converged);
+
 /* Per-kernel device timing of the LAST solve call, measured with hipEvents on the launch
  * stream when enabled.  ms[slot] is the duration of kernel slot `slot` (0 when that kernel was
  * not launched); ftmpc_kernel_name(slot) is the kernel's name as it appears in rocprofv3

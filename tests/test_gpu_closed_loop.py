@@ -73,3 +73,42 @@ def test_solve_mpc_signature():
     x = np.array([1, 0, 1, 1, .5, 0, *IC["orientation"], .3, .8, -.1], float)
     xs, us, dt, cost, status = ctrl.solve_mpc(sm.robot_to_center(x))
     assert len(xs) == 16 and len(us) == 15 and us[0].shape == (16,) and status == "Solve_Succeeded" and cost > 0 and dt > 0
+
+
+def _hover_traj(N, T):
+    xr = np.zeros((9, T + N))
+    xr[8] = 0.6
+    return xr
+
+
+def test_on_device_closed_loop_matches_oracle_loop_f64(gpu_mpc_factory):
+    """ftmpc_simulate_batch (plant step, noise, renormalisation and warm-start shift on the device) against
+    oracle/closed_loop.py: 16-thruster vehicle, shipped double fault, float64 kernel."""
+    from oracle import closed_loop as cl
+    N, NT, B, T = 15, 16, 5, 12
+    mpc = gpu_mpc_factory(N=N, NT=NT, max_iters=40)
+    x0, _, _, _ = qo.make_batch(B, N, NT, 0, 99)
+    ub = np.full((B, NT), 3.4); stuck = np.zeros((B, NT))
+    ub[:, [10, 11]] = 0.0; stuck[:, [10, 11]] = 3.4
+    xr = _hover_traj(N, T)
+    out = mpc.simulate(x0, ub, stuck, xr, T, seed=5, return_inputs=True)
+    xo, uo = cl.simulate(qo.QPConfig(N=N, NT=NT), x0, ub, stuck, xr, T, seed=5)
+    assert out["not_converged"].sum() == 0
+    assert np.abs(out["u"] - uo).max() < 1e-6
+    assert np.abs(out["x"] - xo).max() < 1e-7
+    assert np.allclose(np.linalg.norm(out["x"][:, 6:10], axis=1), 1.0, atol=1e-12)
+
+
+def test_on_device_closed_loop_f32_campaign(gpu_mpc_factory):
+    """fp32 kernels in the loop (8 thrusters, random double faults, warm-started): the closed loop stays
+    within the accumulated per-step tolerance of the float64 oracle loop."""
+    from oracle import closed_loop as cl
+    N, NT, B, T = 20, 8, 24, 8
+    mpc = gpu_mpc_factory(N=N, NT=NT)
+    x0, ub, stuck, _ = qo.make_batch(B, N, NT, 2, 1234)
+    xr = _hover_traj(N, T)
+    out = mpc.simulate(x0, ub, stuck, xr, T, seed=11, return_inputs=True)
+    xo, uo = cl.simulate(qo.QPConfig(N=N, NT=NT), x0, ub, stuck, xr, T, seed=11)
+    assert out["not_converged"].sum() == 0
+    assert np.abs(out["u"] - uo).max() / 3.4 < 5e-4      # 1e-4 per step, perturbation growth over 8 steps
+    assert np.abs(out["x"] - xo).max() < 1e-4

@@ -120,7 +120,7 @@ int build_consts(const ftmpc_config& c, DeviceConsts& d, std::string& why) {
     std::memset(&d, 0, sizeof(d));
     d.N = c.N;
     d.NT = c.NT;
-    d.max_iters = c.max_iters > 0 ? c.max_iters : 16;
+    d.max_iters = c.max_iters > 0 ? c.max_iters : 18;
     if ((c.dtype == FTMPC_DTYPE_F64 || c.N * c.NT > 160) && c.max_iters <= 0) d.max_iters = 30;
     d.dt = c.dt;
     d.inv_mass = 1.0 / c.mass;
@@ -155,7 +155,8 @@ int build_consts(const ftmpc_config& c, DeviceConsts& d, std::string& why) {
     for (int i = 0; i < 9; ++i)
         for (int j = 0; j < 9; ++j) d.LPt[9 * i + j] = s2 * L[9 * j + i];  // sqrt(2) L'
     d.rho = c.rho;
-    d.mu_stop = c.mu_stop > 0 ? c.mu_stop : ((c.dtype == FTMPC_DTYPE_F64 || c.N * c.NT > 160) ? 1e-13 : 1e-10);
+    d.mu_stop = c.mu_stop > 0 ? c.mu_stop : ((c.dtype == FTMPC_DTYPE_F64 || c.N * c.NT > 160) ? 1e-13 : 1e-11);
+    d.mu_refine = 1e-3;
     return FTMPC_OK;
 }
 
@@ -186,10 +187,7 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
     const int lin_blocks = (int)((B + 63) / 64);
     for (bool& u : h->ev_used) u = false;
     if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[0], s));
-    if (h->use_f64)
-        hipLaunchKernelGGL(ftmpc::ftmpc_linearize_kernel<double>, dim3(lin_blocks), dim3(64), 0, s, h->dc, lp);
-    else
-        hipLaunchKernelGGL(ftmpc::ftmpc_linearize_kernel<float>, dim3(lin_blocks), dim3(64), 0, s, h->dc, lp);
+    hipLaunchKernelGGL(ftmpc::ftmpc_linearize_kernel<double>, dim3(lin_blocks), dim3(64), 0, s, h->dc, lp);
     HIP_TRY(h, hipGetLastError());
     if (h->profiling) {
         HIP_TRY(h, hipEventRecord(h->ev[1], s));
@@ -273,7 +271,7 @@ int ftmpc_default_config(ftmpc_config* cfg, int32_t N, int32_t NT) {
     cfg->N = N;
     cfg->NT = NT;
     cfg->dtype = FTMPC_DTYPE_F32;
-    cfg->max_iters = 16;
+    cfg->max_iters = 18;
     cfg->device_id = 0;
     cfg->dt = 0.1;                                   // reactive.yaml:2
     cfg->mass = 16.8;                                // sys_model.py:52
@@ -424,7 +422,7 @@ int ftmpc_reserve(ftmpc_handle* h, int64_t max_batch) {
     float* recf = nullptr;
     if (h->rec) (void)hipFree(h->rec);
     h->rec = nullptr;
-    int rc = grow(h, &recf, B * N * ftmpc::REC_STRIDE * (h->use_f64 ? 2 : 1));
+    int rc = grow(h, &recf, B * N * ftmpc::REC_STRIDE * 2);   // float64 records
     if (rc != FTMPC_OK) return rc;
     h->rec = recf;
     if ((rc = grow(h, &h->d_x0, B * 13)) != FTMPC_OK) return rc;

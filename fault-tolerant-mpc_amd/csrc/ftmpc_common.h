@@ -54,6 +54,7 @@ struct DeviceConsts {
     double sq2Q[9];         // sqrt(2 Q)
     double rho;
     double mu_stop;
+    double mu_refine;       // take the float64 reference gradient once mu falls below this (<= 0: never)
 };
 
 struct LinParams {

@@ -294,7 +294,6 @@ __global__ void __launch_bounds__(64) ftmpc_linearize_kernel(const DeviceConsts 
     }
 }
 
-template __global__ void ftmpc_linearize_kernel<float>(const DeviceConsts, const LinParams);
 template __global__ void ftmpc_linearize_kernel<double>(const DeviceConsts, const LinParams);
 
 }  // namespace ftmpc

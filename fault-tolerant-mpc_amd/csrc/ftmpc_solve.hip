@@ -94,7 +94,8 @@ struct Shape {
     static constexpr int NV = (NPAD + 63) / 64;
     static constexpr int NTILES = NB * (NB + 1) / 2;
     static constexpr int ESTR = (NPAD % 32 == 16) ? NPAD : NPAD + 16;  // ebuf row stride
-    static constexpr int WORK = 2 * NPAD;                               // dvp | xvp
+    static constexpr int WORK = 2 * NPAD;                               // xvp | dvp
+    static constexpr int SEXTRA = (NB == 8) ? 280 : 0;                  // + stage storage of struct_grad (fills the 40 KiB/wave budget)
 };
 
 // ---- cross-lane primitives on the accumulator layout -------------------------------------
@@ -514,6 +515,197 @@ __device__ __forceinline__ void solve_reg(const f32x4 (&T)[NB * (NB + 1) / 2], c
     __syncthreads();
 }
 
+// =============================================================================================
+// Accurate gradient at one reference point (float64, through the stage records instead of the
+// fp32 Hessian):  grad(d) = 2 Bbar' Wbar (e_bar + Bbar d) + 2 Da' R (ut_bar + Da d) + 2 rho (u_bar + d)
+// evaluated by a forward sweep  dc_{k+1} = A_k dc_k + B_k Da d_k  and an adjoint sweep
+// lambda_k = A_k' lambda_{k+1} + W_k (e_k + dc_k),  g_k = 2 Da' (B_k' lambda_{k+1} + R(ut_k + Da d_k)) + 2 rho (..).
+// Lanes 0..12 own one state row each; the stage record (152 doubles) sits in LDS next to the
+// constants {0, 1, dt}.  After this call the IPM evaluates gradients as
+//     grad(d) = grad(d_ref) + H32 (d - d_ref),
+// so the fp32 rounding of H only acts on the (small) distance to the reference point.
+// Cost: ~2 x N short dependent steps, once per instance (~2 % of a solve).
+// =============================================================================================
+__device__ __forceinline__ int aoff(int r, int c) {   // record word of d(next state r)/d(input c); inputs: 13 state + 6 wrench
+    constexpr int ZERO = REC_STRIDE, ONE = REC_STRIDE + 1, DT = REC_STRIDE + 2;
+    if (r >= 13) return ZERO;
+    const int kind = r < 3 ? 0 : (r < 6 ? 1 : (r < 9 ? 2 : 3));   // p, v, w, q row
+    const int a = r < 3 ? r : (r < 6 ? r - 3 : (r < 9 ? r - 6 : r - 9));
+    if (c < 3) return (kind == 0 && c == a) ? ONE : ZERO;                               // d/dp
+    if (c < 6) return (kind == 0 && c - 3 == a) ? DT : ((kind == 1 && c - 3 == a) ? ONE : ZERO);   // d/dv
+    if (c < 9) {                                                                         // d/dw
+        const int j = c - 6;
+        return kind == 0 ? REC_APW + 3 * a + j : (kind == 1 ? REC_AVW + 3 * a + j : (kind == 2 ? REC_AWW + 3 * a + j : REC_AQW + 3 * a + j));
+    }
+    if (c < 13) {                                                                        // d/dq
+        const int j = c - 9;
+        return kind == 0 ? REC_APQ + 4 * a + j : (kind == 1 ? REC_AVQ + 4 * a + j : (kind == 2 ? ZERO : REC_AQQ + 4 * a + j));
+    }
+    if (c < 16) {                                                                        // d/dF
+        const int j = c - 13;
+        return kind == 0 ? REC_BPF + 3 * a + j : (kind == 1 ? REC_BVF + 3 * a + j : ZERO);
+    }
+    const int j = c - 16;                                                                // d/dtau
+    return kind == 0 ? REC_BPT + 3 * a + j : (kind == 1 ? REC_BVT + 3 * a + j : (kind == 2 ? REC_BWT + 3 * a + j : REC_BQT + 3 * a + j));
+}
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f64x4 mfma_d(double a, double b, f64x4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// recg: this instance's float64 records; recd: LDS, REC_STRIDE+4 doubles; dnat: LDS, d in natural order
+// (float); sS: (N+1) x 9 doubles of stage storage (LDS when it fits, else global); gout: global, n doubles.
+// Result: gout[e] = 2 Bbar' Wbar (e_bar + Bbar d) + 2 Da' R (ut_bar + Da d)   (the caller adds 2 rho (u_bar + d)).
+//
+// Every matrix-vector product of the two sweeps is a v_mfma_f64_16x16x4_f64 chain: the 13-vector
+// state/adjoint is kept as an accumulator "column tile" (lane (q, n) holds rows q, q+4, q+8, q+12,
+// replicated over n), which is directly the B operand of the next product (k = 4s + q); the A
+// operand M[m][4s+q] is read from the stage record in LDS through a per-lane word table.  No
+// cross-lane traffic at all.
+__device__ __forceinline__ void struct_grad(const DeviceConsts& C, const double* recg, double* recd, const float* s_Da,
+                                            const float* dnat, double* sS, double* gout, int na, int lane) {
+    constexpr int ZERO = REC_STRIDE;
+    const int N = C.N;
+    const int m = lane & 15, q = lane >> 4;
+    int offX[4], offG[2], offAT[4], offBT[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const int k = 4 * s4 + q;
+        offX[s4] = (k < 13) ? aoff(m, k) : ZERO;                       // A[m][k]
+        offAT[s4] = (k < 13 && m < 13) ? aoff(k, m) : ZERO;           // A[k][m]
+        offBT[s4] = (k < 13 && m < 6) ? aoff(k, 13 + m) : ZERO;       // B[k][m]
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 2; ++s4) offG[s4] = (4 * s4 + q < 6) ? aoff(m, 13 + 4 * s4 + q) : ZERO;   // B[m][g]
+    if (lane == 0) {
+        recd[REC_STRIDE] = 0.0;
+        recd[REC_STRIDE + 1] = 1.0;
+        recd[REC_STRIDE + 2] = C.dt;
+    }
+    // per-lane rows of this lane's column tile: r_i = q + 4 i
+    double qrow[4], rrow[2], da_op[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qrow[i] = (q + 4 * i < 9) ? C.Q[q + 4 * i] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        rrow[i] = (q + 4 * i < 6) ? C.R[q + 4 * i] : 0.0;
+        da_op[i] = (q + 4 * i < 6) ? (double)s_Da[(q + 4 * i) * MAX_NT + m] : 0.0;   // Da[g][a=m]: A operand of Da' z
+    }
+    const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
+    // wrench perturbation tile of stage k: rows g = q and q+4 (< 6) of Da d_k, others zero
+    const float* da0 = s_Da + q * MAX_NT;
+    const float* da1 = s_Da + (q + 4 < 6 ? q + 4 : 0) * MAX_NT;
+    const double m1 = (q + 4 < 6) ? 1.0 : 0.0;
+    auto wrench = [&](int k, double& g0, double& g1) {
+        g0 = 0.0;
+        g1 = 0.0;
+        for (int a = 0; a < na; ++a) {
+            const double dv = (double)dnat[k * na + a];
+            g0 += (double)da0[a] * dv;
+            g1 += (double)da1[a] * dv;
+        }
+        g1 *= m1;
+    };
+    double pf[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) pf[j] = (lane + 64 * j < REC_STRIDE) ? recg[lane + 64 * j] : 0.0;
+    // ---- forward sweep: dc_{k+1} = A_k dc_k + B_k gen_k ----
+    f64x4 dc = zero;
+    for (int k = 0; k < N; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (lane + 64 * j < REC_STRIDE) recd[lane + 64 * j] = pf[j];
+        if (k + 1 < N) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) pf[j] = (lane + 64 * j < REC_STRIDE) ? recg[(int64_t)(k + 1) * REC_STRIDE + lane + 64 * j] : 0.0;
+        }
+        double g0, g1;
+        wrench(k, g0, g1);
+        __syncthreads();
+        f64x4 nx = zero;
+        nx = mfma_d(recd[offX[0]], dc.x, nx);
+        nx = mfma_d(recd[offX[1]], dc.y, nx);
+        nx = mfma_d(recd[offX[2]], dc.z, nx);
+        nx = mfma_d(recd[offX[3]], dc.w, nx);
+        nx = mfma_d(recd[offG[0]], g0, nx);
+        nx = mfma_d(recd[offG[1]], g1, nx);
+        dc = nx;
+        // s_{k+1} = W (e_bar + dc)[0:9]
+        f64x4 sv;
+        if (k + 1 < N) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sv[i] = (q + 4 * i < 9) ? recd[REC_WE + q + 4 * i] + qrow[i] * dc[i] : 0.0;
+        } else {
+            f64x4 t = zero;   // P dc : A operand P[m][4s+q] (9x9, zero padded)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int kk = 4 * s4 + q;
+                const double pa = (m < 9 && kk < 9) ? C.P[9 * m + kk] : 0.0;
+                t = mfma_d(pa, dc[s4], t);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sv[i] = (q + 4 * i < 9) ? recd[REC_WE + q + 4 * i] + t[i] : 0.0;
+        }
+        if (m == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (q + 4 * i < 9) sS[(k + 1) * 9 + q + 4 * i] = sv[i];
+        }
+    }
+    __threadfence_block();
+    // ---- adjoint sweep ----
+#pragma unroll
+    for (int j = 0; j < 3; ++j) pf[j] = (lane + 64 * j < REC_STRIDE) ? recg[(int64_t)(N - 1) * REC_STRIDE + lane + 64 * j] : 0.0;
+    f64x4 lam = zero;
+    for (int k = N - 1; k >= 0; --k) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (lane + 64 * j < REC_STRIDE) recd[lane + 64 * j] = pf[j];
+        if (k > 0) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) pf[j] = (lane + 64 * j < REC_STRIDE) ? recg[(int64_t)(k - 1) * REC_STRIDE + lane + 64 * j] : 0.0;
+        }
+        double g0, g1;
+        wrench(k, g0, g1);
+        __syncthreads();
+        if (k == N - 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lam[i] = (q + 4 * i < 9) ? sS[N * 9 + q + 4 * i] : 0.0;   // lambda_N = s_N
+        }
+        // z = B_k' lambda_{k+1} + R (ut_bar + Da d_k): rows g = q, q+4 (< 6)
+        f64x4 z = zero;
+        z = mfma_d(recd[offBT[0]], lam.x, z);
+        z = mfma_d(recd[offBT[1]], lam.y, z);
+        z = mfma_d(recd[offBT[2]], lam.z, z);
+        z = mfma_d(recd[offBT[3]], lam.w, z);
+        const double z0 = z.x + recd[REC_RUT + q] + rrow[0] * g0;                              // row q  (< 4 <= 6)
+        const double z1 = (q + 4 < 6) ? z.y + recd[REC_RUT + q + 4] + rrow[1] * g1 : 0.0;      // row q+4
+        // g_{k,a} = 2 Da[:,a]' z : A operand Da[g = 4s+q][a = m], B operand z rows 4s+q
+        f64x4 ga = zero;
+        ga = mfma_d(da_op[0], z0, ga);
+        ga = mfma_d(da_op[1], z1, ga);
+        if (m == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (q + 4 * i < na) gout[k * na + q + 4 * i] = 2.0 * ga[i];
+        }
+        // lambda_k = A_k' lambda_{k+1} + [s_k; 0]
+        if (k > 0) {
+            f64x4 nl = zero;
+            nl = mfma_d(recd[offAT[0]], lam.x, nl);
+            nl = mfma_d(recd[offAT[1]], lam.y, nl);
+            nl = mfma_d(recd[offAT[2]], lam.z, nl);
+            nl = mfma_d(recd[offAT[3]], lam.w, nl);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lam[i] = nl[i] + ((q + 4 * i < 9) ? sS[k * 9 + q + 4 * i] : 0.0);
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+}
+
 }  // namespace
 
 template <int NB>
@@ -521,15 +713,15 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
     using SH = Shape<NB>;
     constexpr int NPAD = SH::NPAD, NV = SH::NV, NTILES = SH::NTILES, ESTR = SH::ESTR;
     __shared__ __attribute__((aligned(16))) float tiles[NTILES * 256];
-    __shared__ __attribute__((aligned(16))) float recbuf[2 * REC_STRIDE];
-    __shared__ __attribute__((aligned(16))) float work[SH::WORK];
+    __shared__ __attribute__((aligned(16))) float recbuf[2 * REC_STRIDE + 8];   // two fp32 stage records | one fp64 record + {0,1,dt}
+    __shared__ __attribute__((aligned(16))) float work[SH::WORK + SH::SEXTRA];
     __shared__ __attribute__((aligned(16))) float s_Da[6 * MAX_NT];
     __shared__ unsigned char s_stg[NPAD], s_thr[NPAD];
     __shared__ int s_act[MAX_NT];
     constexpr bool REG = (NB == 8);   // register-resident factorisation (see chol_reg)
     float* const ebuf = tiles;       // build phase only
-    float* const dvp = work;         // d, permuted layout (gradient mat-vec)
-    float* const xvp = work + NPAD;  // rhs / solution of the KKT solves
+    float* const xvp = work;         // rhs / solution of the KKT solves
+    float* const dvp = work + NPAD;  // d, permuted layout (gradient mat-vec); with the tail: struct_grad stage storage
 
     const int lane = threadIdx.x;
     const int li = lane & 15, lq = lane >> 4;
@@ -583,9 +775,15 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
         }
         // zero rows 9..11 of the E buffer (K padding of the MFMA contraction)
         for (int i = lane; i < 3 * ESTR; i += 64) ebuf[9 * ESTR + i] = 0.f;
-        const float* recg = reinterpret_cast<const float*>(P.rec) + inst * (int64_t)N * REC_STRIDE;
+        // stage records are float64 (ftmpc_linearize.hip); the condensing runs on their fp32 rounding,
+        // the reference-point gradient (struct_grad) on the full values
+        typedef double f64x4_t __attribute__((ext_vector_type(4)));
+        const double* recg = reinterpret_cast<const double*>(P.rec) + inst * (int64_t)N * REC_STRIDE;
         f32x4 pre = {0.f, 0.f, 0.f, 0.f};
-        if (lane < REC_STRIDE / 4) pre = *reinterpret_cast<const f32x4*>(recg + 4 * lane);
+        if (lane < REC_STRIDE / 4) {
+            const f64x4_t t = *reinterpret_cast<const f64x4_t*>(recg + 4 * lane);
+            pre = (f32x4){(float)t.x, (float)t.y, (float)t.z, (float)t.w};
+        }
         __syncthreads();
 
         // per-lane column bookkeeping: column e = v*64 + lane
@@ -620,8 +818,10 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
         for (int k = 0; k < N; ++k) {
             float* rb = recbuf + (k & 1) * REC_STRIDE;
             if (lane < REC_STRIDE / 4) *reinterpret_cast<f32x4*>(rb + 4 * lane) = pre;
-            if (k + 1 < N && lane < REC_STRIDE / 4)
-                pre = *reinterpret_cast<const f32x4*>(recg + (k + 1) * REC_STRIDE + 4 * lane);
+            if (k + 1 < N && lane < REC_STRIDE / 4) {
+                const f64x4_t t = *reinterpret_cast<const f64x4_t*>(recg + (k + 1) * REC_STRIDE + 4 * lane);
+                pre = (f32x4){(float)t.x, (float)t.y, (float)t.z, (float)t.w};
+            }
             __syncthreads();
             const bool terminal = (k + 1 == N);
 #pragma unroll
@@ -830,6 +1030,18 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
         f32x4 Tt[REG ? NTILES : 1], Wd[REG ? NB : 1];   // register-resident factor (REG path)
         int status = 1, nit = 0;
         bool first = true;
+        // reference point of the gradient: grad(d) = gref + H32 (d - dref); starts at d = 0 with the fp32 g and
+        // is replaced ONCE by the float64 structured gradient when the iterate is close (mu < mu_refine)
+        double gref[NV];
+        float dref[NV];
+        bool refined = !(C.mu_refine > 0.0);
+        float mu_last = 3.0e38f;
+        double* const sbuf = reinterpret_cast<double*>(P.hscratch + (int64_t)blockIdx.x * P.tile_words);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            gref[v] = (double)gv[v];
+            dref[v] = 0.f;
+        }
         const float inv2n = 1.0f / (float)(2 * n);
         for (int it = 0; it <= C.max_iters; ++it) {
             // H (register-resident accumulator tiles) -> LDS tiles; d (permuted) -> LDS
@@ -845,11 +1057,37 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                     }
                 }
             }
-            // gradient  H d + g  with float64 accumulation
+            float dcur[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) dcur[v] = valid[v] ? ((sl[v] < su[v]) ? lo[v] + sl[v] : hi[v] - su[v]) : 0.f;
+            const bool do_ref = __builtin_amdgcn_readfirstlane(!refined && mu_last < (float)C.mu_refine);
+            if (do_ref) {
+                // one accurate (float64, structured) gradient at the current iterate
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const int e = v * 64 + lane;
+                    if (e < npadr) xvp[e] = dcur[v];
+                }
+                __syncthreads();
+                constexpr int SAVAIL = (NPAD + SH::SEXTRA) * 4;       // bytes of LDS behind dvp
+                double* const gout = sbuf;                               // global, n doubles
+                double* const sS = ((N + 1) * 72 <= SAVAIL) ? reinterpret_cast<double*>(dvp) : sbuf + NPAD;
+                struct_grad(C, recg, reinterpret_cast<double*>(recbuf), s_Da, xvp, sS, gout, na, lane);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const int e = v * 64 + lane;
+                    gref[v] = (valid[v] && e < n) ? gout[e] + 2.0 * C.rho * ((double)ubar[v] + (double)dcur[v]) : 0.0;
+                    dref[v] = dcur[v];
+                    grad[v] = valid[v] ? (float)gref[v] : 0.f;
+                }
+                refined = true;
+                STAMP(8);
+            } else {
+            // gradient  gref + H (d - dref)  with float64 accumulation
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int e = v * 64 + lane;
-                if (e < npadr) dvp[16 * (e >> 4) + vpos(e & 15)] = valid[v] ? ((sl[v] < su[v]) ? lo[v] + sl[v] : hi[v] - su[v]) : 0.f;
+                if (e < npadr) dvp[16 * (e >> 4) + vpos(e & 15)] = dcur[v] - dref[v];
             }
             __syncthreads();
             {
@@ -883,8 +1121,9 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 for (int I = 0; I < NB; ++I)
                     if (I < nbr) {
                         const double a = quad_sum_d(am[I]);
-                        if (lq == (I & 3)) grad[I >> 2] = valid[I >> 2] ? (float)(a + (double)gv[I >> 2]) : 0.f;
+                        if (lq == (I & 3)) grad[I >> 2] = valid[I >> 2] ? (float)(a + gref[I >> 2]) : 0.f;
                     }
+            }
             }
             STAMP(4);
             // complementarity
@@ -911,6 +1150,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
             for (int v = 0; v < NV; ++v)
                 if (valid[v]) t += sl[v] * zl[v] + su[v] * zu[v];
             const float mu = wave_sum(t) * inv2n;
+            mu_last = mu;
             if (__builtin_amdgcn_readfirstlane(!(mu >= mu_stop))) {
                 status = (mu == mu) ? 0 : 2;
                 break;

@@ -1138,7 +1138,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                     }
                 gm = wave_max(gm);
                 wm = wave_max(wm);
-                const float mu0 = fmaxf(0.25f * gm * wm, 1e-3f);
+                const float mu0 = fmaxf(0.02f * gm * wm, 1e-3f);
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
                     zl[v] = valid[v] ? mu0 / sl[v] : 0.f;
@@ -1259,8 +1259,8 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                     if (dzu[v] < 0.f) ad = fminf(ad, -zu[v] * __builtin_amdgcn_rcpf(dzu[v]));
                 }
             }
-            ap = fminf(1.f, 0.995f * wave_min(ap));
-            ad = fminf(1.f, 0.995f * wave_min(ad));
+            ap = fminf(1.f, 0.9995f * wave_min(ap));
+            ad = fminf(1.f, 0.9995f * wave_min(ad));
 #pragma unroll
             for (int v = 0; v < NV; ++v)
                 if (valid[v]) {

@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const Devi
                     }
                 gm = wg_max(gm, red, tid);
                 wm = wg_max(wm, red, tid);
-                const double mu0 = fmax(0.25 * gm * wm, 1e-3);
+                const double mu0 = fmax(0.02 * gm * wm, 1e-3);
 #pragma unroll
                 for (int v = 0; v < NVT; ++v) {
                     zl[v] = valid[v] ? mu0 / sl[v] : 0.0;
@@ -634,8 +634,8 @@ __global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const Devi
                     if (dzu[v] < 0.0) ad = fmin(ad, -zu[v] / dzu[v]);
                 }
             }
-            ap = fmin(1.0, 0.995 * wg_min(ap, red, tid));
-            ad = fmin(1.0, 0.995 * wg_min(ad, red, tid));
+            ap = fmin(1.0, 0.9995 * wg_min(ap, red, tid));
+            ad = fmin(1.0, 0.9995 * wg_min(ad, red, tid));
 #pragma unroll
             for (int v = 0; v < NVT; ++v)
                 if (valid[v]) {

@@ -404,7 +404,7 @@ static int ipm_box(const double* H, const double* g, const double* lo, const dou
                 if (fabs(grad[i]) > gm) gm = fabs(grad[i]);
                 if (hi[i] - lo[i] > wm) wm = hi[i] - lo[i];
             }
-            double mu0 = 0.25 * gm * wm;
+            double mu0 = 0.02 * gm * wm;
             if (mu0 < 1e-3) mu0 = 1e-3;
             for (int i = 0; i < n; ++i) {
                 zl[i] = mu0 / sl[i];
@@ -464,8 +464,8 @@ static int ipm_box(const double* H, const double* g, const double* lo, const dou
             if (dzl < 0 && -zl[i] / dzl < ad) ad = -zl[i] / dzl;
             if (dzu < 0 && -zu[i] / dzu < ad) ad = -zu[i] / dzu;
         }
-        ap = 0.995 * ap; if (ap > 1) ap = 1;
-        ad = 0.995 * ad; if (ad > 1) ad = 1;
+        ap = 0.9995 * ap; if (ap > 1) ap = 1;
+        ad = 0.9995 * ad; if (ad > 1) ad = 1;
         for (int i = 0; i < n; ++i) {
             sl[i] += ap * dd[i];
             su[i] -= ap * dd[i];

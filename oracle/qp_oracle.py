@@ -126,7 +126,7 @@ def ipm_box(H, g, lo, hi, iters=16, dtype=np.float64, polish=False, trace=None, 
          min 1/2 d'H d + g'd   s.t.  lo <= d <= hi      (lo < hi componentwise)
     This is the algorithm the HIP kernel (fault-tolerant-mpc_amd/csrc/ftmpc_solve.hip) and the C
     oracle (oracle/ftmpc_oracle.c) run, step for step:
-      * start at the box centre, duals on the central path at mu0 = max(|grad|_inf * width / 4, 1e-3)
+      * start at the box centre, duals on the central path at mu0 = max(0.02 |grad|_inf * width, 1e-3), step fraction 0.9995
       * slacks s_l = d - lo, s_u = hi - d are carried as state (s += a*ds), never recomputed by
         subtraction; d is read back from the slack of the nearer bound
       * the gradient H d + g is re-evaluated every iteration with float64 accumulation (in the
@@ -148,14 +148,14 @@ def ipm_box(H, g, lo, hi, iters=16, dtype=np.float64, polish=False, trace=None, 
     if mu_stop is None:
         mu_stop = 1e-13 if T is np.float64 else 1e-10
     mu_stop = T(mu_stop)
-    tau = T(0.995)
+    tau = T(0.9995)
     nit = 0
     zl = zu = None
     for it in range(iters + 1):
         d = np.where(sl < su, lo + sl, hi - su)
         grad = (H64 @ d.astype(np.float64) + g64).astype(T)
         if zl is None:
-            mu0 = max(T(np.abs(grad).max()) * T((hi - lo).max()) * T(0.25), T(1e-3))
+            mu0 = max(T(np.abs(grad).max()) * T((hi - lo).max()) * T(0.02), T(1e-3))
             zl = mu0 / sl
             zu = mu0 / su
         mu = (sl @ zl + su @ zu) / T(2 * n)

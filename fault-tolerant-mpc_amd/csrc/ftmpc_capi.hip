@@ -49,9 +49,8 @@ struct ftmpc_handle {
     int32_t *d_status = nullptr, *d_iters = nullptr;
     int64_t cap_xref = 0, cap_uref = 0;
     // per-instantiation Hessian slots
-    float* hs8 = nullptr;
-    float* hs10 = nullptr;
-    int grid8 = 0, grid10 = 0;
+    float* hs[3] = {nullptr, nullptr, nullptr};   // NB = 8, 9, 10 instantiations
+    int grid[3] = {0, 0, 0};
     // float64 general-size path
     bool use_f64 = false;
     int npad_max = 0;
@@ -63,9 +62,9 @@ struct ftmpc_handle {
     float *d_dbgH = nullptr, *d_dbgv = nullptr;
     // profiling
     bool profiling = false;
-    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // start/stop per kernel slot
+    hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // start/stop per kernel slot
     bool ev_valid = false;
-    bool ev_used[4] = {false, false, false, false};
+    bool ev_used[5] = {false, false, false, false, false};
 };
 
 namespace {
@@ -216,43 +215,34 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
         q.dbg_H = h->d_dbgH64;
         q.dbg_vec = h->d_dbgv64;
         const int grid = (int)std::min<int64_t>(B, h->grid64);
-        if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[6], s));
+        if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[8], s));
         hipLaunchKernelGGL(ftmpc::ftmpc_solve_f64_kernel, dim3(grid), dim3(ftmpc::f64k::WG), 0, s, h->dc, q);
         HIP_TRY(h, hipGetLastError());
         if (h->profiling) {
-            HIP_TRY(h, hipEventRecord(h->ev[7], s));
-            h->ev_used[3] = true;
+            HIP_TRY(h, hipEventRecord(h->ev[9], s));
+            h->ev_used[4] = true;
             h->ev_valid = true;
         }
         return FTMPC_OK;
     }
-    // NB = 8 instantiation: instances with at most 128 active variables (and the empty ones)
-    {
-        sp.hscratch = h->hs8;
-        sp.tile_words = (int64_t)tiles_of(8) * 256;
-        sp.nb_lo = 0;
-        sp.nb_hi_owner = (h->nb_max <= 8) ? 1 : 0;
-        const int grid = (int)std::min<int64_t>(B, h->grid8);
-        if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[2], s));
-        hipLaunchKernelGGL(ftmpc::ftmpc_solve_f32_kernel<8>, dim3(grid), dim3(64), 0, s, h->dc, sp);
+    // fp32 instantiations NB = 8, 9, 10: each owns the instances with nb_lo < ceil(n/16) <= NB
+    // (the first also the empty ones, the last reports shapes beyond every instantiation)
+    for (int v = 0; v < 3; ++v) {
+        const int NBv = 8 + v;
+        if (v > 0 && h->nb_max < NBv) break;
+        sp.hscratch = h->hs[v];
+        sp.tile_words = (int64_t)tiles_of(NBv) * 256;
+        sp.nb_lo = (v == 0) ? 0 : NBv - 1;
+        sp.nb_hi_owner = (h->nb_max <= NBv) ? 1 : 0;
+        const int grid = (int)std::min<int64_t>(B, h->grid[v]);
+        if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[2 + 2 * v], s));
+        if (v == 0) hipLaunchKernelGGL(ftmpc::ftmpc_solve_f32_kernel<8>, dim3(grid), dim3(64), 0, s, h->dc, sp);
+        else if (v == 1) hipLaunchKernelGGL(ftmpc::ftmpc_solve_f32_kernel<9>, dim3(grid), dim3(64), 0, s, h->dc, sp);
+        else hipLaunchKernelGGL(ftmpc::ftmpc_solve_f32_kernel<10>, dim3(grid), dim3(64), 0, s, h->dc, sp);
         HIP_TRY(h, hipGetLastError());
         if (h->profiling) {
-            HIP_TRY(h, hipEventRecord(h->ev[3], s));
-            h->ev_used[1] = true;
-        }
-    }
-    if (h->nb_max > 8) {
-        sp.hscratch = h->hs10;
-        sp.tile_words = (int64_t)tiles_of(10) * 256;
-        sp.nb_lo = 8;
-        sp.nb_hi_owner = 1;
-        const int grid = (int)std::min<int64_t>(B, h->grid10);
-        if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[4], s));
-        hipLaunchKernelGGL(ftmpc::ftmpc_solve_f32_kernel<10>, dim3(grid), dim3(64), 0, s, h->dc, sp);
-        HIP_TRY(h, hipGetLastError());
-        if (h->profiling) {
-            HIP_TRY(h, hipEventRecord(h->ev[5], s));
-            h->ev_used[2] = true;
+            HIP_TRY(h, hipEventRecord(h->ev[3 + 2 * v], s));
+            h->ev_used[1 + v] = true;
         }
     }
     if (h->profiling) h->ev_valid = true;
@@ -361,15 +351,13 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
         delete h;
         return fail(nullptr, FTMPC_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
-    for (int i = 0; i < 8; ++i) (void)hipEventCreate(&h->ev[i]);
+    for (int i = 0; i < 10; ++i) (void)hipEventCreate(&h->ev[i]);
     // persistent grids: resident workgroups per CU from the occupancy query (LDS-bound)
-    int per8 = 0, per10 = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per8, ftmpc::ftmpc_solve_f32_kernel<8>, 64, 0);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per10, ftmpc::ftmpc_solve_f32_kernel<10>, 64, 0);
-    if (per8 < 1) per8 = 1;
-    if (per10 < 1) per10 = 1;
-    h->grid8 = h->num_cu * per8;
-    h->grid10 = h->num_cu * per10;
+    int per[3] = {0, 0, 0};
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per[0], ftmpc::ftmpc_solve_f32_kernel<8>, 64, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per[1], ftmpc::ftmpc_solve_f32_kernel<9>, 64, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per[2], ftmpc::ftmpc_solve_f32_kernel<10>, 64, 0);
+    for (int v = 0; v < 3; ++v) h->grid[v] = h->num_cu * (per[v] < 1 ? 1 : per[v]);
     int per64 = 0;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per64, ftmpc::ftmpc_solve_f64_kernel, ftmpc::f64k::WG, 0);
     if (per64 < 1) per64 = 1;
@@ -384,8 +372,9 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
               grow(h, &h->d_dbgH64, (int64_t)h->npad_max * h->npad_max) != FTMPC_OK ||
               grow(h, &h->d_dbgv64, 3 * (int64_t)h->npad_max + 4) != FTMPC_OK;
     } else {
-        bad = grow(h, &h->hs8, (int64_t)h->grid8 * tiles_of(8) * 256) != FTMPC_OK ||
-              (h->nb_max > 8 && grow(h, &h->hs10, (int64_t)h->grid10 * tiles_of(10) * 256) != FTMPC_OK) ||
+        bad = grow(h, &h->hs[0], (int64_t)h->grid[0] * tiles_of(8) * 256) != FTMPC_OK ||
+              (h->nb_max > 8 && grow(h, &h->hs[1], (int64_t)h->grid[1] * tiles_of(9) * 256) != FTMPC_OK) ||
+              (h->nb_max > 9 && grow(h, &h->hs[2], (int64_t)h->grid[2] * tiles_of(10) * 256) != FTMPC_OK) ||
               grow(h, &h->d_dbgH, 4096 * 24 + 160 * 160) != FTMPC_OK || grow(h, &h->d_dbgv, 3 * 160 + 4) != FTMPC_OK;
     }
     if (bad) {
@@ -401,10 +390,10 @@ int ftmpc_destroy(ftmpc_handle* h) {
     if (!h) return FTMPC_OK;
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->rec, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, h->d_uref, h->d_warm, h->d_u0, h->d_U,
-                    h->d_status, h->d_iters, h->hs8, h->hs10, h->d_dbgH, h->d_dbgv, h->Hs, h->Ls, h->Eall, h->d_dbgH64, h->d_dbgv64};
+                    h->d_status, h->d_iters, h->hs[0], h->hs[1], h->hs[2], h->d_dbgH, h->d_dbgv, h->Hs, h->Ls, h->Eall, h->d_dbgH64, h->d_dbgv64};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 10; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -531,10 +520,10 @@ int ftmpc_set_profiling(ftmpc_handle* h, int32_t enabled) {
     return FTMPC_OK;
 }
 
-int ftmpc_last_kernel_ms(ftmpc_handle* h, float ms[4]) {
+int ftmpc_last_kernel_ms(ftmpc_handle* h, float ms[5]) {
     if (!h || !ms) return FTMPC_ERR_ARG;
     if (!h->ev_valid) return fail(h, FTMPC_ERR_ARG, "no profiled solve recorded");
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 5; ++k) {
         ms[k] = 0.f;
         if (!h->ev_used[k]) continue;
         HIP_TRY(h, hipEventSynchronize(h->ev[2 * k + 1]));
@@ -543,10 +532,10 @@ int ftmpc_last_kernel_ms(ftmpc_handle* h, float ms[4]) {
     return FTMPC_OK;
 }
 
-static const char* const k_kernel_names[4] = {"ftmpc_linearize_kernel", "ftmpc_solve_f32_kernel<8>",
+static const char* const k_kernel_names[5] = {"ftmpc_linearize_kernel", "ftmpc_solve_f32_kernel<8>", "ftmpc_solve_f32_kernel<9>",
                                               "ftmpc_solve_f32_kernel<10>", "ftmpc_solve_f64_kernel"};
 
-const char* ftmpc_kernel_name(int32_t slot) { return (slot >= 0 && slot < 4) ? k_kernel_names[slot] : ""; }
+const char* ftmpc_kernel_name(int32_t slot) { return (slot >= 0 && slot < 5) ? k_kernel_names[slot] : ""; }
 
 int ftmpc_debug_build_qp(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, const double* stuck,
                          const double* xref, int64_t xref_stride, const double* uref, int64_t uref_stride,

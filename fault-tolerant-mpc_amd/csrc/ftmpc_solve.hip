@@ -95,7 +95,7 @@ struct Shape {
     static constexpr int NTILES = NB * (NB + 1) / 2;
     static constexpr int ESTR = (NPAD % 32 == 16) ? NPAD : NPAD + 16;  // ebuf row stride
     static constexpr int WORK = 2 * NPAD;                               // xvp | dvp
-    static constexpr int SEXTRA = (NB == 8) ? 280 : 0;                  // + stage storage of struct_grad (fills the 40 KiB/wave budget)
+    static constexpr int SEXTRA = 280;                                  // + stage storage of struct_grad (fills the 40 KiB/wave budget)
 };
 
 // ---- cross-lane primitives on the accumulator layout -------------------------------------
@@ -159,37 +159,73 @@ __device__ __forceinline__ double quad_sum_d(double x) {
 // c[rr] = A[4q+rr][col] (full symmetric tile) on entry; on exit w[rr] = (L^-1)[4q+rr][col].
 // Step j: pivot by v_readlane, row j to every row-group by permlane swaps, column j within each
 // row-group by DPP row_newbcast; every lane updates its own 4 elements (no LDS, no barrier).
-template <int J>
-__device__ __forceinline__ void potrf_step(float (&c)[4], float (&invs)[16], bool& ok, int q, int col) {
+// Lane predicates of the accumulator layout depend on the lane only, so every select of the
+// in-register potrf uses a COMPILE-TIME 64-bit lane mask held in an SGPR pair (one v_cndmask, no
+// compares): lane l = 16 q + col holds rows 4q+rr of column col.
+template <class F>
+constexpr unsigned long long lane_mask(F f) {
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l)
+        if (f(l >> 4, l & 15)) m |= 1ull << l;
+    return m;
+}
+template <unsigned long long M>
+__device__ __forceinline__ float sel(float if_clear, float if_set) {   // per lane: bit set ? if_set : if_clear
+    float o;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(o) : "v"(if_clear), "v"(if_set), "s"(M));
+    return o;
+}
+template <int J, int RR>
+struct PotrfMasks {
+    static constexpr unsigned long long upd = lane_mask([](int q, int col) { return col > J && 4 * q + RR > J; });
+    static constexpr unsigned long long scl = lane_mask([](int q, int col) { return col == J && 4 * q + RR >= J; });
+};
+template <int J, int RR>
+__device__ __forceinline__ void potrf_elem(float& c, float inv, float lcol) {
+    const float lrow = row_bcast<J>(c) * inv;    // L[row][J]
+    const float upd = c - lrow * lcol;
+    c = sel<PotrfMasks<J, RR>::upd>(sel<PotrfMasks<J, RR>::scl>(c, lrow), upd);
+}
+// `work.run<S>()` is called at 80 points of the potrf + inverse (S = 0..79): the caller issues ONE
+// independent MFMA per slot, which then executes in the shadow of this VALU chain (issue is in
+// order, so the two instruction streams must alternate in program order, ~8 VALU per MFMA).
+template <int J, class Work>
+__device__ __forceinline__ void potrf_step(float (&c)[4], float (&invs)[16], bool& ok, int q, int col, const Work& work) {
     constexpr int QJ = J >> 2, RJ = J & 3;
     const float d = readlane_f(c[RJ], 16 * QJ + J);
     ok = ok && (d > 0.0f);
     const float inv = __builtin_amdgcn_rsqf(d);
     invs[J] = inv;
     const float lcol = group_bcast<QJ>(c[RJ]) * inv;   // L[col][J]   (A[J][col] = A[col][J])
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const int row = 4 * q + rr;
-        const float lrow = row_bcast<J>(c[rr]) * inv;    // L[row][J]
-        const float upd = c[rr] - lrow * lcol;
-        c[rr] = (col > J) ? ((row > J) ? upd : c[rr]) : ((col == J && row >= J) ? lrow : c[rr]);
-    }
+    potrf_elem<J, 0>(c[0], inv, lcol);  work.template run<4 * J + 0>();
+    potrf_elem<J, 1>(c[1], inv, lcol);  work.template run<4 * J + 1>();
+    potrf_elem<J, 2>(c[2], inv, lcol);  work.template run<4 * J + 2>();
+    potrf_elem<J, 3>(c[3], inv, lcol);  work.template run<4 * J + 3>();
 }
-template <int K>
+template <int K, int RR>
+struct InvMasks {
+    static constexpr unsigned long long diag = lane_mask([](int, int col) { return col == 4 * K + RR; });
+    static constexpr unsigned long long grp = lane_mask([](int q, int) { return q == K; });
+};
+template <int K, int RR>
+__device__ __forceinline__ void inv_row(const float (&c)[4], const float (&invs)[16], const float (&acc)[4], float (&wk)[4]) {
+    float s = sel<InvMasks<K, RR>::diag>(0.0f, 1.0f) - acc[RR];
+    if (RR > 0) s -= row_bcast<4 * K + 0>(c[RR]) * wk[0];
+    if (RR > 1) s -= row_bcast<4 * K + 1>(c[RR]) * wk[1];
+    if (RR > 2) s -= row_bcast<4 * K + 2>(c[RR]) * wk[2];
+    wk[RR] = s * invs[4 * K + RR];
+}
+template <int K, class Work>
 __device__ __forceinline__ void inv_block(const float (&c)[4], const float (&invs)[16], float (&acc)[4], float (&w)[4],
-                                          int q, int col) {
+                                          int q, int col, const Work& work) {
     // rows 4K..4K+3 (meaningful in row-group K): forward substitution inside the 4x4 diagonal block
     float wk[4];
+    inv_row<K, 0>(c, invs, acc, wk);  work.template run<64 + 4 * K + 0>();
+    inv_row<K, 1>(c, invs, acc, wk);  work.template run<64 + 4 * K + 1>();
+    inv_row<K, 2>(c, invs, acc, wk);  work.template run<64 + 4 * K + 2>();
+    inv_row<K, 3>(c, invs, acc, wk);  work.template run<64 + 4 * K + 3>();
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        float s = ((col == 4 * K + rr) ? 1.0f : 0.0f) - acc[rr];
-        if (rr > 0) s -= row_bcast<4 * K + 0>(c[rr]) * wk[0];
-        if (rr > 1) s -= row_bcast<4 * K + 1>(c[rr]) * wk[1];
-        if (rr > 2) s -= row_bcast<4 * K + 2>(c[rr]) * wk[2];
-        wk[rr] = s * invs[4 * K + rr];
-    }
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) w[rr] = (q == K) ? wk[rr] : w[rr];
+    for (int rr = 0; rr < 4; ++rr) w[rr] = sel<InvMasks<K, 0>::grp>(w[rr], wk[rr]);
     if (K < 3) {
         // block row K of the inverse to every row-group, then acc += L[.,4K..4K+3] W_K
         float wb[4];
@@ -204,26 +240,34 @@ __device__ __forceinline__ void inv_block(const float (&c)[4], const float (&inv
         }
     }
 }
-__device__ __forceinline__ bool potrf_inv16(float (&c)[4], float (&w)[4], int lane) {
+struct NoWork {
+    template <int S>
+    __device__ __forceinline__ void run() const {}
+};
+template <class Work>
+__device__ __forceinline__ bool potrf_inv16(float (&c)[4], float (&w)[4], int lane, const Work& work) {
     const int q = lane >> 4, col = lane & 15;
     float invs[16];
     bool ok = true;
-    potrf_step<0>(c, invs, ok, q, col);  potrf_step<1>(c, invs, ok, q, col);
-    potrf_step<2>(c, invs, ok, q, col);  potrf_step<3>(c, invs, ok, q, col);
-    potrf_step<4>(c, invs, ok, q, col);  potrf_step<5>(c, invs, ok, q, col);
-    potrf_step<6>(c, invs, ok, q, col);  potrf_step<7>(c, invs, ok, q, col);
-    potrf_step<8>(c, invs, ok, q, col);  potrf_step<9>(c, invs, ok, q, col);
-    potrf_step<10>(c, invs, ok, q, col); potrf_step<11>(c, invs, ok, q, col);
-    potrf_step<12>(c, invs, ok, q, col); potrf_step<13>(c, invs, ok, q, col);
-    potrf_step<14>(c, invs, ok, q, col); potrf_step<15>(c, invs, ok, q, col);
+    potrf_step<0>(c, invs, ok, q, col, work);   potrf_step<1>(c, invs, ok, q, col, work);
+    potrf_step<2>(c, invs, ok, q, col, work);   potrf_step<3>(c, invs, ok, q, col, work);
+    potrf_step<4>(c, invs, ok, q, col, work);   potrf_step<5>(c, invs, ok, q, col, work);
+    potrf_step<6>(c, invs, ok, q, col, work);   potrf_step<7>(c, invs, ok, q, col, work);
+    potrf_step<8>(c, invs, ok, q, col, work);   potrf_step<9>(c, invs, ok, q, col, work);
+    potrf_step<10>(c, invs, ok, q, col, work);  potrf_step<11>(c, invs, ok, q, col, work);
+    potrf_step<12>(c, invs, ok, q, col, work);  potrf_step<13>(c, invs, ok, q, col, work);
+    potrf_step<14>(c, invs, ok, q, col, work);  potrf_step<15>(c, invs, ok, q, col, work);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) w[rr] = 0.f;
-    inv_block<0>(c, invs, acc, w, q, col);
-    inv_block<1>(c, invs, acc, w, q, col);
-    inv_block<2>(c, invs, acc, w, q, col);
-    inv_block<3>(c, invs, acc, w, q, col);
+    inv_block<0>(c, invs, acc, w, q, col, work);
+    inv_block<1>(c, invs, acc, w, q, col, work);
+    inv_block<2>(c, invs, acc, w, q, col, work);
+    inv_block<3>(c, invs, acc, w, q, col, work);
     return ok;
+}
+__device__ __forceinline__ bool potrf_inv16(float (&c)[4], float (&w)[4], int lane) {
+    return potrf_inv16(c, w, lane, NoWork{});
 }
 
 // ---- blocked Cholesky of the nb x nb tile matrix in LDS (lower, in place) -----------------
@@ -378,16 +422,33 @@ __device__ __forceinline__ f32x4 mm_tn(const f32x4& X, const f32x4& Y, f32x4 acc
     return acc;
 }
 
-// Out-of-line so that the eight diagonal blocks of the unrolled factorisation share one copy of the
-// ~850-instruction routine (instruction-cache footprint).  A non-positive pivot poisons the result
-// with NaN, which the caller detects.
-__device__ __forceinline__ f32x4 potrf_inv16_call(f32x4 cin, int lane) {
+// A non-positive pivot poisons the result with NaN, which the caller detects.
+template <class Work>
+__device__ __forceinline__ f32x4 potrf_inv16_call(f32x4 cin, int lane, const Work& work) {
     float c[4] = {cin.x, cin.y, cin.z, cin.w}, w[4];
-    const bool ok = potrf_inv16(c, w, lane);
+    const bool ok = potrf_inv16(c, w, lane, work);
     const float poison = ok ? 0.f : __builtin_nanf("");
     const f32x4 r = {w[0] + poison, w[1] + poison, w[2] + poison, w[3] + poison};
     return r;
 }
+
+// The off-diagonal Schur accumulations of block column J, b[I] += T_JK' T_IK (K < J < I): one MFMA per
+// slot of potrf_inv16 (NM <= 48 for NB = 8), consecutive slots hit different accumulators.
+template <int NB, int J>
+struct SchurWork {
+    static constexpr int NI = NB - 1 - J;
+    static constexpr int NM = 4 * J * NI;            // MFMAs
+    static_assert(NM <= 80, "more Schur MFMAs than potrf slots");
+    const f32x4 (&T)[NB * (NB + 1) / 2];
+    f32x4 (&b)[NB];
+    template <int S>
+    __device__ __forceinline__ void run() const {
+        if constexpr (S < NM) {
+            constexpr int K = S / (4 * NI), rem = S % (4 * NI), s4 = rem / NI, I = J + 1 + rem % NI;
+            b[I] = mfma4(T[tidx(J, K)][s4], T[tidx(I, K)][s4], b[I]);
+        }
+    }
+};
 
 // sum over the 16 lanes of a DPP row, result in every lane of the row
 __device__ __forceinline__ float row_sum16(float x) {
@@ -415,21 +476,16 @@ __device__ __forceinline__ void chol_reg_col(const float* tiles, const float* si
             if (K & 1) a1 = mm_tn(T[tidx(J, K)], T[tidx(J, K)], a1);
             else a0 = mm_tn(T[tidx(J, K)], T[tidx(J, K)], a0);
         }
-        // off-diagonal Schur accumulations first: they do not depend on the diagonal block, so the
-        // MFMA pipe works through them while the VALU runs the in-register potrf below
+        // off-diagonal Schur accumulations do not depend on the diagonal block: they are issued in slices
+        // between the steps of the in-register potrf below, so the MFMA pipe works in its shadow
         f32x4 bacc[NB];
 #pragma unroll
-        for (int I = J + 1; I < NB; ++I) bacc[I] = zero;
-#pragma unroll
-        for (int K = 0; K < J; ++K) {
-#pragma unroll
-            for (int I = J + 1; I < NB; ++I) bacc[I] = mm_tn(T[tidx(J, K)], T[tidx(I, K)], bacc[I]);
-        }
+        for (int I = 0; I < NB; ++I) bacc[I] = zero;
         const float sg = sigv[16 * J + li];
         f32x4 cd;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) cd[rr] = tjj[toC[rr]] + ((4 * lq + rr == li) ? sg : 0.f) - (a0[rr] + a1[rr]);
-        const f32x4 w = potrf_inv16_call(cd, lane);
+        const f32x4 w = potrf_inv16_call(cd, lane, SchurWork<NB, J>{T, bacc});
         ok = ok && (w.x == w.x);
         Wd[J] = w;
         // Wt = W' through a 16x17 LDS scratch
@@ -718,7 +774,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
     __shared__ __attribute__((aligned(16))) float s_Da[6 * MAX_NT];
     __shared__ unsigned char s_stg[NPAD], s_thr[NPAD];
     __shared__ int s_act[MAX_NT];
-    constexpr bool REG = (NB == 8);   // register-resident factorisation (see chol_reg)
+    constexpr bool REG = true;        // register-resident factorisation (see chol_reg); the LDS-resident variant (chol_tiles) is kept for reference
     float* const ebuf = tiles;       // build phase only
     float* const xvp = work;         // rhs / solution of the KKT solves
     float* const dvp = work + NPAD;  // d, permuted layout (gradient mat-vec); with the tail: struct_grad stage storage
@@ -1303,6 +1359,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
 }
 
 template __global__ void ftmpc_solve_f32_kernel<8>(const DeviceConsts, const SolveParams);
+template __global__ void ftmpc_solve_f32_kernel<9>(const DeviceConsts, const SolveParams);
 template __global__ void ftmpc_solve_f32_kernel<10>(const DeviceConsts, const SolveParams);
 
 }  // namespace ftmpc

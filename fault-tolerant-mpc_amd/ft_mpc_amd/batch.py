@@ -190,9 +190,9 @@ class BatchedMPC:
 
     def last_kernel_ms(self):
         """{kernel name: device ms} of the last profiled solve (kernels that were launched)."""
-        ms = (C.c_float * 4)()
+        ms = (C.c_float * 5)()
         self._check(self.lib.ftmpc_last_kernel_ms(self._h, ms))
-        return {self.kernel_name(k): float(ms[k]) for k in range(4) if ms[k] > 0}
+        return {self.kernel_name(k): float(ms[k]) for k in range(5) if ms[k] > 0}
 
     # -- test hook ----------------------------------------------------------------------
     def debug_build_qp(self, x0, ub, stuck, xref, inst, uref=None, warmU=None):

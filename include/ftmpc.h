@@ -161,10 +161,10 @@ int ftmpc_simulate_batch(ftmpc_handle* h, int64_t B, int32_t T, double* x, const
 /* Per-kernel device timing of the LAST solve call, measured with hipEvents on the launch
  * stream when enabled.  ms[slot] is the duration of kernel slot `slot` (0 when that kernel was
  * not launched); ftmpc_kernel_name(slot) is the kernel's name as it appears in rocprofv3
- * traces:  0 linearise, 1 condense+IPM fp32 (n<=128), 2 condense+IPM fp32 (n<=160),
- * 3 condense+IPM fp64 (general n). */
+ * traces:  0 linearise, 1..3 condense+IPM fp32 for n <= 128 / 144 / 160, 4 condense+IPM fp64
+ * (general n). */
 int ftmpc_set_profiling(ftmpc_handle* h, int32_t enabled);
-int ftmpc_last_kernel_ms(ftmpc_handle* h, float ms[4]);
+int ftmpc_last_kernel_ms(ftmpc_handle* h, float ms[5]);
 const char* ftmpc_kernel_name(int32_t slot);
 
 /*

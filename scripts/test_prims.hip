@@ -24,6 +24,21 @@ __global__ void k_potrf(const float* A, float* W, float* Lout, int* okout) {
     for (int rr = 0; rr < 4; ++rr) { W[(4 * q + rr) * 16 + col] = w[rr]; Lout[(4 * q + rr) * 16 + col] = c[rr]; }
     if (lane == 0) *okout = ok;
 }
+__global__ void k_potrf_time(const float* A, float* W, unsigned long long* cyc) {
+    const int lane = threadIdx.x, q = lane >> 4, col = lane & 15;
+    float c0[4], w[4];
+    for (int rr = 0; rr < 4; ++rr) c0[rr] = A[(4 * q + rr) * 16 + col];
+    float sum = 0.f;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < 256; ++it) {
+        float c[4] = {c0[0] + sum * 1e-30f, c0[1], c0[2], c0[3]};
+        potrf_inv16(c, w, lane);
+        sum += w[0];
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) *cyc = (t1 - t0) / 256;
+    W[lane] = sum;
+}
 }
 int main() {
     float* d; hipMalloc(&d, 7 * 64 * 4);
@@ -47,6 +62,10 @@ int main() {
     for (int i = 0; i < 16; ++i) for (int j = 0; j <= i; ++j) eL = fmax(eL, fabs(L[i * 16 + j] - Lr[i * 16 + j]));
     // W*L should be identity (lower)
     for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) { double s = 0; for (int k = 0; k < 16; ++k) s += (double)W[i * 16 + k] * Lr[k * 16 + j]; eW = fmax(eW, fabs(s - (i == j))); }
+    unsigned long long* dcy; hipMalloc(&dcy, 8);
+    hipLaunchKernelGGL(ftmpc::k_potrf_time, dim3(1), dim3(64), 0, 0, dA, dW, dcy);
+    unsigned long long cy; hipMemcpy(&cy, dcy, 8, hipMemcpyDeviceToHost);
+    printf("potrf_inv16 alone: %llu cycles per call\n", cy);
     printf("potrf ok=%d  max|L-Lref|=%.3e  max|W*L-I|=%.3e\n", ok, eL, eW);
     double up = 0; for (int i = 0; i < 16; ++i) for (int j = i + 1; j < 16; ++j) up = fmax(up, fabs(W[i * 16 + j]));
     printf("max upper(W)=%.3e\n", up);

@@ -1,26 +1,27 @@
-// ftmpc_solve.hip -- kernel 2 of the MPC QP-step path: condensed-QP build + primal-dual IPM.
+// ftmpc_solve.hip -- kernel 2 of the MPC QP-step path: condensed-QP build + primal-dual IPM (fp32).
 //
 // ONE WAVEFRONT (64 lanes, one workgroup) PER QP INSTANCE, persistent over the batch
 // (instance = blockIdx.x, += gridDim.x).  For its instance the wave
 //   1. propagates the horizon-stacked input-to-state map  G_{k+1} = A_k G_k | B_k D_act
 //      one COLUMN PER LANE in registers (the stage records come from ftmpc_linearize.hip),
 //   2. contracts  H = sum_k E_k' E_k,  E_k = sqrt(2 W_k) G_k[0:9],  with fp32 MFMA
-//      (v_mfma_f32_16x16x4_f32) into register-resident 16x16 accumulator tiles,
+//      (v_mfma_f32_16x16x4_f32) into register-resident 16x16 accumulator tiles, and parks H in LDS,
 //   3. runs a Mehrotra predictor-corrector interior-point method on
 //         min 1/2 d'H d + g'd,  lo <= d <= hi      (d = U - Ubar, active thrusters only)
-//      whose KKT matrix H + Sigma is factorised by a left-looking 16x16-blocked Cholesky in
-//      LDS (SYRK/GEMM/TRSM tile updates on MFMA, diagonal tiles factorised and inverted in
-//      registers with v_readlane broadcasts), solved with the stored diagonal inverses,
-//      and whose gradient H d + g is re-evaluated every iteration with float64 accumulation.
+//      whose KKT matrix H + Sigma is factorised by a left-looking 16x16-blocked Cholesky that lives
+//      ENTIRELY IN REGISTERS (tiles transposed in the MFMA accumulator layout, every tile product an
+//      MFMA on register operands; diagonal tiles factorised and inverted with v_readlane / DPP /
+//      v_permlane swaps), solved with MFMA (forward) and VALU+DPP (backward) substitutions, and whose
+//      gradient is gref + H (d - dref) with float64 accumulation around one accurate float64
+//      reference gradient (struct_grad).
 // The algorithm is the one restated in oracle/qp_oracle.py (ipm_box); the reference solves
 // the corresponding NLP with CasADi/IPOPT (ft_mpc/controllers/spiraling_mpc.py:87-238,319-354)
 // followed by a cvxpy min-norm allocation (controllers/tools/control_allocator.py:65-94).
 //
-// LDS per wave (NB = max tiles per dimension): NB(NB+1)/2 tiles x 1 KiB + ~3 KiB
-//   NB=8  (n<=128): 39.9 KiB -> 4 waves/CU (one per SIMD)
-//   NB=10 (n<=160): 59.4 KiB -> 2 waves/CU
-// H is kept in a per-workgroup global slot (L2/MALL resident) and re-staged into LDS once per
-// IPM iteration because the factorisation overwrites it in place.
+// LDS per wave (NB = tiles per dimension): NB(NB+1)/2 H tiles x 1 KiB + ~4 KiB
+//   NB=8  (n<=128): 40.0 KiB -> 4 waves/CU (one per SIMD)
+//   NB=9  (n<=144): 49.2 KiB -> 3 waves/CU
+//   NB=10 (n<=160): 59.3 KiB -> 2 waves/CU
 #include <hip/hip_runtime.h>
 
 #include "ftmpc_common.h"
@@ -268,139 +269,6 @@ __device__ __forceinline__ bool potrf_inv16(float (&c)[4], float (&w)[4], int la
 }
 __device__ __forceinline__ bool potrf_inv16(float (&c)[4], float (&w)[4], int lane) {
     return potrf_inv16(c, w, lane, NoWork{});
-}
-
-// ---- blocked Cholesky of the nb x nb tile matrix in LDS (lower, in place) -----------------
-// After return: off-diagonal tiles hold L_IJ, diagonal tiles hold W_J = L_JJ^-1.
-// Each tile of block column J is produced TRANSPOSED in the accumulator,
-//     C_IJ' = M_IJ' - sum_K L_JK L_IK',
-// so that the triangular solve  L_IJ' = W_J C_IJ'  takes the accumulator directly as the MFMA B
-// operand (k runs over its row index: register s of row-group q' is k = 4q'+s) -- no LDS round trip.
-template <int NB>
-__device__ __forceinline__ bool chol_tiles(float* tiles, int nb, int lane) {
-    const int li = lane & 15, lq = lane >> 4;
-    const int opoff = chunk_off(li, lq);
-    int toT[4];   // word of element (row li, col 4lq+rr): transposed access of a tile
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) toT[rr] = toff(li, 4 * lq + rr);
-    bool ok = true;
-    for (int J = 0; J < nb; ++J) {
-        f32x4 bJ[NB - 1];
-#pragma unroll
-        for (int K = 0; K < NB - 1; ++K)
-            if (K < J) bJ[K] = lds4(tiles + tidx(J, K) * 256 + opoff);
-        // ---- diagonal tile: factorise + invert in registers ----
-        float* tjj = tiles + tidx(J, J) * 256;
-        {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int K = 0; K < NB - 1; ++K)
-                if (K < J) {
-                    acc = mfma4(bJ[K].x, bJ[K].x, acc);
-                    acc2 = mfma4(bJ[K].y, bJ[K].y, acc2);
-                    acc = mfma4(bJ[K].z, bJ[K].z, acc);
-                    acc2 = mfma4(bJ[K].w, bJ[K].w, acc2);
-                }
-            float c[4], w[4];
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) c[rr] = tjj[toff(4 * lq + rr, li)] - (acc[rr] + acc2[rr]);
-            ok = potrf_inv16(c, w, lane) && ok;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) tjj[toff(4 * lq + rr, li)] = w[rr];
-        }
-        __syncthreads();
-        // A operand of the solve: W[li][4lq+s], s = 0..3
-        float wa[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) wa[s] = tjj[toT[s]];
-        // ---- off-diagonal tiles, two at a time (independent MFMA chains) ----
-        for (int I = J + 1; I < nb; I += 2) {
-            const bool two = (I + 1 < nb);
-            const float* rowA = tiles + tidx(I, 0) * 256;
-            const float* rowB = tiles + tidx(two ? I + 1 : I, 0) * 256;
-            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int K = 0; K < NB - 1; ++K)
-                if (K < J) {
-                    const f32x4 tA = lds4(rowA + K * 256 + opoff);
-                    const f32x4 tB = lds4(rowB + K * 256 + opoff);
-                    a0 = mfma4(bJ[K].x, tA.x, a0);
-                    a1 = mfma4(bJ[K].x, tB.x, a1);
-                    a0 = mfma4(bJ[K].y, tA.y, a0);
-                    a1 = mfma4(bJ[K].y, tB.y, a1);
-                    a0 = mfma4(bJ[K].z, tA.z, a0);
-                    a1 = mfma4(bJ[K].z, tB.z, a1);
-                    a0 = mfma4(bJ[K].w, tA.w, a0);
-                    a1 = mfma4(bJ[K].w, tB.w, a1);
-                }
-            float* tA = tiles + tidx(I, J) * 256;
-            float* tB = tiles + tidx(two ? I + 1 : I, J) * 256;
-            float c0[4], c1[4];
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                c0[rr] = tA[toT[rr]] - a0[rr];
-                c1[rr] = tB[toT[rr]] - a1[rr];
-            }
-            f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                x0 = mfma4(wa[s], c0[s], x0);
-                x1 = mfma4(wa[s], c1[s], x1);
-            }
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) tA[toT[rr]] = x0[rr];
-            if (two) {
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) tB[toT[rr]] = x1[rr];
-            }
-        }
-        __syncthreads();
-    }
-    return ok;
-}
-
-// ---- solve (L L') x = b with the factor of chol_tiles; b/x live in the permuted LDS vector --
-template <int NB>
-__device__ __forceinline__ void solve_tiles(const float* tiles, float* xvp, int nb, int lane) {
-    const int li = lane & 15, lq = lane >> 4;
-    const int opoff = chunk_off(li, lq);
-    const int myp = vpos(li);
-    // forward  L y = b
-    for (int J = 0; J < nb; ++J) {
-        float part = 0.f;
-        const float* rowJ = tiles + tidx(J, 0) * 256;
-        for (int K = 0; K < J; ++K) {
-            const f32x4 t4 = lds4(rowJ + K * 256 + opoff);
-            const f32x4 y4 = lds4(xvp + 16 * K + 4 * lq);
-            part += t4.x * y4.x + t4.y * y4.y + t4.z * y4.z + t4.w * y4.w;
-        }
-        part = quad_sum(part);
-        const float r = xvp[16 * J + myp] - part;
-        const f32x4 w4 = lds4(rowJ + J * 256 + opoff);
-        float y = w4.x * __shfl(r, lq, 64) + w4.y * __shfl(r, 4 + lq, 64) + w4.z * __shfl(r, 8 + lq, 64) +
-                  w4.w * __shfl(r, 12 + lq, 64);
-        y = quad_sum(y);
-        if (lq == 0) xvp[16 * J + myp] = y;
-        __syncthreads();
-    }
-    // backward  L' x = y
-    for (int J = nb - 1; J >= 0; --J) {
-        float part = 0.f;
-        for (int I = J + 1; I < nb; ++I) {
-            const float* t = tiles + tidx(I, J) * 256;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) part += t[toff(4 * lq + rr, li)] * xvp[16 * I + rr * 4 + lq];
-        }
-        part = quad_sum(part);
-        const float r = xvp[16 * J + myp] - part;
-        const float* t = tiles + tidx(J, J) * 256;
-        float x = 0.f;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) x += t[toff(4 * lq + rr, li)] * __shfl(r, 4 * lq + rr, 64);
-        x = quad_sum(x);
-        if (lq == 0) xvp[16 * J + myp] = x;
-        __syncthreads();
-    }
 }
 
 // =============================================================================================
@@ -774,7 +642,6 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
     __shared__ __attribute__((aligned(16))) float s_Da[6 * MAX_NT];
     __shared__ unsigned char s_stg[NPAD], s_thr[NPAD];
     __shared__ int s_act[MAX_NT];
-    constexpr bool REG = true;        // register-resident factorisation (see chol_reg); the LDS-resident variant (chol_tiles) is kept for reference
     float* const ebuf = tiles;       // build phase only
     float* const xvp = work;         // rhs / solution of the KKT solves
     float* const dvp = work + NPAD;  // d, permuted layout (gradient mat-vec); with the tail: struct_grad stage storage
@@ -815,7 +682,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
         }
         // the register-resident path always runs the full NB x NB tile grid (identity padding blocks),
         // which keeps its factorisation free of data-dependent branches
-        const int nbr = REG ? NB : nb;
+        const int nbr = NB;
         const int npadr = 16 * nbr;
         const int myrank = __popcll(amask & ((1ull << lane) - 1ull));
         if (lane < NT && ub_l > 0.0) s_act[myrank] = lane;
@@ -1023,7 +890,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                     }
                 }
             }
-        if constexpr (REG) {
+        {
             // H -> LDS once; it is never overwritten (the factor lives in registers)
             __syncthreads();
 #pragma unroll
@@ -1083,7 +950,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
 
         STAMP(3);
         // ---------------- interior-point iterations ----------------
-        f32x4 Tt[REG ? NTILES : 1], Wd[REG ? NB : 1];   // register-resident factor (REG path)
+        f32x4 Tt[NTILES], Wd[NB];   // register-resident factor
         int status = 1, nit = 0;
         bool first = true;
         // reference point of the gradient: grad(d) = gref + H32 (d - dref); starts at d = 0 with the fp32 g and
@@ -1100,19 +967,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
         }
         const float inv2n = 1.0f / (float)(2 * n);
         for (int it = 0; it <= C.max_iters; ++it) {
-            // H (register-resident accumulator tiles) -> LDS tiles; d (permuted) -> LDS
             __syncthreads();
-            if constexpr (!REG) {
-#pragma unroll
-            for (int I = 0; I < NB; ++I)
-                if (I < nbr) {
-#pragma unroll
-                    for (int J = 0; J <= I; ++J) {
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) tiles[((I * (I + 1)) / 2 + J) * 256 + toff(4 * lq + rr, li)] = acc[(I * (I + 1)) / 2 + J][rr];
-                    }
-                }
-            }
             float dcur[NV];
 #pragma unroll
             for (int v = 0; v < NV; ++v) dcur[v] = valid[v] ? ((sl[v] < su[v]) ? lo[v] + sl[v] : hi[v] - su[v]) : 0.f;
@@ -1215,27 +1070,18 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
             ++nit;
             // KKT matrix: H + Sigma on the diagonal
             float Sig[NV], rsl[NV], rsu[NV];   // 1/s_l, 1/s_u by v_rcp_f32 (1 ulp; the IPM tolerates it)
-            if constexpr (REG) __syncthreads();   // dvp is dead: it becomes the Sigma vector
+            __syncthreads();   // dvp is dead: it becomes the Sigma vector
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 rsl[v] = __builtin_amdgcn_rcpf(sl[v]);
                 rsu[v] = __builtin_amdgcn_rcpf(su[v]);
                 Sig[v] = valid[v] ? zl[v] * rsl[v] + zu[v] * rsu[v] : 0.f;
                 const int e = v * 64 + lane;
-                if (e < npadr) {
-                    if constexpr (REG) {
-                        dvp[e] = Sig[v];
-                    } else {
-                        const int I = e >> 4, r = e & 15;
-                        tiles[((I * (I + 1)) / 2 + I) * 256 + toff(r, r)] += Sig[v];
-                    }
-                }
+                if (e < npadr) dvp[e] = Sig[v];
             }
             __syncthreads();
             STAMP(7);
-            bool ok;
-            if constexpr (REG) ok = chol_reg<NB>(tiles, dvp, recbuf, nbr, lane, Tt, Wd);
-            else ok = chol_tiles<NB>(tiles, nbr, lane);
+            const bool ok = chol_reg<NB>(tiles, dvp, recbuf, nbr, lane, Tt, Wd);
             STAMP(5);
             if (__builtin_amdgcn_readfirstlane(!ok)) {
                 status = 2;
@@ -1245,19 +1091,18 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int e = v * 64 + lane;
-                if (e < npadr) xvp[REG ? e : 16 * (e >> 4) + vpos(e & 15)] = -grad[v];
+                if (e < npadr) xvp[e] = -grad[v];
             }
             __syncthreads();
             STAMP(7);
-            if constexpr (REG) solve_reg<NB>(Tt, Wd, xvp, nbr, lane);
-            else solve_tiles<NB>(tiles, xvp, nbr, lane);
+            solve_reg<NB>(Tt, Wd, xvp, nbr, lane);
             STAMP(6);
             float da[NV], dzl_a[NV], dzu_a[NV];
             float ap = 1.f, ad = 1.f;
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int e = v * 64 + lane;
-                da[v] = (e < npadr && valid[v]) ? xvp[REG ? e : 16 * (e >> 4) + vpos(e & 15)] : 0.f;
+                da[v] = (e < npadr && valid[v]) ? xvp[e] : 0.f;
                 dzl_a[v] = dzu_a[v] = 0.f;
                 if (valid[v]) {
                     dzl_a[v] = -zl[v] - zl[v] * da[v] * rsl[v];
@@ -1290,12 +1135,11 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                     rhs[v] = -(grad[v] - zl[v] + zu[v]) - rcl[v] * rsl[v] + rcu[v] * rsu[v];
                 }
                 const int e = v * 64 + lane;
-                if (e < npadr) xvp[REG ? e : 16 * (e >> 4) + vpos(e & 15)] = rhs[v];
+                if (e < npadr) xvp[e] = rhs[v];
             }
             __syncthreads();
             STAMP(7);
-            if constexpr (REG) solve_reg<NB>(Tt, Wd, xvp, nbr, lane);
-            else solve_tiles<NB>(tiles, xvp, nbr, lane);
+            solve_reg<NB>(Tt, Wd, xvp, nbr, lane);
             STAMP(6);
             float dd[NV], dzl[NV], dzu[NV];
             ap = 1e30f;
@@ -1303,7 +1147,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int e = v * 64 + lane;
-                dd[v] = (e < npadr && valid[v]) ? xvp[REG ? e : 16 * (e >> 4) + vpos(e & 15)] : 0.f;
+                dd[v] = (e < npadr && valid[v]) ? xvp[e] : 0.f;
                 dzl[v] = dzu[v] = 0.f;
                 if (valid[v]) {
                     dzl[v] = (-rcl[v] - zl[v] * dd[v]) * rsl[v];

@@ -57,9 +57,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        sys.exit("bench.py --gpus N (N > 1) must be launched with one rank per GPU: python -m torch.distributed.run "
+                 "--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     if world > 1:
+        # The data path has NO collective (independent instances, batch-sharded): torch.distributed is
+        # only the timing bracket (barrier + max over ranks), on CPU tensors over gloo.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local}"))
+        dist.init_process_group(backend="gloo")
+    # FTMPC_BENCH_SINGLE_DEVICE=1 (tests only) maps every rank to cuda:0 to rehearse the multi-rank path on a 1-GPU box
+    if os.environ.get("FTMPC_BENCH_SINGLE_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
 
@@ -93,7 +101,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -140,3 +140,36 @@ def test_mixed_fault_counts_and_empty_instances(gpu_mpc_factory):
     assert (out["status"] == 0).all()
     assert np.abs(out["u0"] - ref["u0"]).max() / F_MAX <= 1e-4
     assert (out["u0"][31] == 0).all() and out["iters"][31] == 0
+
+
+def test_device_pointer_entry_matches_host_entry(gpu_mpc_factory):
+    """ftmpc_solve_batch_device (HBM-resident buffers on a caller stream; what bench.py times) gives
+    the same answers as the host-buffer entry, including in-place warm-start update (out_U == warmU)."""
+    import torch
+    N, NT, B = 20, 8, 96
+    mpc = gpu_mpc_factory(N=N, NT=NT)
+    x0, ub, stuck, xref = qo.make_batch(B, N, NT, 2, 555)
+    xr = np.ascontiguousarray(xref.reshape(-1, order="F"))
+    host = mpc.solve(x0, ub, stuck, xr, return_U=True)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_x0, d_ub, d_st, d_xr = t(x0), t(ub), t(stuck), t(xr)
+    d_u0 = torch.zeros(B, NT, dtype=torch.float64, device=dev)
+    d_U = torch.zeros(B, N, NT, dtype=torch.float64, device=dev)
+    d_status = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    d_iters = torch.zeros(B, dtype=torch.int32, device=dev)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        mpc.solve_device(B, d_x0.data_ptr(), d_ub.data_ptr(), d_st.data_ptr(), d_xr.data_ptr(), 0, 0, 0, 0,
+                         d_u0.data_ptr(), d_U.data_ptr(), d_status.data_ptr(), d_iters.data_ptr(), s.cuda_stream)
+    s.synchronize()
+    assert (d_status.cpu().numpy() == 0).all()
+    assert np.array_equal(d_u0.cpu().numpy(), host["u0"]) and np.array_equal(d_U.cpu().numpy(), host["U"])
+    # second step, warm-started in place from the first solution
+    with torch.cuda.stream(s):
+        mpc.solve_device(B, d_x0.data_ptr(), d_ub.data_ptr(), d_st.data_ptr(), d_xr.data_ptr(), 0, 0, 0, d_U.data_ptr(),
+                         d_u0.data_ptr(), d_U.data_ptr(), d_status.data_ptr(), d_iters.data_ptr(), s.cuda_stream)
+    s.synchronize()
+    W = host["U"].copy()
+    host2 = mpc.solve(x0, ub, stuck, xr, warmU=W, return_U=True)
+    assert np.array_equal(d_U.cpu().numpy(), host2["U"]) and np.array_equal(W, host2["U"])

@@ -126,10 +126,25 @@ class BatchedMPC:
             us = 0 if uref.size == 6 * (N + 1) else uref.size // B
         return xref, xs, uref, us
 
-    def solve(self, x0, ub, stuck, xref, uref=None, warmU=None, return_U=False):
+    def solve(self, x0, ub, stuck, xref, uref=None, warmU=None, return_U=False, relinearize=0):
         """x0 [B,13], ub/stuck [B,NT], xref 9x(N+1) column-major flat (shared) or [B, 9(N+1)],
         uref likewise with 6 rows or None (hover), warmU [B,N,NT] or None (updated in place).
+        relinearize=k runs k further QP steps, each linearised about the previous solution (sequential
+        QP towards the reference's nonlinear program; iterations accumulate).
         Returns dict(u0 [B,NT], U [B,N,NT]|None, status [B], iters [B])."""
+        if relinearize > 0:
+            out = self.solve(x0, ub, stuck, xref, uref=uref, warmU=warmU, return_U=True)
+            W = np.ascontiguousarray(out["U"])
+            iters = out["iters"].copy()
+            for _ in range(int(relinearize)):
+                out = self.solve(x0, ub, stuck, xref, uref=uref, warmU=W, return_U=True)   # W <- U* in place
+                iters += out["iters"]
+            if warmU is not None:
+                warmU[...] = W.reshape(warmU.shape)
+            out["iters"] = iters
+            if not return_U:
+                out["U"] = None
+            return out
         N, NT = self.cfg.N, self.cfg.NT
         x0 = _f64(x0).reshape(-1, 13)
         B = x0.shape[0]

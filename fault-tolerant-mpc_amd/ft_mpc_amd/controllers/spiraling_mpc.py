@@ -68,7 +68,8 @@ class SpiralingController:
         if self.optimal_solution is not None:      # shift by one stage (spiraling_mpc.py:324-334)
             warm = np.vstack([self.optimal_solution[1:], np.zeros((1, self.model.Nu_full))])[None].copy()
         out = self.mpc.solve(np.asarray(x0, float).reshape(1, 13), ub, stuck, self.x_sp.reshape(-1),
-                             uref=self.u_sp.reshape(-1), warmU=warm, return_U=True)
+                             uref=self.u_sp.reshape(-1), warmU=warm, return_U=True,
+                             relinearize=int(self.params.get("sqp_iters", 1)) - 1)
         self.optimal_solution = out["U"][0]
         return out
 

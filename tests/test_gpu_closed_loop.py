@@ -112,3 +112,43 @@ def test_on_device_closed_loop_f32_campaign(gpu_mpc_factory):
     assert out["not_converged"].sum() == 0
     assert np.abs(out["u"] - uo).max() / 3.4 < 5e-4      # 1e-4 per step, perturbation growth over 8 steps
     assert np.abs(out["x"] - xo).max() < 1e-4
+
+
+def test_relinearisation_converges_and_matches_oracle(gpu_mpc_factory):
+    """Sequential QP (re-linearise about the previous solution): the GPU loop equals the oracle loop and
+    the iterates contract (first step: nonlinear dynamics, quadratic terminal cost)."""
+    N, NT, B = 15, 16, 4
+    mpc = gpu_mpc_factory(N=N, NT=NT, max_iters=40)
+    x0, _, _, xref = qo.make_batch(B, N, NT, 0, 321)
+    ub = np.full((B, NT), 3.4); stuck = np.zeros((B, NT))
+    ub[:, 3] = 0.0; stuck[:, 3] = 1.0
+    xr = xref.reshape(-1, order="F")
+    cfg = qo.QPConfig(N=N, NT=NT)
+    outs = [mpc.solve(x0, ub, stuck, xr, return_U=True, relinearize=k)["U"] for k in (0, 1, 2, 3)]
+    W = None
+    for k in range(4):
+        ref = co.solve_batch(cfg, x0, ub, stuck, xref, warmU=W, max_iters=60)
+        assert np.abs(outs[k] - ref["U"]).max() < 1e-6
+        W = ref["U"]
+    # full-step sequential QP (no line search): the iterates contract linearly, instance by instance
+    d = np.array([np.abs(outs[k + 1] - outs[k]).reshape(B, -1).max(axis=1) for k in range(3)])
+    assert (d[2] < d[0]).all()
+
+
+def test_debug_export_has_reference_csv_format(tmp_path):
+    m = SystemModel(0.1)
+    m.set_fault(BrokenThruster(10, 1.0))
+    hist = ControllerDebug()
+    ctrl = SpiralingController(SpiralModel.from_system_model(m), PARAMS, hist, quiet=True)
+    ctrl.load_trajectory("hover", 5)
+    env = SimulationEnvironment(m, ctrl, seed=1)
+    env.set_initial_state(**IC)
+    env.run_simulation(0.5)
+    path = hist.export(str(tmp_path / "debug_data"))
+    lines = open(path).read().splitlines()
+    head = lines[0].lstrip("# ").split(";")
+    assert len(head) == 67 and head[0] == "time" and head[14] == "input_0" and head[-1] == "circle_angular_velocity_error_z"
+    data = np.loadtxt(path, delimiter=";")
+    assert data.shape == (5, 67) and np.allclose(data[:, 0], [0, .1, .2, .3, .4])
+    assert np.allclose(data[:, 14 + 10], 0.0)                      # broken thruster is never commanded
+    assert np.allclose(data[:, 30:33], (m.D @ data[:, 14:30].T).T[:, 0:3])   # force = D u

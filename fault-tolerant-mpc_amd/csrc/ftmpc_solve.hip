@@ -516,23 +516,25 @@ __device__ __forceinline__ void struct_grad(const DeviceConsts& C, const double*
         da_op[i] = (q + 4 * i < 6) ? (double)s_Da[(q + 4 * i) * MAX_NT + m] : 0.0;   // Da[g][a=m]: A operand of Da' z
     }
     const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
-    // wrench perturbation tile of stage k: rows g = q and q+4 (< 6) of Da d_k, others zero
-    const float* da0 = s_Da + q * MAX_NT;
-    const float* da1 = s_Da + (q + 4 < 6 ? q + 4 : 0) * MAX_NT;
-    const double m1 = (q + 4 < 6) ? 1.0 : 0.0;
-    auto wrench = [&](int k, double& g0, double& g1) {
-        g0 = 0.0;
-        g1 = 0.0;
-        for (int a = 0; a < na; ++a) {
-            const double dv = (double)dnat[k * na + a];
-            g0 += (double)da0[a] * dv;
-            g1 += (double)da1[a] * dv;
-        }
-        g1 *= m1;
-    };
-    double pf[3];
+    // wrench perturbations gen_k = Da d_k of ALL stages up front, one (stage, component) pair per lane,
+    // parked behind the gradient in the global scratch (N x 8 doubles) and prefetched with the records
+    double* genS = gout + 16 * ((N * na + 15) / 16);
+    for (int t = lane; t < N * 8; t += 64) {
+        const int k = t >> 3, g = t & 7;
+        double acc = 0.0;
+        if (g < 6)
+            for (int a = 0; a < na; ++a) acc += (double)s_Da[g * MAX_NT + a] * (double)dnat[k * na + a];
+        genS[t] = acc;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // this lane's two wrench rows (g = q and q+4) of stage k
+    const int g1 = (q + 4 < 6) ? q + 4 : 7;      // slot 7 of every stage is zero
+    double pf[3], pg0, pg1;
 #pragma unroll
     for (int j = 0; j < 3; ++j) pf[j] = (lane + 64 * j < REC_STRIDE) ? recg[lane + 64 * j] : 0.0;
+    pg0 = genS[q];
+    pg1 = genS[g1];
     // ---- forward sweep: dc_{k+1} = A_k dc_k + B_k gen_k ----
     f64x4 dc = zero;
     for (int k = 0; k < N; ++k) {
@@ -540,12 +542,13 @@ __device__ __forceinline__ void struct_grad(const DeviceConsts& C, const double*
 #pragma unroll
         for (int j = 0; j < 3; ++j)
             if (lane + 64 * j < REC_STRIDE) recd[lane + 64 * j] = pf[j];
+        const double g0 = pg0, g1v = pg1;
         if (k + 1 < N) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) pf[j] = (lane + 64 * j < REC_STRIDE) ? recg[(int64_t)(k + 1) * REC_STRIDE + lane + 64 * j] : 0.0;
+            pg0 = genS[(k + 1) * 8 + q];
+            pg1 = genS[(k + 1) * 8 + g1];
         }
-        double g0, g1;
-        wrench(k, g0, g1);
         __syncthreads();
         f64x4 nx = zero;
         nx = mfma_d(recd[offX[0]], dc.x, nx);
@@ -553,50 +556,53 @@ __device__ __forceinline__ void struct_grad(const DeviceConsts& C, const double*
         nx = mfma_d(recd[offX[2]], dc.z, nx);
         nx = mfma_d(recd[offX[3]], dc.w, nx);
         nx = mfma_d(recd[offG[0]], g0, nx);
-        nx = mfma_d(recd[offG[1]], g1, nx);
+        nx = mfma_d(recd[offG[1]], g1v, nx);
         dc = nx;
-        // s_{k+1} = W (e_bar + dc)[0:9]
-        f64x4 sv;
-        if (k + 1 < N) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sv[i] = (q + 4 * i < 9) ? recd[REC_WE + q + 4 * i] + qrow[i] * dc[i] : 0.0;
-        } else {
-            f64x4 t = zero;   // P dc : A operand P[m][4s+q] (9x9, zero padded)
+        // s_{k+1} = W (e_bar + dc)[0:9]: this lane's tile rows are q, q+4, q+8 (< 9 only for q = 0), q+12
+        f64x4 t = zero;
+        if (k + 1 == N) {   // terminal weight P: A operand P[m][4s+q] (9x9, zero padded)
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 const int kk = 4 * s4 + q;
                 const double pa = (m < 9 && kk < 9) ? C.P[9 * m + kk] : 0.0;
                 t = mfma_d(pa, dc[s4], t);
             }
+        } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) sv[i] = (q + 4 * i < 9) ? recd[REC_WE + q + 4 * i] + t[i] : 0.0;
+            for (int i = 0; i < 3; ++i) t[i] = qrow[i] * dc[i];
         }
         if (m == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (q + 4 * i < 9) sS[(k + 1) * 9 + q + 4 * i] = sv[i];
+            double* srow = sS + (k + 1) * 9;
+            srow[q] = recd[REC_WE + q] + t.x;
+            srow[q + 4] = recd[REC_WE + q + 4] + t.y;
+            if (q == 0) srow[8] = recd[REC_WE + 8] + t.z;
         }
     }
     __threadfence_block();
     // ---- adjoint sweep ----
 #pragma unroll
     for (int j = 0; j < 3; ++j) pf[j] = (lane + 64 * j < REC_STRIDE) ? recg[(int64_t)(N - 1) * REC_STRIDE + lane + 64 * j] : 0.0;
+    pg0 = genS[(N - 1) * 8 + q];
+    pg1 = genS[(N - 1) * 8 + g1];
     f64x4 lam = zero;
     for (int k = N - 1; k >= 0; --k) {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 3; ++j)
             if (lane + 64 * j < REC_STRIDE) recd[lane + 64 * j] = pf[j];
+        const double g0 = pg0, g1v = pg1;
         if (k > 0) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) pf[j] = (lane + 64 * j < REC_STRIDE) ? recg[(int64_t)(k - 1) * REC_STRIDE + lane + 64 * j] : 0.0;
+            pg0 = genS[(k - 1) * 8 + q];
+            pg1 = genS[(k - 1) * 8 + g1];
         }
-        double g0, g1;
-        wrench(k, g0, g1);
         __syncthreads();
-        if (k == N - 1) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) lam[i] = (q + 4 * i < 9) ? sS[N * 9 + q + 4 * i] : 0.0;   // lambda_N = s_N
+        if (k == N - 1) {   // lambda_N = s_N
+            lam.x = sS[N * 9 + q];
+            lam.y = sS[N * 9 + q + 4];
+            lam.z = (q == 0) ? sS[N * 9 + 8] : 0.0;
+            lam.w = 0.0;
         }
         // z = B_k' lambda_{k+1} + R (ut_bar + Da d_k): rows g = q, q+4 (< 6)
         f64x4 z = zero;
@@ -605,7 +611,7 @@ __device__ __forceinline__ void struct_grad(const DeviceConsts& C, const double*
         z = mfma_d(recd[offBT[2]], lam.z, z);
         z = mfma_d(recd[offBT[3]], lam.w, z);
         const double z0 = z.x + recd[REC_RUT + q] + rrow[0] * g0;                              // row q  (< 4 <= 6)
-        const double z1 = (q + 4 < 6) ? z.y + recd[REC_RUT + q + 4] + rrow[1] * g1 : 0.0;      // row q+4
+        const double z1 = (q + 4 < 6) ? z.y + recd[REC_RUT + q + 4] + rrow[1] * g1v : 0.0;     // row q+4
         // g_{k,a} = 2 Da[:,a]' z : A operand Da[g = 4s+q][a = m], B operand z rows 4s+q
         f64x4 ga = zero;
         ga = mfma_d(da_op[0], z0, ga);
@@ -622,8 +628,10 @@ __device__ __forceinline__ void struct_grad(const DeviceConsts& C, const double*
             nl = mfma_d(recd[offAT[1]], lam.y, nl);
             nl = mfma_d(recd[offAT[2]], lam.z, nl);
             nl = mfma_d(recd[offAT[3]], lam.w, nl);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) lam[i] = nl[i] + ((q + 4 * i < 9) ? sS[k * 9 + q + 4 * i] : 0.0);
+            lam.x = nl.x + sS[k * 9 + q];
+            lam.y = nl.y + sS[k * 9 + q + 4];
+            lam.z = nl.z + ((q == 0) ? sS[k * 9 + 8] : 0.0);
+            lam.w = nl.w;
         }
     }
     __threadfence_block();
@@ -982,7 +990,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 __syncthreads();
                 constexpr int SAVAIL = (NPAD + SH::SEXTRA) * 4;       // bytes of LDS behind dvp
                 double* const gout = sbuf;                               // global, n doubles
-                double* const sS = ((N + 1) * 72 <= SAVAIL) ? reinterpret_cast<double*>(dvp) : sbuf + NPAD;
+                double* const sS = ((N + 1) * 72 <= SAVAIL) ? reinterpret_cast<double*>(dvp) : sbuf + NPAD + 8 * 64;
                 struct_grad(C, recg, reinterpret_cast<double*>(recbuf), s_Da, xvp, sS, gout, na, lane);
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {

@@ -11,6 +11,14 @@ sys.path.insert(0, str(ROOT / "fault-tolerant-mpc_amd"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Tests that hand torch tensors to the C-ABI need ONE HIP runtime in the process: let torch bring
+    # its runtime up first (as bench.py does), the library then binds to the runtime already loaded.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")

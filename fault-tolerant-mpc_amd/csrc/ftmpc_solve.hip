@@ -158,11 +158,17 @@ __device__ __forceinline__ double quad_sum_d(double x) {
 
 // ---- 16x16 Cholesky + inverse of the diagonal tile, in the accumulator layout ---------------
 // c[rr] = A[4q+rr][col] (full symmetric tile) on entry; on exit w[rr] = (L^-1)[4q+rr][col].
-// Step j: pivot by v_readlane, row j to every row-group by permlane swaps, column j within each
-// row-group by DPP row_newbcast; every lane updates its own 4 elements (no LDS, no barrier).
-// Lane predicates of the accumulator layout depend on the lane only, so every select of the
-// in-register potrf uses a COMPILE-TIME 64-bit lane mask held in an SGPR pair (one v_cndmask, no
-// compares): lane l = 16 q + col holds rows 4q+rr of column col.
+// Right-looking elimination WITHOUT scaling the pivot column: after step j column j of the tile is
+// a_j = sqrt(d_j) L[:,j] and is never touched again by anything that matters, so the step is
+//     c[r][col] += bcast_j(c[r]) * nm[col],   nm = -c[j][col] / d_j            (one v_fmac_f32_dpp per register)
+// applied to EVERY lane: the lanes of the columns <= j are dead from here on (they are read only by
+// the row_newbcast of their own step, which is over) and may hold anything, NaN included.
+// The inverse is built alongside: E starts as I, row j of W is E[j]/sqrt(d_j), and
+//     E[r][col] += bcast_j(c[r]) * nw[col],   nw = -E[j][col] / d_j            (c still unscaled -> 1/d, not 1/sqrt d)
+// again on every lane (rows <= j of E are dead once row j has been copied out).  Per step: one
+// v_readlane (pivot), one v_rsq, two row broadcasts through the permlane swaps, 8 fused DPP FMAs,
+// one select.  No LDS, no barrier, no compare: a non-positive pivot shows up in the running minimum
+// of the pivot bit patterns (positive floats order like integers, negative ones are negative).
 template <class F>
 constexpr unsigned long long lane_mask(F f) {
     unsigned long long m = 0;
@@ -170,75 +176,62 @@ constexpr unsigned long long lane_mask(F f) {
         if (f(l >> 4, l & 15)) m |= 1ull << l;
     return m;
 }
+// per lane: bit set ? if_set : if_clear.  The mask is a literal moved into vcc right here (two SALU
+// issues next to a 4-cycle VALU are free); as "s" operands the ~100 distinct masks of the unrolled
+// factorisation get hoisted out of the IPM loop and spilled, each use then pays two v_readlane.
 template <unsigned long long M>
-__device__ __forceinline__ float sel(float if_clear, float if_set) {   // per lane: bit set ? if_set : if_clear
+__device__ __forceinline__ float sel(float if_clear, float if_set) {
     float o;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(o) : "v"(if_clear), "v"(if_set), "s"(M));
+    asm("s_mov_b32 vcc_lo, %3\n\ts_mov_b32 vcc_hi, %4\n\tv_cndmask_b32_e32 %0, %1, %2, vcc"
+        : "=v"(o)
+        : "v"(if_clear), "v"(if_set), "n"((int)(unsigned)(M & 0xffffffffull)), "n"((int)(unsigned)(M >> 32))
+        : "vcc");
     return o;
 }
-template <int J, int RR>
-struct PotrfMasks {
-    static constexpr unsigned long long upd = lane_mask([](int q, int col) { return col > J && 4 * q + RR > J; });
-    static constexpr unsigned long long scl = lane_mask([](int q, int col) { return col == J && 4 * q + RR >= J; });
-};
-template <int J, int RR>
-__device__ __forceinline__ void potrf_elem(float& c, float inv, float lcol) {
-    const float lrow = row_bcast<J>(c) * inv;    // L[row][J]
-    const float upd = c - lrow * lcol;
-    c = sel<PotrfMasks<J, RR>::upd>(sel<PotrfMasks<J, RR>::scl>(c, lrow), upd);
+// d[r] += (lane J of the own 16-lane row of s[r]) * m   for the four registers of a tile.
+// The leading s_nop covers "VALU writes VGPR -> DPP reads it" (2 wait states) for whatever the
+// compiler scheduled right before; the four FMAs are independent of each other.
+template <int J>
+__device__ __forceinline__ void fmac4_rowbcast(float (&d)[4], const float (&s)[4], float m) {
+    asm("s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %4, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %5, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %6, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %7, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+        : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3])
+        : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(m), "n"(J));
 }
+template <int J>
+struct StepMasks {
+    static constexpr unsigned long long grp = lane_mask([](int q, int) { return q == (J >> 2); });
+};
 // `work.run<S>()` is called at 80 points of the potrf + inverse (S = 0..79): the caller issues ONE
 // independent MFMA per slot, which then executes in the shadow of this VALU chain (issue is in
-// order, so the two instruction streams must alternate in program order, ~8 VALU per MFMA).
+// order, so the two instruction streams must alternate in program order).
 template <int J, class Work>
-__device__ __forceinline__ void potrf_step(float (&c)[4], float (&invs)[16], bool& ok, int q, int col, const Work& work) {
+__device__ __forceinline__ void potrf_inv_step(float (&c)[4], float (&e)[4], float (&w)[4], int& dmin, const Work& work) {
     constexpr int QJ = J >> 2, RJ = J & 3;
     const float d = readlane_f(c[RJ], 16 * QJ + J);
-    ok = ok && (d > 0.0f);
+    const int db = __builtin_bit_cast(int, d);
+    dmin = db < dmin ? db : dmin;
     const float inv = __builtin_amdgcn_rsqf(d);
-    invs[J] = inv;
-    const float lcol = group_bcast<QJ>(c[RJ]) * inv;   // L[col][J]   (A[J][col] = A[col][J])
-    potrf_elem<J, 0>(c[0], inv, lcol);  work.template run<4 * J + 0>();
-    potrf_elem<J, 1>(c[1], inv, lcol);  work.template run<4 * J + 1>();
-    potrf_elem<J, 2>(c[2], inv, lcol);  work.template run<4 * J + 2>();
-    potrf_elem<J, 3>(c[3], inv, lcol);  work.template run<4 * J + 3>();
-}
-template <int K, int RR>
-struct InvMasks {
-    static constexpr unsigned long long diag = lane_mask([](int, int col) { return col == 4 * K + RR; });
-    static constexpr unsigned long long grp = lane_mask([](int q, int) { return q == K; });
-};
-template <int K, int RR>
-__device__ __forceinline__ void inv_row(const float (&c)[4], const float (&invs)[16], const float (&acc)[4], float (&wk)[4]) {
-    float s = sel<InvMasks<K, RR>::diag>(0.0f, 1.0f) - acc[RR];
-    if (RR > 0) s -= row_bcast<4 * K + 0>(c[RR]) * wk[0];
-    if (RR > 1) s -= row_bcast<4 * K + 1>(c[RR]) * wk[1];
-    if (RR > 2) s -= row_bcast<4 * K + 2>(c[RR]) * wk[2];
-    wk[RR] = s * invs[4 * K + RR];
-}
-template <int K, class Work>
-__device__ __forceinline__ void inv_block(const float (&c)[4], const float (&invs)[16], float (&acc)[4], float (&w)[4],
-                                          int q, int col, const Work& work) {
-    // rows 4K..4K+3 (meaningful in row-group K): forward substitution inside the 4x4 diagonal block
-    float wk[4];
-    inv_row<K, 0>(c, invs, acc, wk);  work.template run<64 + 4 * K + 0>();
-    inv_row<K, 1>(c, invs, acc, wk);  work.template run<64 + 4 * K + 1>();
-    inv_row<K, 2>(c, invs, acc, wk);  work.template run<64 + 4 * K + 2>();
-    inv_row<K, 3>(c, invs, acc, wk);  work.template run<64 + 4 * K + 3>();
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) w[rr] = sel<InvMasks<K, 0>::grp>(w[rr], wk[rr]);
-    if (K < 3) {
-        // block row K of the inverse to every row-group, then acc += L[.,4K..4K+3] W_K
-        float wb[4];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) wb[kk] = group_bcast<K>(wk[kk]);
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            acc[rr] += row_bcast<4 * K + 0>(c[rr]) * wb[0];
-            acc[rr] += row_bcast<4 * K + 1>(c[rr]) * wb[1];
-            acc[rr] += row_bcast<4 * K + 2>(c[rr]) * wb[2];
-            acc[rr] += row_bcast<4 * K + 3>(c[rr]) * wb[3];
-        }
+    const float nrd = -inv * inv;
+    work.template run<5 * J + 0>();
+    const float ej = group_bcast<QJ>(e[RJ]);      // E[J][col] in every row-group
+    const float wj = ej * inv;                    // W[J][col]
+    work.template run<5 * J + 1>();
+    w[RJ] = sel<StepMasks<J>::grp>(w[RJ], wj);
+    if constexpr (J < 15) {
+        const float rowj = group_bcast<QJ>(c[RJ]);    // A[J][col] (= A[col][J]) in every row-group
+        work.template run<5 * J + 2>();
+        fmac4_rowbcast<J>(e, c, ej * nrd);            // before c's own update: needs the unscaled column J
+        work.template run<5 * J + 3>();
+        fmac4_rowbcast<J>(c, c, rowj * nrd);
+        work.template run<5 * J + 4>();
+    } else {
+        work.template run<5 * J + 2>();
+        work.template run<5 * J + 3>();
+        work.template run<5 * J + 4>();
     }
 }
 struct NoWork {
@@ -248,24 +241,22 @@ struct NoWork {
 template <class Work>
 __device__ __forceinline__ bool potrf_inv16(float (&c)[4], float (&w)[4], int lane, const Work& work) {
     const int q = lane >> 4, col = lane & 15;
-    float invs[16];
-    bool ok = true;
-    potrf_step<0>(c, invs, ok, q, col, work);   potrf_step<1>(c, invs, ok, q, col, work);
-    potrf_step<2>(c, invs, ok, q, col, work);   potrf_step<3>(c, invs, ok, q, col, work);
-    potrf_step<4>(c, invs, ok, q, col, work);   potrf_step<5>(c, invs, ok, q, col, work);
-    potrf_step<6>(c, invs, ok, q, col, work);   potrf_step<7>(c, invs, ok, q, col, work);
-    potrf_step<8>(c, invs, ok, q, col, work);   potrf_step<9>(c, invs, ok, q, col, work);
-    potrf_step<10>(c, invs, ok, q, col, work);  potrf_step<11>(c, invs, ok, q, col, work);
-    potrf_step<12>(c, invs, ok, q, col, work);  potrf_step<13>(c, invs, ok, q, col, work);
-    potrf_step<14>(c, invs, ok, q, col, work);  potrf_step<15>(c, invs, ok, q, col, work);
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float e[4];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) w[rr] = 0.f;
-    inv_block<0>(c, invs, acc, w, q, col, work);
-    inv_block<1>(c, invs, acc, w, q, col, work);
-    inv_block<2>(c, invs, acc, w, q, col, work);
-    inv_block<3>(c, invs, acc, w, q, col, work);
-    return ok;
+    for (int rr = 0; rr < 4; ++rr) {
+        e[rr] = (4 * q + rr == col) ? 1.f : 0.f;
+        w[rr] = 0.f;
+    }
+    int dmin = 0x7f800000;
+    potrf_inv_step<0>(c, e, w, dmin, work);   potrf_inv_step<1>(c, e, w, dmin, work);
+    potrf_inv_step<2>(c, e, w, dmin, work);   potrf_inv_step<3>(c, e, w, dmin, work);
+    potrf_inv_step<4>(c, e, w, dmin, work);   potrf_inv_step<5>(c, e, w, dmin, work);
+    potrf_inv_step<6>(c, e, w, dmin, work);   potrf_inv_step<7>(c, e, w, dmin, work);
+    potrf_inv_step<8>(c, e, w, dmin, work);   potrf_inv_step<9>(c, e, w, dmin, work);
+    potrf_inv_step<10>(c, e, w, dmin, work);  potrf_inv_step<11>(c, e, w, dmin, work);
+    potrf_inv_step<12>(c, e, w, dmin, work);  potrf_inv_step<13>(c, e, w, dmin, work);
+    potrf_inv_step<14>(c, e, w, dmin, work);  potrf_inv_step<15>(c, e, w, dmin, work);
+    return dmin > 0;
 }
 __device__ __forceinline__ bool potrf_inv16(float (&c)[4], float (&w)[4], int lane) {
     return potrf_inv16(c, w, lane, NoWork{});

@@ -66,7 +66,8 @@ int main() {
     hipLaunchKernelGGL(ftmpc::k_potrf_time, dim3(1), dim3(64), 0, 0, dA, dW, dcy);
     unsigned long long cy; hipMemcpy(&cy, dcy, 8, hipMemcpyDeviceToHost);
     printf("potrf_inv16 alone: %llu cycles per call\n", cy);
-    printf("potrf ok=%d  max|L-Lref|=%.3e  max|W*L-I|=%.3e\n", ok, eL, eW);
+    (void)eL;  // the tile itself is no longer a by-product (columns stay unscaled): only W is checked
+    printf("potrf ok=%d  max|W*L-I|=%.3e\n", ok, eW);
     double up = 0; for (int i = 0; i < 16; ++i) for (int j = i + 1; j < 16; ++j) up = fmax(up, fabs(W[i * 16 + j]));
     printf("max upper(W)=%.3e\n", up);
     return 0;

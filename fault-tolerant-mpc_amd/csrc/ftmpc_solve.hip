@@ -31,6 +31,7 @@ namespace ftmpc {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---- tile addressing -------------------------------------------------------------------
 // A 16x16 tile is stored row-major with its 16-B chunks permuted so that the MFMA operand
@@ -167,8 +168,9 @@ __device__ __forceinline__ double quad_sum_d(double x) {
 //     E[r][col] += bcast_j(c[r]) * nw[col],   nw = -E[j][col] / d_j            (c still unscaled -> 1/d, not 1/sqrt d)
 // again on every lane (rows <= j of E are dead once row j has been copied out).  Per step: one
 // v_readlane (pivot), one v_rsq, two row broadcasts through the permlane swaps, 8 fused DPP FMAs,
-// one select.  No LDS, no barrier, no compare: a non-positive pivot shows up in the running minimum
-// of the pivot bit patterns (positive floats order like integers, negative ones are negative).
+// one select.  No LDS, no barrier, no compare: a non-positive pivot d makes rsq(d) NaN or inf, every
+// later nw = -E[j][col]/d has a 0 * inf in it, and W[15][15] (lane 63, register 3) ends up NaN (inf
+// when only the last pivot is bad).
 template <class F>
 constexpr unsigned long long lane_mask(F f) {
     unsigned long long m = 0;
@@ -209,11 +211,9 @@ struct StepMasks {
 // independent MFMA per slot, which then executes in the shadow of this VALU chain (issue is in
 // order, so the two instruction streams must alternate in program order).
 template <int J, class Work>
-__device__ __forceinline__ void potrf_inv_step(float (&c)[4], float (&e)[4], float (&w)[4], int& dmin, const Work& work) {
+__device__ __forceinline__ void potrf_inv_step(float (&c)[4], float (&e)[4], float (&w)[4], const Work& work) {
     constexpr int QJ = J >> 2, RJ = J & 3;
     const float d = readlane_f(c[RJ], 16 * QJ + J);
-    const int db = __builtin_bit_cast(int, d);
-    dmin = db < dmin ? db : dmin;
     const float inv = __builtin_amdgcn_rsqf(d);
     const float nrd = -inv * inv;
     work.template run<5 * J + 0>();
@@ -239,7 +239,7 @@ struct NoWork {
     __device__ __forceinline__ void run() const {}
 };
 template <class Work>
-__device__ __forceinline__ bool potrf_inv16(float (&c)[4], float (&w)[4], int lane, const Work& work) {
+__device__ __forceinline__ void potrf_inv16(float (&c)[4], float (&w)[4], int lane, const Work& work) {
     const int q = lane >> 4, col = lane & 15;
     float e[4];
 #pragma unroll
@@ -247,19 +247,17 @@ __device__ __forceinline__ bool potrf_inv16(float (&c)[4], float (&w)[4], int la
         e[rr] = (4 * q + rr == col) ? 1.f : 0.f;
         w[rr] = 0.f;
     }
-    int dmin = 0x7f800000;
-    potrf_inv_step<0>(c, e, w, dmin, work);   potrf_inv_step<1>(c, e, w, dmin, work);
-    potrf_inv_step<2>(c, e, w, dmin, work);   potrf_inv_step<3>(c, e, w, dmin, work);
-    potrf_inv_step<4>(c, e, w, dmin, work);   potrf_inv_step<5>(c, e, w, dmin, work);
-    potrf_inv_step<6>(c, e, w, dmin, work);   potrf_inv_step<7>(c, e, w, dmin, work);
-    potrf_inv_step<8>(c, e, w, dmin, work);   potrf_inv_step<9>(c, e, w, dmin, work);
-    potrf_inv_step<10>(c, e, w, dmin, work);  potrf_inv_step<11>(c, e, w, dmin, work);
-    potrf_inv_step<12>(c, e, w, dmin, work);  potrf_inv_step<13>(c, e, w, dmin, work);
-    potrf_inv_step<14>(c, e, w, dmin, work);  potrf_inv_step<15>(c, e, w, dmin, work);
-    return dmin > 0;
+    potrf_inv_step<0>(c, e, w, work);   potrf_inv_step<1>(c, e, w, work);
+    potrf_inv_step<2>(c, e, w, work);   potrf_inv_step<3>(c, e, w, work);
+    potrf_inv_step<4>(c, e, w, work);   potrf_inv_step<5>(c, e, w, work);
+    potrf_inv_step<6>(c, e, w, work);   potrf_inv_step<7>(c, e, w, work);
+    potrf_inv_step<8>(c, e, w, work);   potrf_inv_step<9>(c, e, w, work);
+    potrf_inv_step<10>(c, e, w, work);  potrf_inv_step<11>(c, e, w, work);
+    potrf_inv_step<12>(c, e, w, work);  potrf_inv_step<13>(c, e, w, work);
+    potrf_inv_step<14>(c, e, w, work);  potrf_inv_step<15>(c, e, w, work);
 }
-__device__ __forceinline__ bool potrf_inv16(float (&c)[4], float (&w)[4], int lane) {
-    return potrf_inv16(c, w, lane, NoWork{});
+__device__ __forceinline__ void potrf_inv16(float (&c)[4], float (&w)[4], int lane) {
+    potrf_inv16(c, w, lane, NoWork{});
 }
 
 // =============================================================================================
@@ -281,13 +279,12 @@ __device__ __forceinline__ f32x4 mm_tn(const f32x4& X, const f32x4& Y, f32x4 acc
     return acc;
 }
 
-// A non-positive pivot poisons the result with NaN, which the caller detects.
+// A non-positive pivot leaves NaN or inf in W[15][15] (lane 63, .w), which the caller detects.
 template <class Work>
 __device__ __forceinline__ f32x4 potrf_inv16_call(f32x4 cin, int lane, const Work& work) {
     float c[4] = {cin.x, cin.y, cin.z, cin.w}, w[4];
-    const bool ok = potrf_inv16(c, w, lane, work);
-    const float poison = ok ? 0.f : __builtin_nanf("");
-    const f32x4 r = {w[0] + poison, w[1] + poison, w[2] + poison, w[3] + poison};
+    potrf_inv16(c, w, lane, work);
+    const f32x4 r = {w[0], w[1], w[2], w[3]};
     return r;
 }
 
@@ -345,7 +342,7 @@ __device__ __forceinline__ void chol_reg_col(const float* tiles, const float* si
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) cd[rr] = tjj[toC[rr]] + ((4 * lq + rr == li) ? sg : 0.f) - (a0[rr] + a1[rr]);
         const f32x4 w = potrf_inv16_call(cd, lane, SchurWork<NB, J>{T, bacc});
-        ok = ok && (w.x == w.x);
+        ok = ok && (fabsf(w.w) <= 3.0e38f);   // NaN or inf in W[15][15]: non-positive pivot
         Wd[J] = w;
         // Wt = W' through a 16x17 LDS scratch
         __syncthreads();
@@ -383,49 +380,56 @@ __device__ __forceinline__ bool chol_reg(const float* tiles, const float* sigv, 
     return __all(ok);
 }
 
-// xv: LDS vector in natural order; in: right-hand side, out: solution.
-//   forward  (MFMA):        y_J = W_J (b_J - sum_{K<J} L_JK y_K)      vectors as accumulator column tiles
-//   backward (VALU + DPP):  r_J = y_J - sum_{I>J} L_IJ' x_I           with x_I as a per-lane row value
-//                           x_J' = r_J' W_J  (MFMA: mm_tn(R, W_J) replicates x_J[col] over the rows)
+// xv: LDS vector in natural order; in: right-hand side, out: solution.  Matrix-vector work does not
+// belong on the matrix cores (a vector as a 16-column tile wastes 15/16 of every MFMA and each
+// dependent MFMA costs its full 8 passes): both sweeps are packed VALU FMAs on the register tiles,
+// with the two reductions the accumulator layout offers,
+//     over the 16 columns of a row-group (DPP row_ror)    -> "column tile" vectors  v[4q+s] in register s
+//     over the 4 row-groups (permlane swaps)              -> "row" vectors          v[col] in every row-group
+//   forward   r_J = b_J - sum_{K<J} L_JK y_K   (row vector:  sum_q sum_s T_JK[s] y_K[s]),   y_J = W_J r_J   (column tile)
+//   backward  r_J = y_J - sum_{I>J} L_IJ' x_I  (column tile: row sums of T_IJ[s] x_I[col]), x_J = W_J' r_J  (row vector)
 template <int NB>
 __device__ __forceinline__ void solve_reg(const f32x4 (&T)[NB * (NB + 1) / 2], const f32x4 (&Wd)[NB],
                                           float* xv, int nb, int lane) {
     const int li = lane & 15, lq = lane >> 4;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 Y[NB];
 #pragma unroll
     for (int J = 0; J < NB; ++J) {
-        Y[J] = zero;
-        {
-            const f32x4 b = lds4(xv + 16 * J + 4 * lq);
-            f32x4 a0 = zero, a1 = zero;
+        const float brow = xv[16 * J + li];
+        f32x2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f};
 #pragma unroll
-            for (int K = 0; K < J; ++K) {
-                if (K & 1) a1 = mm_tn(T[tidx(J, K)], Y[K], a1);
-                else a0 = mm_tn(T[tidx(J, K)], Y[K], a0);
-            }
-            const f32x4 r = b - (a0 + a1);
-            Y[J] = mm_tn(T[tidx(J, J)], r, zero);
+        for (int K = 0; K < J; ++K) {
+            const f32x4& t = T[tidx(J, K)];
+            p0 += f32x2{t.x, t.y} * f32x2{Y[K].x, Y[K].y};
+            p1 += f32x2{t.z, t.w} * f32x2{Y[K].z, Y[K].w};
         }
+        float r = brow;
+        if (J > 0) r -= quad_sum((p0.x + p0.y) + (p1.x + p1.y));
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) Y[J][s4] = row_sum16(Wd[J][s4] * r);
     }
     __syncthreads();
     float xr[NB];
 #pragma unroll
     for (int J = NB - 1; J >= 0; --J) {
-        xr[J] = 0.f;
-        {
-            f32x4 a = zero;
+        f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
-            for (int I = J + 1; I < NB; ++I) {
-                a += T[tidx(I, J)] * xr[I];
-            }
-            f32x4 r;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) r[rr] = Y[J][rr] - row_sum16(a[rr]);
-            const f32x4 xrow = mm_tn(r, Wd[J], zero);
-            xr[J] = xrow.x;
-            if (lq == 0) xv[16 * J + li] = xr[J];
+        for (int I = J + 1; I < NB; ++I) {
+            const f32x4& t = T[tidx(I, J)];
+            const f32x2 xx = {xr[I], xr[I]};
+            a0 += f32x2{t.x, t.y} * xx;
+            a1 += f32x2{t.z, t.w} * xx;
         }
+        f32x4 r = Y[J];
+        if (J < NB - 1) {
+            r.x -= row_sum16(a0.x);
+            r.y -= row_sum16(a0.y);
+            r.z -= row_sum16(a1.x);
+            r.w -= row_sum16(a1.y);
+        }
+        const f32x2 d2 = f32x2{Wd[J].x, Wd[J].y} * f32x2{r.x, r.y} + f32x2{Wd[J].z, Wd[J].w} * f32x2{r.z, r.w};
+        xr[J] = quad_sum(d2.x + d2.y);
+        if (lq == 0) xv[16 * J + li] = xr[J];
     }
     __syncthreads();
 }

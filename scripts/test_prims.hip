@@ -20,7 +20,8 @@ __global__ void k_potrf(const float* A, float* W, float* Lout, int* okout) {
     const int lane = threadIdx.x, q = lane >> 4, col = lane & 15;
     float c[4], w[4];
     for (int rr = 0; rr < 4; ++rr) c[rr] = A[(4 * q + rr) * 16 + col];
-    bool ok = potrf_inv16(c, w, lane);
+    potrf_inv16(c, w, lane);
+    const bool ok = __all(fabsf(w[3]) <= 3.0e38f);
     for (int rr = 0; rr < 4; ++rr) { W[(4 * q + rr) * 16 + col] = w[rr]; Lout[(4 * q + rr) * 16 + col] = c[rr]; }
     if (lane == 0) *okout = ok;
 }

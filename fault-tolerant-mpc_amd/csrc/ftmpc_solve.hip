@@ -39,6 +39,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // conflict-free ds_read_b128:  word(r, c) = 16 r + 4 ((c&3) ^ g4[r>>2]) + (c>>2).
 // chunk swizzle table {0,2,3,1} by row quad, packed in 2-bit fields (0 | 2<<2 | 3<<4 | 1<<6 = 0x78):
 // makes the four 16-lane service groups of ds_read_b128 hit 16 distinct 4-bank slots.
+// One wave per workgroup: the LDS operations of a wave execute in issue order, so exchanging data
+// between its lanes through LDS needs no s_barrier -- and, unlike __syncthreads(), must not drain the
+// outstanding global loads (stage-record prefetch) or scratch traffic.  A compiler barrier suffices.
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("" ::: "memory"); }
+// same for the few exchanges that go through the per-workgroup global slot: stores must have landed
+__device__ __forceinline__ void wave_global_fence() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ int swz(int rq) { return (0x78 >> (2 * rq)) & 3; }
 __device__ __forceinline__ int toff(int r, int c) { return 16 * r + 4 * ((c & 3) ^ swz(r >> 2)) + (c >> 2); }
 __device__ __forceinline__ int chunk_off(int r, int ch) { return 16 * r + 4 * (ch ^ swz(r >> 2)); }
@@ -95,7 +101,6 @@ struct Shape {
     static constexpr int NPAD = 16 * NB;
     static constexpr int NV = (NPAD + 63) / 64;
     static constexpr int NTILES = NB * (NB + 1) / 2;
-    static constexpr int ESTR = (NPAD % 32 == 16) ? NPAD : NPAD + 16;  // ebuf row stride
     static constexpr int WORK = 2 * NPAD;                               // xvp | dvp
     static constexpr int SEXTRA = 280;                                  // + stage storage of struct_grad (fills the 40 KiB/wave budget)
 };
@@ -345,10 +350,10 @@ __device__ __forceinline__ void chol_reg_col(const float* tiles, const float* si
         ok = ok && (fabsf(w.w) <= 3.0e38f);   // NaN or inf in W[15][15]: non-positive pivot
         Wd[J] = w;
         // Wt = W' through a 16x17 LDS scratch
-        __syncthreads();
+        wave_lds_fence();
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) S[(4 * lq + rr) * 17 + li] = w[rr];
-        __syncthreads();
+        wave_lds_fence();
         f32x4 wt;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) wt[rr] = S[li * 17 + 4 * lq + rr];
@@ -408,7 +413,7 @@ __device__ __forceinline__ void solve_reg(const f32x4 (&T)[NB * (NB + 1) / 2], c
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) Y[J][s4] = row_sum16(Wd[J][s4] * r);
     }
-    __syncthreads();
+    wave_lds_fence();
     float xr[NB];
 #pragma unroll
     for (int J = NB - 1; J >= 0; --J) {
@@ -431,7 +436,7 @@ __device__ __forceinline__ void solve_reg(const f32x4 (&T)[NB * (NB + 1) / 2], c
         xr[J] = quad_sum(d2.x + d2.y);
         if (lq == 0) xv[16 * J + li] = xr[J];
     }
-    __syncthreads();
+    wave_lds_fence();
 }
 
 // =============================================================================================
@@ -481,7 +486,7 @@ __device__ __forceinline__ f64x4 mfma_d(double a, double b, f64x4 c) {
 // replicated over n), which is directly the B operand of the next product (k = 4s + q); the A
 // operand M[m][4s+q] is read from the stage record in LDS through a per-lane word table.  No
 // cross-lane traffic at all.
-__device__ __forceinline__ void struct_grad(const DeviceConsts& C, const double* recg, double* recd, const float* s_Da,
+__device__ __noinline__ void struct_grad(const DeviceConsts& C, const double* recg, double* recd, const float* s_Da,
                                             const float* dnat, double* sS, double* gout, int na, int lane) {
     constexpr int ZERO = REC_STRIDE;
     const int N = C.N;
@@ -522,7 +527,7 @@ __device__ __forceinline__ void struct_grad(const DeviceConsts& C, const double*
         genS[t] = acc;
     }
     __threadfence_block();
-    __syncthreads();
+    wave_global_fence();   // lanes exchange through the global slot here
     // this lane's two wrench rows (g = q and q+4) of stage k
     const int g1 = (q + 4 < 6) ? q + 4 : 7;      // slot 7 of every stage is zero
     double pf[3], pg0, pg1;
@@ -533,7 +538,7 @@ __device__ __forceinline__ void struct_grad(const DeviceConsts& C, const double*
     // ---- forward sweep: dc_{k+1} = A_k dc_k + B_k gen_k ----
     f64x4 dc = zero;
     for (int k = 0; k < N; ++k) {
-        __syncthreads();
+        wave_lds_fence();
 #pragma unroll
         for (int j = 0; j < 3; ++j)
             if (lane + 64 * j < REC_STRIDE) recd[lane + 64 * j] = pf[j];
@@ -544,7 +549,7 @@ __device__ __forceinline__ void struct_grad(const DeviceConsts& C, const double*
             pg0 = genS[(k + 1) * 8 + q];
             pg1 = genS[(k + 1) * 8 + g1];
         }
-        __syncthreads();
+        wave_lds_fence();
         f64x4 nx = zero;
         nx = mfma_d(recd[offX[0]], dc.x, nx);
         nx = mfma_d(recd[offX[1]], dc.y, nx);
@@ -573,7 +578,7 @@ __device__ __forceinline__ void struct_grad(const DeviceConsts& C, const double*
             if (q == 0) srow[8] = recd[REC_WE + 8] + t.z;
         }
     }
-    __threadfence_block();
+    wave_global_fence();   // the stage storage may be the global slot (long horizons)
     // ---- adjoint sweep ----
 #pragma unroll
     for (int j = 0; j < 3; ++j) pf[j] = (lane + 64 * j < REC_STRIDE) ? recg[(int64_t)(N - 1) * REC_STRIDE + lane + 64 * j] : 0.0;
@@ -581,7 +586,7 @@ __device__ __forceinline__ void struct_grad(const DeviceConsts& C, const double*
     pg1 = genS[(N - 1) * 8 + g1];
     f64x4 lam = zero;
     for (int k = N - 1; k >= 0; --k) {
-        __syncthreads();
+        wave_lds_fence();
 #pragma unroll
         for (int j = 0; j < 3; ++j)
             if (lane + 64 * j < REC_STRIDE) recd[lane + 64 * j] = pf[j];
@@ -592,7 +597,7 @@ __device__ __forceinline__ void struct_grad(const DeviceConsts& C, const double*
             pg0 = genS[(k - 1) * 8 + q];
             pg1 = genS[(k - 1) * 8 + g1];
         }
-        __syncthreads();
+        wave_lds_fence();
         if (k == N - 1) {   // lambda_N = s_N
             lam.x = sS[N * 9 + q];
             lam.y = sS[N * 9 + q + 4];
@@ -630,22 +635,59 @@ __device__ __forceinline__ void struct_grad(const DeviceConsts& C, const double*
         }
     }
     __threadfence_block();
-    __syncthreads();
+    wave_global_fence();   // lanes exchange through the global slot here
 }
+
+// ---- dense operand images of the stage matrices ------------------------------------------------
+// State component r (p 0-2, v 3-5, w 6-8, q 9-12) -> row of the 16-row sensitivity tile.  The nine
+// costed components go to rows {4q+s : q, s < 3} (registers 0..2 of row-groups 0..2), so that
+// E' E contracts over three MFMAs; the quaternion takes rows 12, 13, 14 and 3.
+__host__ __device__ constexpr int tile_row(int r) { return r < 9 ? 4 * (r % 3) + r / 3 : (r < 12 ? 12 + (r - 9) : 3); }
+constexpr int DENSE_DUMP = 256 + 128;          // write-only word for record entries that are not matrix entries
+constexpr int DENSE_WORDS = 400;               // A (256) | B (128) | dump, padded
+constexpr int dense_blk(int w, int base, int ncol, int rowc, int colc, bool isB) {
+    const int a = (w - base) / ncol, c = (w - base) % ncol;
+    return isB ? 256 + 8 * tile_row(rowc + a) + (colc + c) : 16 * tile_row(rowc + a) + tile_row(colc + c);
+}
+constexpr int dense_pos(int w) {
+    if (w < REC_APQ) return dense_blk(w, REC_APW, 3, 0, 6, false);
+    if (w < REC_AVW) return dense_blk(w, REC_APQ, 4, 0, 9, false);
+    if (w < REC_AVQ) return dense_blk(w, REC_AVW, 3, 3, 6, false);
+    if (w < REC_AWW) return dense_blk(w, REC_AVQ, 4, 3, 9, false);
+    if (w < REC_AQW) return dense_blk(w, REC_AWW, 3, 6, 6, false);
+    if (w < REC_AQQ) return dense_blk(w, REC_AQW, 3, 9, 6, false);
+    if (w < REC_BPF) return dense_blk(w, REC_AQQ, 4, 9, 9, false);
+    if (w < REC_BPT) return dense_blk(w, REC_BPF, 3, 0, 0, true);
+    if (w < REC_BVF) return dense_blk(w, REC_BPT, 3, 0, 3, true);
+    if (w < REC_BVT) return dense_blk(w, REC_BVF, 3, 3, 0, true);
+    if (w < REC_BWT) return dense_blk(w, REC_BVT, 3, 3, 3, true);
+    if (w < REC_BQT) return dense_blk(w, REC_BWT, 3, 6, 3, true);
+    if (w < REC_WE) return dense_blk(w, REC_BQT, 3, 9, 3, true);
+    return DENSE_DUMP;
+}
+struct DensePosTable {
+    unsigned short v[REC_STRIDE];
+};
+constexpr DensePosTable make_dense_pos() {
+    DensePosTable t{};
+    for (int w = 0; w < REC_STRIDE; ++w) t.v[w] = (unsigned short)dense_pos(w);
+    return t;
+}
+__device__ const DensePosTable k_dense_pos = make_dense_pos();
 
 }  // namespace
 
 template <int NB>
 __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceConsts C, const SolveParams P) {
     using SH = Shape<NB>;
-    constexpr int NPAD = SH::NPAD, NV = SH::NV, NTILES = SH::NTILES, ESTR = SH::ESTR;
+    constexpr int NPAD = SH::NPAD, NV = SH::NV, NTILES = SH::NTILES;
     __shared__ __attribute__((aligned(16))) float tiles[NTILES * 256];
     __shared__ __attribute__((aligned(16))) float recbuf[2 * REC_STRIDE + 8];   // two fp32 stage records | one fp64 record + {0,1,dt}
     __shared__ __attribute__((aligned(16))) float work[SH::WORK + SH::SEXTRA];
     __shared__ __attribute__((aligned(16))) float s_Da[6 * MAX_NT];
     __shared__ unsigned char s_stg[NPAD], s_thr[NPAD];
     __shared__ int s_act[MAX_NT];
-    float* const ebuf = tiles;       // build phase only
+    float* const dense = tiles;      // build phase only: 2 x (A 16x16 | B 16x8 | dump word), then LPt 16x16
     float* const xvp = work;         // rhs / solution of the KKT solves
     float* const dvp = work + NPAD;  // d, permuted layout (gradient mat-vec); with the tail: struct_grad stage storage
 
@@ -654,6 +696,9 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
     const int N = C.N, NT = C.NT;
     const float rho = (float)C.rho;
     const float mu_stop = (float)C.mu_stop;
+    int dpos[4];                     // where this lane's four record words go in the dense images
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dpos[j] = (lane < REC_STRIDE / 4) ? k_dense_pos.v[4 * lane + j] : DENSE_DUMP;
     float Rf[6];
 #pragma unroll
     for (int g = 0; g < 6; ++g) Rf[g] = (float)C.R[g];
@@ -661,7 +706,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
     for (int64_t inst = blockIdx.x; inst < P.B; inst += gridDim.x) {
         STAMP_DECL;
         STAMP_START();
-        __syncthreads();
+        wave_lds_fence();
         // ---------------- prologue: active thrusters, index tables ----------------
         double ub_l = 0.0;
         if (lane < NT) ub_l = P.ub[inst * NT + lane];
@@ -689,7 +734,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
         const int npadr = 16 * nbr;
         const int myrank = __popcll(amask & ((1ull << lane) - 1ull));
         if (lane < NT && ub_l > 0.0) s_act[myrank] = lane;
-        __syncthreads();
+        wave_lds_fence();
         if (lane < na) {
 #pragma unroll
             for (int g = 0; g < 6; ++g) s_Da[g * MAX_NT + lane] = (float)C.D[g * MAX_NT + s_act[lane]];
@@ -699,8 +744,6 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
             s_stg[e] = (unsigned char)(e < n ? s : 255);
             s_thr[e] = (unsigned char)(e < n ? e - s * na : 255);
         }
-        // zero rows 9..11 of the E buffer (K padding of the MFMA contraction)
-        for (int i = lane; i < 3 * ESTR; i += 64) ebuf[9 * ESTR + i] = 0.f;
         // stage records are float64 (ftmpc_linearize.hip); the condensing runs on their fp32 rounding,
         // the reference-point gradient (struct_grad) on the full values
         typedef double f64x4_t __attribute__((ext_vector_type(4)));
@@ -710,12 +753,30 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
             const f64x4_t t = *reinterpret_cast<const f64x4_t*>(recg + 4 * lane);
             pre = (f32x4){(float)t.x, (float)t.y, (float)t.z, (float)t.w};
         }
-        __syncthreads();
+        // dense operand images of the stage matrices (build phase only, in the tile area):
+        //   dense[b] = A_k as 16x16 (rows/columns permuted by tile_row) | [B_pF B_pT; ...] as 16x8
+        // constant entries (I, dt I) and zeros are written here once, the record scatter keeps them.
+        for (int i = lane; i < 2 * DENSE_WORDS + 256; i += 64) dense[i] = 0.f;
+        wave_lds_fence();
+        if (lane < 6) {
+            const int a = lane % 3, isv = lane / 3;              // rows p_a (isv = 0) and v_a (isv = 1)
+#pragma unroll
+            for (int bsel = 0; bsel < 2; ++bsel) {
+                float* dd = dense + bsel * DENSE_WORDS;
+                dd[16 * tile_row(3 * isv + a) + tile_row(3 * isv + a)] = 1.f;
+                if (!isv) dd[16 * tile_row(a) + tile_row(3 + a)] = (float)C.dt;
+            }
+        }
+        for (int i = lane; i < 81; i += 64) {
+            const int r = i / 9, c = i - 9 * r;
+            if (c >= r) dense[2 * DENSE_WORDS + 16 * tile_row(r) + tile_row(c)] = (float)C.LPt[i];
+        }
+        wave_lds_fence();
+        const f32x4 lp4 = lds4(dense + 2 * DENSE_WORDS + 16 * li + 4 * lq);   // A operand of E_N = LPt G9
 
         // per-lane column bookkeeping: column e = v*64 + lane
         int kcol[NV], acol[NV];
         float ubar[NV], ubv[NV], gacc[NV];
-        float G[13][NV];
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int e = v * 64 + lane;
@@ -731,141 +792,125 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                     const float wv = (float)P.warmU[(inst * N + kcol[v]) * NT + t];
                     ubar[v] = fminf(fmaxf(wv, 0.f), ubv[v]);
                 }
-            }
+                // input-cost gradient of the column's own stage: Da[:, a]' (R .* ut_k)
+                float gr = 0.f;
 #pragma unroll
-            for (int r = 0; r < 13; ++r) G[r][v] = 0.f;
+                for (int g = 0; g < 6; ++g) gr += s_Da[g * MAX_NT + acol[v]] * (float)recg[kcol[v] * REC_STRIDE + REC_RUT + g];
+                gacc[v] = gr;
+            }
         }
+        // the sensitivity G = d c_{k+1} / d U as accumulator tiles: G[X] reg s of lane (q, col) is row 4q+s
+        // (tile_row order: the 9 costed components sit in registers 0..2 of row-groups 0..2) of column 16X+col
+        int kX[NB];
+        float DaB[NB][2];           // B operand of the new columns: Da[g = 4s+q][thruster of column 16X+col]
+        f32x4 G[NB];
+        float gpart[NB];
+#pragma unroll
+        for (int X = 0; X < NB; ++X) {
+            kX[X] = s_stg[16 * X + li];
+            const int ax = s_thr[16 * X + li];
+            DaB[X][0] = (ax != 255) ? s_Da[lq * MAX_NT + ax] : 0.f;
+            DaB[X][1] = (ax != 255 && lq < 2) ? s_Da[(4 + lq) * MAX_NT + ax] : 0.f;
+            G[X] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            gpart[X] = 0.f;
+        }
+        float esc[3];               // sqrt(2 Q) of this lane's costed rows (row-group 3 holds the quaternion: 0)
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) esc[s3] = (lq < 3) ? (float)C.sq2Q[3 * s3 + lq] : 0.f;
         f32x4 acc[NTILES];
 #pragma unroll
         for (int t = 0; t < NTILES; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         STAMP(0);
-        // ---------------- build: stage loop ----------------
+        // ---------------- build: stage loop (everything on the matrix cores) ----------------
+        //   G_X <- A_k G_X (+ B_k Da on the columns of stage k),  E_X = sqrt(2W) G_X (rows 0..8),
+        //   acc(I,J) += E_I' E_J,   g += G' W e_k
         for (int k = 0; k < N; ++k) {
             float* rb = recbuf + (k & 1) * REC_STRIDE;
-            if (lane < REC_STRIDE / 4) *reinterpret_cast<f32x4*>(rb + 4 * lane) = pre;
+            float* dd = dense + (k & 1) * DENSE_WORDS;
+            if (lane < REC_STRIDE / 4) {
+                *reinterpret_cast<f32x4*>(rb + 4 * lane) = pre;
+                dd[dpos[0]] = pre.x;
+                dd[dpos[1]] = pre.y;
+                dd[dpos[2]] = pre.z;
+                dd[dpos[3]] = pre.w;
+            }
             if (k + 1 < N && lane < REC_STRIDE / 4) {
                 const f64x4_t t = *reinterpret_cast<const f64x4_t*>(recg + (k + 1) * REC_STRIDE + 4 * lane);
                 pre = (f32x4){(float)t.x, (float)t.y, (float)t.z, (float)t.w};
             }
-            __syncthreads();
+            wave_lds_fence();
             const bool terminal = (k + 1 == N);
+            const f32x4 a4 = lds4(dd + 16 * li + 4 * lq);
+            const float b0 = dd[256 + 8 * li + lq], b1 = dd[256 + 8 * li + 4 + lq];
+            float we[3];
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                if (kcol[v] < k) {
-                    // G <- A_k G  (block-structured, see ftmpc_common.h)
-                    float p[3], vv[3], w[3], q[4];
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) {
-                        p[a] = G[a][v] + (float)C.dt * G[3 + a][v];
-                        vv[a] = G[3 + a][v];
-                        w[a] = 0.f;
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            p[a] += rb[REC_APW + 3 * a + c] * G[6 + c][v];
-                            vv[a] += rb[REC_AVW + 3 * a + c] * G[6 + c][v];
-                            w[a] += rb[REC_AWW + 3 * a + c] * G[6 + c][v];
-                        }
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            p[a] += rb[REC_APQ + 4 * a + c] * G[9 + c][v];
-                            vv[a] += rb[REC_AVQ + 4 * a + c] * G[9 + c][v];
-                        }
-                    }
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        q[a] = 0.f;
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) q[a] += rb[REC_AQW + 3 * a + c] * G[6 + c][v];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) q[a] += rb[REC_AQQ + 4 * a + c] * G[9 + c][v];
-                    }
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) {
-                        G[a][v] = p[a];
-                        G[3 + a][v] = vv[a];
-                        G[6 + a][v] = w[a];
-                    }
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) G[9 + a][v] = q[a];
-                } else if (kcol[v] == k) {
-                    // new column: B_k D_act[:, a]
-                    float F[3], T[3];
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) {
-                        F[a] = s_Da[a * MAX_NT + acol[v]];
-                        T[a] = s_Da[(3 + a) * MAX_NT + acol[v]];
-                    }
-                    float gr = 0.f;
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) gr += F[a] * rb[REC_RUT + a] + T[a] * rb[REC_RUT + 3 + a];
-                    gacc[v] += gr;
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) {
-                        float sp = 0.f, sv = 0.f, sw = 0.f;
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            sp += rb[REC_BPF + 3 * a + c] * F[c] + rb[REC_BPT + 3 * a + c] * T[c];
-                            sv += rb[REC_BVF + 3 * a + c] * F[c] + rb[REC_BVT + 3 * a + c] * T[c];
-                            sw += rb[REC_BWT + 3 * a + c] * T[c];
-                        }
-                        G[a][v] = sp;
-                        G[3 + a][v] = sv;
-                        G[6 + a][v] = sw;
-                    }
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        float sq = 0.f;
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) sq += rb[REC_BQT + 3 * a + c] * T[c];
-                        G[9 + a][v] = sq;
-                    }
-                }
-                // gradient:  G9' (W e)
-                float gs = 0.f;
-#pragma unroll
-                for (int r = 0; r < 9; ++r) gs += G[r][v] * rb[REC_WE + r];
-                gacc[v] += gs;
-                // E = sqrt(2 W) G9  -> LDS
-                const int e = v * 64 + lane;
-                if (e < npadr) {
-                    if (!terminal) {
-#pragma unroll
-                        for (int r = 0; r < 9; ++r) ebuf[r * ESTR + e] = (float)C.sq2Q[r] * G[r][v];
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 9; ++r) {
-                            float s = 0.f;
-#pragma unroll
-                            for (int c = r; c < 9; ++c) s += (float)C.LPt[9 * r + c] * G[c][v];
-                            ebuf[r * ESTR + e] = s;
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            STAMP(1);
-            // MFMA contraction: acc(I,J) += E_I' E_J over the 12 (9 used) rows
+            for (int s3 = 0; s3 < 3; ++s3) we[s3] = (lq < 3) ? rb[REC_WE + 3 * s3 + lq] : 0.f;
             const int Imax = ((k + 1) * na - 1) >> 4;
-            float op[NB][3];
+            const int Xnew = (k * na) >> 4;
+            float E[NB][3];
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int X = 0; X < NB; ++X)
                 if (X <= Imax) {
-#pragma unroll
-                    for (int s = 0; s < 3; ++s) op[X][s] = ebuf[(4 * s + lq) * ESTR + 16 * X + li];
+                    f32x4 o = zero4;
+                    if (X >= Xnew) {
+                        const bool mine = (kX[X] == k);
+                        o = mfma4(b0, mine ? DaB[X][0] : 0.f, o);
+                        o = mfma4(b1, mine ? DaB[X][1] : 0.f, o);
+                    }
+                    o = mfma4(a4.x, G[X].x, o);
+                    o = mfma4(a4.y, G[X].y, o);
+                    o = mfma4(a4.z, G[X].z, o);
+                    o = mfma4(a4.w, G[X].w, o);
+                    G[X] = o;
                 }
+#pragma unroll
+            for (int X = 0; X < NB; ++X)
+                if (X <= Imax) {
+                    gpart[X] += we[0] * G[X].x + we[1] * G[X].y + we[2] * G[X].z;
+                    if (!terminal) {
+                        E[X][0] = esc[0] * G[X].x;
+                        E[X][1] = esc[1] * G[X].y;
+                        E[X][2] = esc[2] * G[X].z;
+                    } else {
+                        f32x4 o = zero4;
+                        o = mfma4(lp4.x, G[X].x, o);
+                        o = mfma4(lp4.y, G[X].y, o);
+                        o = mfma4(lp4.z, G[X].z, o);
+                        o = mfma4(lp4.w, G[X].w, o);
+                        E[X][0] = o.x;
+                        E[X][1] = o.y;
+                        E[X][2] = o.z;
+                    }
+                }
+            STAMP(1);
 #pragma unroll
             for (int I = 0; I < NB; ++I)
                 if (I <= Imax) {
 #pragma unroll
                     for (int J = 0; J <= I; ++J) {
 #pragma unroll
-                        for (int s = 0; s < 3; ++s) acc[(I * (I + 1)) / 2 + J] = mfma4(op[I][s], op[J][s], acc[(I * (I + 1)) / 2 + J]);
+                        for (int s3 = 0; s3 < 3; ++s3) acc[(I * (I + 1)) / 2 + J] = mfma4(E[I][s3], E[J][s3], acc[(I * (I + 1)) / 2 + J]);
                     }
                 }
-            __syncthreads();
             STAMP(2);
         }
+        // column gradients back to the column-per-lane order: column 64v + lane sits in tile 4v + lq
+        {
+            float qs[NB];
+#pragma unroll
+            for (int X = 0; X < NB; ++X) qs[X] = quad_sum(gpart[X]);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                float t = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (4 * v + j < NB) t = (lq == j) ? qs[4 * v + j] : t;
+                gacc[v] += t;
+            }
+        }
+        wave_lds_fence();   // the dense images in the tile area are dead from here
 
         // ---------------- finalise H: + 2 (Da' R Da + rho I) per stage block, unit pad diagonal ----
 #pragma unroll
@@ -895,7 +940,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
             }
         {
             // H -> LDS once; it is never overwritten (the factor lives in registers)
-            __syncthreads();
+            wave_lds_fence();
 #pragma unroll
             for (int I = 0; I < NB; ++I)
                 if (I < nbr) {
@@ -905,7 +950,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                         for (int rr = 0; rr < 4; ++rr) tiles[((I * (I + 1)) / 2 + J) * 256 + toff(4 * lq + rr, li)] = acc[(I * (I + 1)) / 2 + J][rr];
                     }
                 }
-            __syncthreads();
+            wave_lds_fence();
         }
 
         // g, bounds, start point
@@ -970,7 +1015,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
         }
         const float inv2n = 1.0f / (float)(2 * n);
         for (int it = 0; it <= C.max_iters; ++it) {
-            __syncthreads();
+            wave_lds_fence();
             float dcur[NV];
 #pragma unroll
             for (int v = 0; v < NV; ++v) dcur[v] = valid[v] ? ((sl[v] < su[v]) ? lo[v] + sl[v] : hi[v] - su[v]) : 0.f;
@@ -982,7 +1027,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                     const int e = v * 64 + lane;
                     if (e < npadr) xvp[e] = dcur[v];
                 }
-                __syncthreads();
+                wave_lds_fence();
                 constexpr int SAVAIL = (NPAD + SH::SEXTRA) * 4;       // bytes of LDS behind dvp
                 double* const gout = sbuf;                               // global, n doubles
                 double* const sS = ((N + 1) * 72 <= SAVAIL) ? reinterpret_cast<double*>(dvp) : sbuf + NPAD + 8 * 64;
@@ -997,45 +1042,49 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 refined = true;
                 STAMP(8);
             } else {
-            // gradient  gref + H (d - dref)  with float64 accumulation
+            // gradient  gref + H (d - dref)
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int e = v * 64 + lane;
                 if (e < npadr) dvp[16 * (e >> 4) + vpos(e & 15)] = dcur[v] - dref[v];
             }
-            __syncthreads();
+            wave_lds_fence();
             {
-                // J-outer so that each d chunk is converted to float64 once; per-lane partial sums
-                // a[I] cover (row li of block I) x (this lane's 4 columns of block J)
-                double am[NB];
+                // per-lane partial sums a[I] cover (row li of block I) x (this lane's 4 columns of block J).
+                // fp32 is enough here: the product only spans the distance to the reference point of the
+                // gradient (float64, see struct_grad), so its rounding is second order.
+                f32x2 am[NB];
 #pragma unroll
-                for (int I = 0; I < NB; ++I) am[I] = 0.0;
+                for (int I = 0; I < NB; ++I) am[I] = f32x2{0.f, 0.f};
 #pragma unroll
                 for (int J = 0; J < NB; ++J)
                     if (J < nbr) {
                         const f32x4 d4 = lds4(dvp + 16 * J + 4 * lq);   // columns {lq,4+lq,8+lq,12+lq} of block J
-                        const double dx = d4.x, dy = d4.y, dz = d4.z, dw = d4.w;
-                        double dt[4];                                  // rows 4lq+rr of block J (transposed use)
+                        f32x4 dt;                                      // rows 4lq+rr of block J (transposed use)
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) dt[rr] = (double)dvp[16 * J + rr * 4 + lq];
+                        for (int rr = 0; rr < 4; ++rr) dt[rr] = dvp[16 * J + rr * 4 + lq];
 #pragma unroll
                         for (int I = 0; I < NB; ++I)
                             if (I < nbr) {
+                                f32x4 t4;
                                 if (J <= I) {
-                                    const f32x4 t4 = lds4(tiles + ((I * (I + 1)) / 2 + J) * 256 + chunk_off(li, lq));
-                                    am[I] += (double)t4.x * dx + (double)t4.y * dy + (double)t4.z * dz + (double)t4.w * dw;
+                                    t4 = lds4(tiles + ((I * (I + 1)) / 2 + J) * 256 + chunk_off(li, lq));
+                                    am[I] += f32x2{t4.x, t4.y} * f32x2{d4.x, d4.y};
+                                    am[I] += f32x2{t4.z, t4.w} * f32x2{d4.z, d4.w};
                                 } else {
                                     const float* t = tiles + ((J * (J + 1)) / 2 + I) * 256;
 #pragma unroll
-                                    for (int rr = 0; rr < 4; ++rr) am[I] += (double)t[toff(4 * lq + rr, li)] * dt[rr];
+                                    for (int rr = 0; rr < 4; ++rr) t4[rr] = t[toff(4 * lq + rr, li)];
+                                    am[I] += f32x2{t4.x, t4.y} * f32x2{dt.x, dt.y};
+                                    am[I] += f32x2{t4.z, t4.w} * f32x2{dt.z, dt.w};
                                 }
                             }
                     }
 #pragma unroll
                 for (int I = 0; I < NB; ++I)
                     if (I < nbr) {
-                        const double a = quad_sum_d(am[I]);
-                        if (lq == (I & 3)) grad[I >> 2] = valid[I >> 2] ? (float)(a + gref[I >> 2]) : 0.f;
+                        const float a = quad_sum(am[I].x + am[I].y);
+                        if (lq == (I & 3)) grad[I >> 2] = valid[I >> 2] ? (float)((double)a + gref[I >> 2]) : 0.f;
                     }
             }
             }
@@ -1073,7 +1122,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
             ++nit;
             // KKT matrix: H + Sigma on the diagonal
             float Sig[NV], rsl[NV], rsu[NV];   // 1/s_l, 1/s_u by v_rcp_f32 (1 ulp; the IPM tolerates it)
-            __syncthreads();   // dvp is dead: it becomes the Sigma vector
+            wave_lds_fence();   // dvp is dead: it becomes the Sigma vector
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 rsl[v] = __builtin_amdgcn_rcpf(sl[v]);
@@ -1082,7 +1131,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 const int e = v * 64 + lane;
                 if (e < npadr) dvp[e] = Sig[v];
             }
-            __syncthreads();
+            wave_lds_fence();
             STAMP(7);
             const bool ok = chol_reg<NB>(tiles, dvp, recbuf, nbr, lane, Tt, Wd);
             STAMP(5);
@@ -1096,7 +1145,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 const int e = v * 64 + lane;
                 if (e < npadr) xvp[e] = -grad[v];
             }
-            __syncthreads();
+            wave_lds_fence();
             STAMP(7);
             solve_reg<NB>(Tt, Wd, xvp, nbr, lane);
             STAMP(6);
@@ -1128,7 +1177,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
             sigma = fminf(fmaxf(sigma * sigma * sigma, 0.f), 1.f);
             // corrector
             float rcl[NV], rcu[NV], rhs[NV];
-            __syncthreads();
+            wave_lds_fence();
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 rcl[v] = rcu[v] = rhs[v] = 0.f;
@@ -1140,7 +1189,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 const int e = v * 64 + lane;
                 if (e < npadr) xvp[e] = rhs[v];
             }
-            __syncthreads();
+            wave_lds_fence();
             STAMP(7);
             solve_reg<NB>(Tt, Wd, xvp, nbr, lane);
             STAMP(6);
@@ -1176,10 +1225,10 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
         }
 
         // ---------------- outputs ----------------
-        __syncthreads();
+        wave_lds_fence();
         float* ubuf = tiles;  // N*NT words, zero = broken thruster
         for (int i = lane; i < N * NT; i += 64) ubuf[i] = 0.f;
-        __syncthreads();
+        wave_lds_fence();
 #pragma unroll
         for (int v = 0; v < NV; ++v)
             if (valid[v]) {
@@ -1187,7 +1236,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 if (status == 2) u = ubar[v];
                 ubuf[kcol[v] * NT + s_act[acol[v]]] = u;
             }
-        __syncthreads();
+        wave_lds_fence();
         if (lane < NT) P.out_u0[inst * NT + lane] = (double)ubuf[lane];
         if (P.out_U)
             for (int i = lane; i < N * NT; i += 64) P.out_U[inst * (int64_t)N * NT + i] = (double)ubuf[i];

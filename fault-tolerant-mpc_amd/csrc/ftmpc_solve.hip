@@ -696,9 +696,6 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
     const int N = C.N, NT = C.NT;
     const float rho = (float)C.rho;
     const float mu_stop = (float)C.mu_stop;
-    int dpos[4];                     // where this lane's four record words go in the dense images
-#pragma unroll
-    for (int j = 0; j < 4; ++j) dpos[j] = (lane < REC_STRIDE / 4) ? k_dense_pos.v[4 * lane + j] : DENSE_DUMP;
     float Rf[6];
 #pragma unroll
     for (int g = 0; g < 6; ++g) Rf[g] = (float)C.R[g];
@@ -748,10 +745,23 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
         // the reference-point gradient (struct_grad) on the full values
         typedef double f64x4_t __attribute__((ext_vector_type(4)));
         const double* recg = reinterpret_cast<const double*>(P.rec) + inst * (int64_t)N * REC_STRIDE;
-        f32x4 pre = {0.f, 0.f, 0.f, 0.f};
-        if (lane < REC_STRIDE / 4) {
-            const f64x4_t t = *reinterpret_cast<const f64x4_t*>(recg + 4 * lane);
-            pre = (f32x4){(float)t.x, (float)t.y, (float)t.z, (float)t.w};
+        // prefetched one stage ahead and kept RAW: converting right after the load would put the whole
+        // global latency on the stage's critical path
+        f64x4_t pre64 = {0.0, 0.0, 0.0, 0.0};
+        if (lane < REC_STRIDE / 4) pre64 = *reinterpret_cast<const f64x4_t*>(recg + 4 * lane);
+        // where this lane's four record words go in the dense images (loaded per instance: as a kernel-long
+        // live range the four values end up in scratch and every stage waits for them)
+        int dpos[4] = {DENSE_DUMP, DENSE_DUMP, DENSE_DUMP, DENSE_DUMP};
+        {
+            int w0 = 4 * lane;
+            asm volatile("" : "+v"(w0));
+            if (lane < REC_STRIDE / 4) {
+                const ushort4 t = *reinterpret_cast<const ushort4*>(&k_dense_pos.v[w0]);
+                dpos[0] = t.x;
+                dpos[1] = t.y;
+                dpos[2] = t.z;
+                dpos[3] = t.w;
+            }
         }
         // dense operand images of the stage matrices (build phase only, in the tile area):
         //   dense[b] = A_k as 16x16 (rows/columns permuted by tile_row) | [B_pF B_pT; ...] as 16x8
@@ -829,15 +839,13 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
             float* rb = recbuf + (k & 1) * REC_STRIDE;
             float* dd = dense + (k & 1) * DENSE_WORDS;
             if (lane < REC_STRIDE / 4) {
+                const f32x4 pre = {(float)pre64.x, (float)pre64.y, (float)pre64.z, (float)pre64.w};
                 *reinterpret_cast<f32x4*>(rb + 4 * lane) = pre;
                 dd[dpos[0]] = pre.x;
                 dd[dpos[1]] = pre.y;
                 dd[dpos[2]] = pre.z;
                 dd[dpos[3]] = pre.w;
-            }
-            if (k + 1 < N && lane < REC_STRIDE / 4) {
-                const f64x4_t t = *reinterpret_cast<const f64x4_t*>(recg + (k + 1) * REC_STRIDE + 4 * lane);
-                pre = (f32x4){(float)t.x, (float)t.y, (float)t.z, (float)t.w};
+                if (k + 1 < N) pre64 = *reinterpret_cast<const f64x4_t*>(recg + (k + 1) * REC_STRIDE + 4 * lane);
             }
             wave_lds_fence();
             const bool terminal = (k + 1 == N);

@@ -1,7 +1,12 @@
 import sys, time
 sys.path.insert(0,'/root/repo/fault-tolerant-mpc_amd'); sys.path.insert(0,'/root/repo')
 import numpy as np, torch
+import os
 import ft_mpc_amd
+from ft_mpc_amd import _lib
+if os.environ.get('FTMPC_LIB'):  # diagnostic: time another build of the library
+    from pathlib import Path
+    _lib._SO = Path(os.environ['FTMPC_LIB'])
 B=int(sys.argv[1]) if len(sys.argv)>1 else 65536
 nf=int(sys.argv[2]) if len(sys.argv)>2 else 2
 N,NT=20,8

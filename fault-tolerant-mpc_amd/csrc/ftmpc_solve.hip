@@ -397,44 +397,49 @@ template <int NB>
 __device__ __forceinline__ void solve_reg(const f32x4 (&T)[NB * (NB + 1) / 2], const f32x4 (&Wd)[NB],
                                           float* xv, int nb, int lane) {
     const int li = lane & 15, lq = lane >> 4;
+    // Right-looking order: as soon as a block of the solution is known its contribution goes to ALL
+    // later right-hand sides.  These updates are independent of each other and fill the issue slots
+    // of the one chain that is serial (reduce -> W -> reduce), which a single wave cannot hide otherwise.
     f32x4 Y[NB];
+    f32x2 p[NB];
+#pragma unroll
+    for (int J = 0; J < NB; ++J) p[J] = f32x2{0.f, 0.f};
 #pragma unroll
     for (int J = 0; J < NB; ++J) {
-        const float brow = xv[16 * J + li];
-        f32x2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f};
-#pragma unroll
-        for (int K = 0; K < J; ++K) {
-            const f32x4& t = T[tidx(J, K)];
-            p0 += f32x2{t.x, t.y} * f32x2{Y[K].x, Y[K].y};
-            p1 += f32x2{t.z, t.w} * f32x2{Y[K].z, Y[K].w};
-        }
-        float r = brow;
-        if (J > 0) r -= quad_sum((p0.x + p0.y) + (p1.x + p1.y));
+        float r = xv[16 * J + li];
+        if (J > 0) r -= quad_sum(p[J].x + p[J].y);
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) Y[J][s4] = row_sum16(Wd[J][s4] * r);
-    }
-    wave_lds_fence();
-    float xr[NB];
-#pragma unroll
-    for (int J = NB - 1; J >= 0; --J) {
-        f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
         for (int I = J + 1; I < NB; ++I) {
             const f32x4& t = T[tidx(I, J)];
-            const f32x2 xx = {xr[I], xr[I]};
-            a0 += f32x2{t.x, t.y} * xx;
-            a1 += f32x2{t.z, t.w} * xx;
+            p[I] += f32x2{t.x, t.y} * f32x2{Y[J].x, Y[J].y};
+            p[I] += f32x2{t.z, t.w} * f32x2{Y[J].z, Y[J].w};
         }
+    }
+    wave_lds_fence();
+    f32x2 a0[NB], a1[NB];
+#pragma unroll
+    for (int J = 0; J < NB; ++J) a0[J] = a1[J] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int J = NB - 1; J >= 0; --J) {
         f32x4 r = Y[J];
         if (J < NB - 1) {
-            r.x -= row_sum16(a0.x);
-            r.y -= row_sum16(a0.y);
-            r.z -= row_sum16(a1.x);
-            r.w -= row_sum16(a1.y);
+            r.x -= row_sum16(a0[J].x);
+            r.y -= row_sum16(a0[J].y);
+            r.z -= row_sum16(a1[J].x);
+            r.w -= row_sum16(a1[J].y);
         }
         const f32x2 d2 = f32x2{Wd[J].x, Wd[J].y} * f32x2{r.x, r.y} + f32x2{Wd[J].z, Wd[J].w} * f32x2{r.z, r.w};
-        xr[J] = quad_sum(d2.x + d2.y);
-        if (lq == 0) xv[16 * J + li] = xr[J];
+        const float xr = quad_sum(d2.x + d2.y);
+        if (lq == 0) xv[16 * J + li] = xr;
+        const f32x2 xx = {xr, xr};
+#pragma unroll
+        for (int K = 0; K < J; ++K) {
+            const f32x4& t = T[tidx(J, K)];
+            a0[K] += f32x2{t.x, t.y} * xx;
+            a1[K] += f32x2{t.z, t.w} * xx;
+        }
     }
     wave_lds_fence();
 }

@@ -1029,10 +1029,12 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
         const float inv2n = 1.0f / (float)(2 * n);
         for (int it = 0; it <= C.max_iters; ++it) {
             wave_lds_fence();
-            float dcur[NV];
-#pragma unroll
-            for (int v = 0; v < NV; ++v) dcur[v] = valid[v] ? ((sl[v] < su[v]) ? lo[v] + sl[v] : hi[v] - su[v]) : 0.f;
             const bool do_ref = __builtin_amdgcn_readfirstlane(!refined && mu_last < (float)C.mu_refine);
+            float dcur[NV];
+            if (do_ref || it == 0) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) dcur[v] = valid[v] ? ((sl[v] < su[v]) ? lo[v] + sl[v] : hi[v] - su[v]) : 0.f;
+            }
             if (do_ref) {
                 // one accurate (float64, structured) gradient at the current iterate
 #pragma unroll
@@ -1054,8 +1056,12 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 }
                 refined = true;
                 STAMP(8);
-            } else {
-            // gradient  gref + H (d - dref)
+            } else if (it == 0) {
+            // gradient at the start point, gref + H (d - dref).  Later iterates do not need the product
+            // again: the Newton system just solved gives  H dd = rhs - Sigma dd,  so the gradient follows
+            // the step (see the update at the end of the iteration).  For variables at a bound the two
+            // terms are large and cancel poorly, but there an error of the gradient only shifts the
+            // multiplier; for free variables both terms vanish with the step.
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int e = v * 64 + lane;
@@ -1229,6 +1235,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
 #pragma unroll
             for (int v = 0; v < NV; ++v)
                 if (valid[v]) {
+                    grad[v] += ap * (rhs[v] - Sig[v] * dd[v]);   // + ap H dd
                     sl[v] += ap * dd[v];
                     su[v] -= ap * dd[v];
                     zl[v] += ad * dzl[v];

@@ -24,6 +24,8 @@
 //   NB=10 (n<=160): 59.3 KiB -> 2 waves/CU
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "ftmpc_common.h"
 
 namespace ftmpc {
@@ -455,7 +457,7 @@ __device__ __forceinline__ void solve_reg(const f32x4 (&T)[NB * (NB + 1) / 2], c
 // so the fp32 rounding of H only acts on the (small) distance to the reference point.
 // Cost: ~2 x N short dependent steps, once per instance (~2 % of a solve).
 // =============================================================================================
-__device__ __forceinline__ int aoff(int r, int c) {   // record word of d(next state r)/d(input c); inputs: 13 state + 6 wrench
+__host__ __device__ constexpr int aoff(int r, int c) {   // record word of d(next state r)/d(input c); inputs: 13 state + 6 wrench
     constexpr int ZERO = REC_STRIDE, ONE = REC_STRIDE + 1, DT = REC_STRIDE + 2;
     if (r >= 13) return ZERO;
     const int kind = r < 3 ? 0 : (r < 6 ? 1 : (r < 9 ? 2 : 3));   // p, v, w, q row
@@ -477,6 +479,18 @@ __device__ __forceinline__ int aoff(int r, int c) {   // record word of d(next s
     const int j = c - 16;                                                                // d/dtau
     return kind == 0 ? REC_BPT + 3 * a + j : (kind == 1 ? REC_BVT + 3 * a + j : (kind == 2 ? REC_BWT + 3 * a + j : REC_BQT + 3 * a + j));
 }
+// the same as a table (16 rows x 19 inputs): evaluated per lane at run time the chain of selects above
+// costs ~1000 instructions per call of struct_grad
+struct AoffTable {
+    unsigned char v[16][20];
+};
+constexpr AoffTable make_aoff_table() {
+    AoffTable t{};
+    for (int r = 0; r < 16; ++r)
+        for (int c = 0; c < 20; ++c) t.v[r][c] = (unsigned char)((c < 19) ? aoff(r, c) : REC_STRIDE);
+    return t;
+}
+__device__ const AoffTable k_aoff = make_aoff_table();
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f64x4 mfma_d(double a, double b, f64x4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
@@ -491,8 +505,16 @@ __device__ __forceinline__ f64x4 mfma_d(double a, double b, f64x4 c) {
 // replicated over n), which is directly the B operand of the next product (k = 4s + q); the A
 // operand M[m][4s+q] is read from the stage record in LDS through a per-lane word table.  No
 // cross-lane traffic at all.
-__device__ __noinline__ void struct_grad(const DeviceConsts& C, const double* recg, double* recd, const float* s_Da,
-                                            const float* dnat, double* sS, double* gout, int na, int lane) {
+// The pointers carry their address space: as a non-inlined function with generic pointers every access
+// became a FLAT instruction behind a run-time aperture test, and a flat access in flight forces every
+// later wait to vmcnt(0) -- i.e. onto the record prefetch.
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef __attribute__((address_space(3))) const float lds_cf32;
+typedef __attribute__((address_space(1))) double glb_f64;
+typedef __attribute__((address_space(1))) const double glb_cf64;
+template <class SPtr>   // stage storage: lds_f64* when it fits behind the vectors, else glb_f64* (long horizons)
+__device__ __noinline__ void struct_grad(const DeviceConsts& C, glb_cf64* recg, lds_f64* recd, lds_cf32* s_Da,
+                                            lds_cf32* dnat, SPtr sS, glb_f64* gout, int na, int lane) {
     constexpr int ZERO = REC_STRIDE;
     const int N = C.N;
     const int m = lane & 15, q = lane >> 4;
@@ -500,12 +522,12 @@ __device__ __noinline__ void struct_grad(const DeviceConsts& C, const double* re
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
         const int k = 4 * s4 + q;
-        offX[s4] = (k < 13) ? aoff(m, k) : ZERO;                       // A[m][k]
-        offAT[s4] = (k < 13 && m < 13) ? aoff(k, m) : ZERO;           // A[k][m]
-        offBT[s4] = (k < 13 && m < 6) ? aoff(k, 13 + m) : ZERO;       // B[k][m]
+        offX[s4] = (k < 13) ? k_aoff.v[m][k] : ZERO;                        // A[m][k]
+        offAT[s4] = (k < 13 && m < 13) ? k_aoff.v[k][m] : ZERO;            // A[k][m]
+        offBT[s4] = (k < 13 && m < 6) ? k_aoff.v[k][13 + m] : ZERO;        // B[k][m]
     }
 #pragma unroll
-    for (int s4 = 0; s4 < 2; ++s4) offG[s4] = (4 * s4 + q < 6) ? aoff(m, 13 + 4 * s4 + q) : ZERO;   // B[m][g]
+    for (int s4 = 0; s4 < 2; ++s4) offG[s4] = (4 * s4 + q < 6) ? k_aoff.v[m][13 + 4 * s4 + q] : ZERO;   // B[m][g]
     if (lane == 0) {
         recd[REC_STRIDE] = 0.0;
         recd[REC_STRIDE + 1] = 1.0;
@@ -520,10 +542,15 @@ __device__ __noinline__ void struct_grad(const DeviceConsts& C, const double* re
         rrow[i] = (q + 4 * i < 6) ? C.R[q + 4 * i] : 0.0;
         da_op[i] = (q + 4 * i < 6) ? (double)s_Da[(q + 4 * i) * MAX_NT + m] : 0.0;   // Da[g][a=m]: A operand of Da' z
     }
+    // terminal weight as an A operand, P[m][4s+q] (9x9, zero padded).  Read HERE: `C` is a generic
+    // reference, and a flat load inside the sweeps would force every later wait to vmcnt(0).
+    double pa[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) pa[s4] = (m < 9 && 4 * s4 + q < 9) ? C.P[9 * m + 4 * s4 + q] : 0.0;
     const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
     // wrench perturbations gen_k = Da d_k of ALL stages up front, one (stage, component) pair per lane,
     // parked behind the gradient in the global scratch (N x 8 doubles) and prefetched with the records
-    double* genS = gout + 16 * ((N * na + 15) / 16);
+    glb_f64* genS = gout + 16 * ((N * na + 15) / 16);
     for (int t = lane; t < N * 8; t += 64) {
         const int k = t >> 3, g = t & 7;
         double acc = 0.0;
@@ -535,73 +562,91 @@ __device__ __noinline__ void struct_grad(const DeviceConsts& C, const double* re
     wave_global_fence();   // lanes exchange through the global slot here
     // this lane's two wrench rows (g = q and q+4) of stage k
     const int g1 = (q + 4 < 6) ? q + 4 : 7;      // slot 7 of every stage is zero
-    double pf[3], pg0, pg1;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) pf[j] = (lane + 64 * j < REC_STRIDE) ? recg[lane + 64 * j] : 0.0;
-    pg0 = genS[q];
-    pg1 = genS[g1];
+    // The float64 records come from HBM (they were last touched by the condensing, a few hundred
+    // thousand cycles ago) and one stage of a sweep is only ~500 cycles of work: the loads run FOUR
+    // stages ahead, in four statically named register sets (a rotating copy would wait for the load).
+    double pf[4][3], pg[4][2];
+    // branch-free on purpose (clamped indices, a dump word for the lanes past the record): every
+    // conditional around a load turns into a phi whose copy waits for the load just issued
+    const int w2 = (lane + 128 < REC_STRIDE) ? lane + 128 : REC_STRIDE - 1;     // third word of this lane (152 = 2*64 + 24)
+    const int d2 = (lane + 128 < REC_STRIDE) ? lane + 128 : REC_STRIDE + 3;     // LDS dump word behind {0, 1, dt}
+    auto issue = [&](auto SL, int kk) {
+        constexpr int sl = decltype(SL)::value;
+        glb_cf64* r = recg + (int64_t)kk * REC_STRIDE;
+        pf[sl][0] = r[lane];
+        pf[sl][1] = r[lane + 64];
+        pf[sl][2] = r[w2];
+        pg[sl][0] = genS[kk * 8 + q];
+        pg[sl][1] = genS[kk * 8 + g1];
+    };
+    auto stage_to_lds = [&](auto SL) {
+        constexpr int sl = decltype(SL)::value;
+        recd[lane] = pf[sl][0];
+        recd[lane + 64] = pf[sl][1];
+        recd[d2] = pf[sl][2];
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    using S3 = std::integral_constant<int, 3>;
     // ---- forward sweep: dc_{k+1} = A_k dc_k + B_k gen_k ----
     f64x4 dc = zero;
-    for (int k = 0; k < N; ++k) {
+    auto fwd = [&](auto SL, int k) {
+        constexpr int sl = decltype(SL)::value;
         wave_lds_fence();
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            if (lane + 64 * j < REC_STRIDE) recd[lane + 64 * j] = pf[j];
-        const double g0 = pg0, g1v = pg1;
-        if (k + 1 < N) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) pf[j] = (lane + 64 * j < REC_STRIDE) ? recg[(int64_t)(k + 1) * REC_STRIDE + lane + 64 * j] : 0.0;
-            pg0 = genS[(k + 1) * 8 + q];
-            pg1 = genS[(k + 1) * 8 + g1];
-        }
+        stage_to_lds(SL);
+        const double g0 = pg[sl][0], g1v = pg[sl][1];
+        issue(SL, (k + 4 < N) ? k + 4 : N - 1);
         wave_lds_fence();
-        f64x4 nx = zero;
+        // two accumulators: a dependent float64 MFMA costs its full 16 passes, so halve the chain
+        f64x4 nx = zero, ny = zero;
         nx = mfma_d(recd[offX[0]], dc.x, nx);
-        nx = mfma_d(recd[offX[1]], dc.y, nx);
+        ny = mfma_d(recd[offX[1]], dc.y, ny);
         nx = mfma_d(recd[offX[2]], dc.z, nx);
-        nx = mfma_d(recd[offX[3]], dc.w, nx);
+        ny = mfma_d(recd[offX[3]], dc.w, ny);
         nx = mfma_d(recd[offG[0]], g0, nx);
-        nx = mfma_d(recd[offG[1]], g1v, nx);
-        dc = nx;
+        ny = mfma_d(recd[offG[1]], g1v, ny);
+        dc = nx + ny;
         // s_{k+1} = W (e_bar + dc)[0:9]: this lane's tile rows are q, q+4, q+8 (< 9 only for q = 0), q+12
         f64x4 t = zero;
         if (k + 1 == N) {   // terminal weight P: A operand P[m][4s+q] (9x9, zero padded)
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const int kk = 4 * s4 + q;
-                const double pa = (m < 9 && kk < 9) ? C.P[9 * m + kk] : 0.0;
-                t = mfma_d(pa, dc[s4], t);
-            }
+            for (int s4 = 0; s4 < 4; ++s4) t = mfma_d(pa[s4], dc[s4], t);
         } else {
 #pragma unroll
             for (int i = 0; i < 3; ++i) t[i] = qrow[i] * dc[i];
         }
         if (m == 0) {
-            double* srow = sS + (k + 1) * 9;
+            SPtr srow = sS + (k + 1) * 9;
             srow[q] = recd[REC_WE + q] + t.x;
             srow[q + 4] = recd[REC_WE + q + 4] + t.y;
             if (q == 0) srow[8] = recd[REC_WE + 8] + t.z;
         }
+    };
+    const int N4 = N & ~3;
+    issue(S0{}, 0);
+    issue(S1{}, (1 < N) ? 1 : 0);
+    issue(S2{}, (2 < N) ? 2 : 0);
+    issue(S3{}, (3 < N) ? 3 : 0);
+    for (int k = 0; k < N4; k += 4) {
+        fwd(S0{}, k);
+        fwd(S1{}, k + 1);
+        fwd(S2{}, k + 2);
+        fwd(S3{}, k + 3);
+    }
+    for (int k = N4; k < N; ++k) {   // N not a multiple of 4: the tail reloads its stage (latency exposed)
+        issue(S0{}, k);
+        fwd(S0{}, k);
     }
     wave_global_fence();   // the stage storage may be the global slot (long horizons)
-    // ---- adjoint sweep ----
-#pragma unroll
-    for (int j = 0; j < 3; ++j) pf[j] = (lane + 64 * j < REC_STRIDE) ? recg[(int64_t)(N - 1) * REC_STRIDE + lane + 64 * j] : 0.0;
-    pg0 = genS[(N - 1) * 8 + q];
-    pg1 = genS[(N - 1) * 8 + g1];
+    // ---- adjoint sweep (stage N-1-i uses register set i & 3) ----
     f64x4 lam = zero;
-    for (int k = N - 1; k >= 0; --k) {
+    auto adj = [&](auto SL, int k) {
+        constexpr int sl = decltype(SL)::value;
         wave_lds_fence();
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            if (lane + 64 * j < REC_STRIDE) recd[lane + 64 * j] = pf[j];
-        const double g0 = pg0, g1v = pg1;
-        if (k > 0) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) pf[j] = (lane + 64 * j < REC_STRIDE) ? recg[(int64_t)(k - 1) * REC_STRIDE + lane + 64 * j] : 0.0;
-            pg0 = genS[(k - 1) * 8 + q];
-            pg1 = genS[(k - 1) * 8 + g1];
-        }
+        stage_to_lds(SL);
+        const double g0 = pg[sl][0], g1v = pg[sl][1];
+        issue(SL, (k - 4 >= 0) ? k - 4 : 0);
         wave_lds_fence();
         if (k == N - 1) {   // lambda_N = s_N
             lam.x = sS[N * 9 + q];
@@ -610,11 +655,12 @@ __device__ __noinline__ void struct_grad(const DeviceConsts& C, const double* re
             lam.w = 0.0;
         }
         // z = B_k' lambda_{k+1} + R (ut_bar + Da d_k): rows g = q, q+4 (< 6)
-        f64x4 z = zero;
+        f64x4 z = zero, zb = zero;
         z = mfma_d(recd[offBT[0]], lam.x, z);
-        z = mfma_d(recd[offBT[1]], lam.y, z);
+        zb = mfma_d(recd[offBT[1]], lam.y, zb);
         z = mfma_d(recd[offBT[2]], lam.z, z);
-        z = mfma_d(recd[offBT[3]], lam.w, z);
+        zb = mfma_d(recd[offBT[3]], lam.w, zb);
+        z += zb;
         const double z0 = z.x + recd[REC_RUT + q] + rrow[0] * g0;                              // row q  (< 4 <= 6)
         const double z1 = (q + 4 < 6) ? z.y + recd[REC_RUT + q + 4] + rrow[1] * g1v : 0.0;     // row q+4
         // g_{k,a} = 2 Da[:,a]' z : A operand Da[g = 4s+q][a = m], B operand z rows 4s+q
@@ -628,16 +674,32 @@ __device__ __noinline__ void struct_grad(const DeviceConsts& C, const double* re
         }
         // lambda_k = A_k' lambda_{k+1} + [s_k; 0]
         if (k > 0) {
-            f64x4 nl = zero;
+            f64x4 nl = zero, nm = zero;
             nl = mfma_d(recd[offAT[0]], lam.x, nl);
-            nl = mfma_d(recd[offAT[1]], lam.y, nl);
+            nm = mfma_d(recd[offAT[1]], lam.y, nm);
             nl = mfma_d(recd[offAT[2]], lam.z, nl);
-            nl = mfma_d(recd[offAT[3]], lam.w, nl);
+            nm = mfma_d(recd[offAT[3]], lam.w, nm);
+            nl += nm;
             lam.x = nl.x + sS[k * 9 + q];
             lam.y = nl.y + sS[k * 9 + q + 4];
             lam.z = nl.z + ((q == 0) ? sS[k * 9 + 8] : 0.0);
             lam.w = nl.w;
         }
+    };
+    issue(S0{}, N - 1);
+    issue(S1{}, (N - 2 >= 0) ? N - 2 : 0);
+    issue(S2{}, (N - 3 >= 0) ? N - 3 : 0);
+    issue(S3{}, (N - 4 >= 0) ? N - 4 : 0);
+    int ka = N - 1;
+    for (; ka >= 3; ka -= 4) {
+        adj(S0{}, ka);
+        adj(S1{}, ka - 1);
+        adj(S2{}, ka - 2);
+        adj(S3{}, ka - 3);
+    }
+    for (; ka >= 0; --ka) {
+        issue(S0{}, ka);
+        adj(S0{}, ka);
     }
     __threadfence_block();
     wave_global_fence();   // lanes exchange through the global slot here
@@ -1045,8 +1107,12 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 wave_lds_fence();
                 constexpr int SAVAIL = (NPAD + SH::SEXTRA) * 4;       // bytes of LDS behind dvp
                 double* const gout = sbuf;                               // global, n doubles
-                double* const sS = ((N + 1) * 72 <= SAVAIL) ? reinterpret_cast<double*>(dvp) : sbuf + NPAD + 8 * 64;
-                struct_grad(C, recg, reinterpret_cast<double*>(recbuf), s_Da, xvp, sS, gout, na, lane);
+                if ((N + 1) * 72 <= SAVAIL)
+                    struct_grad(C, (glb_cf64*)recg, (lds_f64*)reinterpret_cast<double*>(recbuf), (lds_cf32*)s_Da, (lds_cf32*)xvp,
+                                (lds_f64*)reinterpret_cast<double*>(dvp), (glb_f64*)gout, na, lane);
+                else
+                    struct_grad(C, (glb_cf64*)recg, (lds_f64*)reinterpret_cast<double*>(recbuf), (lds_cf32*)s_Da, (lds_cf32*)xvp,
+                                (glb_f64*)(sbuf + NPAD + 8 * 64), (glb_f64*)gout, na, lane);
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
                     const int e = v * 64 + lane;

@@ -3,7 +3,9 @@ import sys, ctypes as C
 sys.path.insert(0,'/root/repo/fault-tolerant-mpc_amd'); sys.path.insert(0,'/root/repo')
 import numpy as np
 from ft_mpc_amd import _lib
-_lib._SO = _lib._HERE / "libftmpc_hip_stamps.so"
+import os
+from pathlib import Path
+_lib._SO = Path(os.environ["FTMPC_LIB"]) if os.environ.get("FTMPC_LIB") else _lib._HERE / "libftmpc_hip_stamps.so"
 import ft_mpc_amd
 B=int(sys.argv[1]) if len(sys.argv)>1 else 4096
 nf=int(sys.argv[2]) if len(sys.argv)>2 else 2

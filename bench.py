@@ -122,6 +122,34 @@ def main():
     iters = d_iters.cpu().numpy()
     status = d_status.cpu().numpy()
     u0_gpu = d_u0.cpu().numpy()
+
+    # SURVEY.md 8(d) asks for the warm-started rate next to the cold one (never `value`): same states,
+    # linearised about the previous solution shifted by one stage (spiraling_mpc.py:324-334)
+    d_U = torch.zeros(B, N, NT, dtype=torch.float64, device=dev)
+    mpc.solve_device(B, d_x0.data_ptr(), d_ub.data_ptr(), d_st.data_ptr(), d_xr.data_ptr(), 0, 0, 0, 0,
+                     d_u0.data_ptr(), d_U.data_ptr(), d_status.data_ptr(), d_iters.data_ptr(), stream)
+    torch.cuda.synchronize()
+    d_warm = torch.cat([d_U[:, 1:], d_U[:, -1:]], dim=1).contiguous()
+    d_u0w = torch.zeros_like(d_u0)
+    d_itw = torch.zeros_like(d_iters)
+
+    def step_warm():
+        mpc.solve_device(B, d_x0.data_ptr(), d_ub.data_ptr(), d_st.data_ptr(), d_xr.data_ptr(), 0, 0, 0, d_warm.data_ptr(),
+                         d_u0w.data_ptr(), 0, d_status.data_ptr(), d_itw.data_ptr(), stream)
+
+    step_warm()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step_warm()
+    barrier()
+    warm_elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([warm_elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        warm_elapsed = float(t.item())
+    warm_iters = float(d_itw.float().mean().item())
+    warm_du0 = float((d_u0w - d_u0).abs().amax(dim=1).median().item() / 3.4)
     na = (ub > 0).sum(axis=1)
     flops = float(sum(algorithmic_flops(N, int(a), int(k)) for a, k in zip(na, iters)))
 
@@ -153,6 +181,9 @@ def main():
                          "kernel": dom, "kernel_ms": sol_ms, "other_kernels_ms": {"ftmpc_linearize_kernel": lin_ms, **{k: v for k, v in med.items() if k != dom}},
                          "flops_per_launch": flops},
         }
+        line["warm_start"] = {"value": args.steps * B * world / warm_elapsed, "unit": "QP-steps/s", "ipm_iters_mean": warm_iters,
+                              "median_u0_change_over_fmax": warm_du0,
+                              "note": "same states, linearised about the previous solution shifted by one stage; reported beside the cold-start `value`"}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import c_oracle, qp_oracle
             cores = os.cpu_count() or 1

@@ -129,8 +129,10 @@ def ipm_box(H, g, lo, hi, iters=16, dtype=np.float64, polish=False, trace=None, 
       * start at the box centre, duals on the central path at mu0 = max(0.02 |grad|_inf * width, 1e-3), step fraction 0.9995
       * slacks s_l = d - lo, s_u = hi - d are carried as state (s += a*ds), never recomputed by
         subtraction; d is read back from the slack of the nearer bound
-      * the gradient H d + g is re-evaluated every iteration with float64 accumulation (in the
-        fp32 kernel this is what bounds the final error by the fp32 representation of H, g)
+      * the gradient H d + g is re-evaluated every iteration with float64 accumulation.  The fp32
+        kernel evaluates it once, then lets it follow the step (H dd = rhs - Sigma dd from the Newton
+        system just solved) and replaces it once by a float64 gradient computed through the stage
+        records: the same iterates up to rounding
       * one Cholesky of H + diag(z_l/s_l + z_u/s_u) per iteration, two solves
       * stop when the mean complementarity falls below mu_stop
     `dtype=np.float32` emulates the kernel's arithmetic.  Returns (d, z_l, z_u, iterations).

@@ -17,7 +17,7 @@ cnt=min(B,4096)
 buf=np.zeros((cnt,12),np.uint64)
 f=mpc.lib.ftmpc_debug_read_stamps; f.argtypes=[C.c_void_p,C.c_int64,C.c_void_p]
 assert f(mpc._h,cnt,buf.ctypes.data_as(C.c_void_p))==0
-names=["prologue","build:propagate","build:mfma","finalize+store","matvec","chol","solves(2)","elementwise","refine (f64 grad)","output","",""]
+names=["prologue","build:propagate","build:mfma","finalize+store","matvec","chol","solves(2)","elementwise","refine (f64 grad)","output","x10","x11"]
 m=buf.astype(np.float64).mean(axis=0); tot=m.sum()
 print("iters mean %.2f   total cycles/QP %.0f"%(out['iters'].mean(),tot))
 for n_,v in zip(names,m):

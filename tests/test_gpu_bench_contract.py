@@ -30,6 +30,8 @@ def test_single_gpu_line():
     assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] < 1
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["gpu_vs_port_max_u0_err_over_fmax"] < 1e-4
     assert j["config"]["not_converged"] == 0 and j["value"] > 1e5
+    # the warm-started rate is reported beside the cold one (a different linearisation point, hence a different QP)
+    assert j["warm_start"]["value"] > 1e5 and j["warm_start"]["ipm_iters_mean"] > 1
 
 
 def test_two_ranks_on_one_gpu():

@@ -53,6 +53,22 @@ def test_u0_matches_exact_solution(gpu_mpc_factory, nfault, B):
     assert out["iters"].max() <= 24
 
 
+@pytest.mark.parametrize("N,nfault", [(3, 2), (6, 0), (18, 2), (23, 2), (26, 2)])
+def test_horizons_not_multiple_of_four(gpu_mpc_factory, N, nfault):
+    """The reference-gradient sweeps run four stages per round with a scalar tail, and the three
+    instantiations split at n = 128 / 144 / 160: horizons on every side of those seams, against the
+    C oracle converged to mu 1e-13 (N=26 with six healthy thrusters: n = 156, the NB=10 kernel)."""
+    NT, B = 8, 24
+    mpc = gpu_mpc_factory(N=N, NT=NT)
+    x0, ub, stuck, xref = qo.make_batch(B, N, NT, nfault, 3100 + N)
+    out = mpc.solve(x0, ub, stuck, xref.reshape(-1, order="F"), return_U=True)
+    assert (out["status"] == 0).all(), out["status"]
+    ref = co.solve_batch(_cfg(N, NT), x0, ub, stuck, xref, nthreads=4, max_iters=60, mu_stop=1e-13)
+    assert (ref["status"] == 0).all()
+    assert np.abs(out["u0"] - ref["u0"]).max() / F_MAX <= 1e-4
+    assert np.abs(out["U"] - ref["U"]).max() / F_MAX <= 2e-3
+
+
 # ---------------------------------------------------------------------------------------------
 # float64 general-size kernel (reference 16-thruster vehicle, long horizons)
 # ---------------------------------------------------------------------------------------------

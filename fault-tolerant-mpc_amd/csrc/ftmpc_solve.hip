@@ -1,19 +1,23 @@
 // ftmpc_solve.hip -- kernel 2 of the MPC QP-step path: condensed-QP build + primal-dual IPM (fp32).
 //
 // ONE WAVEFRONT (64 lanes, one workgroup) PER QP INSTANCE, persistent over the batch
-// (instance = blockIdx.x, += gridDim.x).  For its instance the wave
-//   1. propagates the horizon-stacked input-to-state map  G_{k+1} = A_k G_k | B_k D_act
-//      one COLUMN PER LANE in registers (the stage records come from ftmpc_linearize.hip),
-//   2. contracts  H = sum_k E_k' E_k,  E_k = sqrt(2 W_k) G_k[0:9],  with fp32 MFMA
-//      (v_mfma_f32_16x16x4_f32) into register-resident 16x16 accumulator tiles, and parks H in LDS,
+// (instance = blockIdx.x, += gridDim.x).  Everything is kept in the MFMA ACCUMULATOR LAYOUT of a
+// 16x16 tile (lane (q, col), register s = element (4q+s, col)): register s of row-group q' is then
+// contraction index k = 4q'+s, so BOTH operands of X'Y are plain accumulator registers (mm_tn).
+// For its instance the wave
+//   1. propagates the horizon-stacked input-to-state map  G_{k+1} = A_k G_k | B_k D_act  as NB
+//      accumulator tiles with v_mfma_f32_16x16x4_f32 against dense LDS images of the stage matrices
+//      (the stage records come from ftmpc_linearize.hip),
+//   2. contracts  H = sum_k E_k' E_k,  E_k = sqrt(2 W_k) G_k[0:9],  straight from those registers
+//      into register-resident accumulator tiles, and parks -H in LDS (tile = one b128 per lane),
 //   3. runs a Mehrotra predictor-corrector interior-point method on
 //         min 1/2 d'H d + g'd,  lo <= d <= hi      (d = U - Ubar, active thrusters only)
 //      whose KKT matrix H + Sigma is factorised by a left-looking 16x16-blocked Cholesky that lives
-//      ENTIRELY IN REGISTERS (tiles transposed in the MFMA accumulator layout, every tile product an
-//      MFMA on register operands; diagonal tiles factorised and inverted with v_readlane / DPP /
-//      v_permlane swaps), solved with MFMA (forward) and VALU+DPP (backward) substitutions, and whose
-//      gradient is gref + H (d - dref) with float64 accumulation around one accurate float64
-//      reference gradient (struct_grad).
+//      ENTIRELY IN REGISTERS (tiles transposed, every tile product an MFMA on register operands,
+//      every accumulator seeded directly from the LDS tile; diagonal tiles factorised and inverted
+//      with v_readlane / fused DPP FMAs / v_permlane swaps), solved with packed VALU FMAs and
+//      DPP / permlane reductions, and whose gradient follows the step through the solved Newton
+//      system around one accurate float64 reference gradient (struct_grad).
 // The algorithm is the one restated in oracle/qp_oracle.py (ipm_box); the reference solves
 // the corresponding NLP with CasADi/IPOPT (ft_mpc/controllers/spiraling_mpc.py:87-238,319-354)
 // followed by a cvxpy min-norm allocation (controllers/tools/control_allocator.py:65-94).
@@ -36,23 +40,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---- tile addressing -------------------------------------------------------------------
-// A 16x16 tile is stored row-major with its 16-B chunks permuted so that the MFMA operand
-// read (lane (r = lane&15, q = lane>>4) needs columns {q, 4+q, 8+q, 12+q} of row r) is ONE
-// conflict-free ds_read_b128:  word(r, c) = 16 r + 4 ((c&3) ^ g4[r>>2]) + (c>>2).
-// chunk swizzle table {0,2,3,1} by row quad, packed in 2-bit fields (0 | 2<<2 | 3<<4 | 1<<6 = 0x78):
-// makes the four 16-lane service groups of ds_read_b128 hit 16 distinct 4-bank slots.
+// Tile (I, J), I >= J, of the lower triangle is tile number I(I+1)/2 + J; in LDS a tile is 256 words
+// in REGISTER ORDER (word 4*lane + s = register s of that lane): one conflict-free b128 per lane.
 // One wave per workgroup: the LDS operations of a wave execute in issue order, so exchanging data
 // between its lanes through LDS needs no s_barrier -- and, unlike __syncthreads(), must not drain the
 // outstanding global loads (stage-record prefetch) or scratch traffic.  A compiler barrier suffices.
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("" ::: "memory"); }
 // same for the few exchanges that go through the per-workgroup global slot: stores must have landed
 __device__ __forceinline__ void wave_global_fence() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ int swz(int rq) { return (0x78 >> (2 * rq)) & 3; }
-__device__ __forceinline__ int toff(int r, int c) { return 16 * r + 4 * ((c & 3) ^ swz(r >> 2)) + (c >> 2); }
-__device__ __forceinline__ int chunk_off(int r, int ch) { return 16 * r + 4 * (ch ^ swz(r >> 2)); }
 __device__ __forceinline__ int tidx(int I, int J) { return (I * (I + 1)) / 2 + J; }
-// position of element c of a 16-block inside the permuted LDS vectors (matches chunk reads)
-__device__ __forceinline__ int vpos(int c) { return (c & 3) * 4 + (c >> 2); }
 
 __device__ __forceinline__ float readlane_f(float x, int l) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
@@ -326,28 +322,25 @@ __device__ __forceinline__ float row_sum16(float x) {
 // `#pragma unroll` loop: the barrier inside would otherwise block the unroller and push the
 // tile arrays into scratch).  T[tidx(I,J)] = L_IJ' for I > J, T[tidx(J,J)] = W_J', Wd[J] = W_J.
 template <int NB, int J>
-__device__ __forceinline__ void chol_reg_col(const float* tiles, const float* sigv, float* S, int nb, int lane,
-                                             const int (&toT)[4], const int (&toC)[4], bool& ok,
+__device__ __forceinline__ void chol_reg_col(const float* tiles, const float* sigv, float* S, int nb, int lane, bool& ok,
                                              f32x4 (&T)[NB * (NB + 1) / 2], f32x4 (&Wd)[NB]) {
     const int li = lane & 15, lq = lane >> 4;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     {
-        const float* tjj = tiles + tidx(J, J) * 256;
-        f32x4 a0 = zero, a1 = zero;
+        // every accumulator starts from the LDS tile (-H, register order) and collects  sum_K T_JK' T_IK  on top
+        f32x4 a0 = lds4(tiles + tidx(J, J) * 256 + 4 * lane), a1 = zero;
 #pragma unroll
         for (int K = 0; K < J; ++K) {
             if (K & 1) a1 = mm_tn(T[tidx(J, K)], T[tidx(J, K)], a1);
             else a0 = mm_tn(T[tidx(J, K)], T[tidx(J, K)], a0);
         }
-        // off-diagonal Schur accumulations do not depend on the diagonal block: they are issued in slices
-        // between the steps of the in-register potrf below, so the MFMA pipe works in its shadow
         f32x4 bacc[NB];
 #pragma unroll
-        for (int I = 0; I < NB; ++I) bacc[I] = zero;
+        for (int I = 0; I < NB; ++I) bacc[I] = (I > J) ? lds4(tiles + tidx(I, J) * 256 + 4 * lane) : zero;
         const float sg = sigv[16 * J + li];
         f32x4 cd;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) cd[rr] = tjj[toC[rr]] + ((4 * lq + rr == li) ? sg : 0.f) - (a0[rr] + a1[rr]);
+        for (int rr = 0; rr < 4; ++rr) cd[rr] = ((4 * lq + rr == li) ? sg : 0.f) - (a0[rr] + a1[rr]);   // H + Sigma - sum
         const f32x4 w = potrf_inv16_call(cd, lane, SchurWork<NB, J>{T, bacc});
         ok = ok && (fabsf(w.w) <= 3.0e38f);   // NaN or inf in W[15][15]: non-positive pivot
         Wd[J] = w;
@@ -356,34 +349,24 @@ __device__ __forceinline__ void chol_reg_col(const float* tiles, const float* si
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) S[(4 * lq + rr) * 17 + li] = w[rr];
         wave_lds_fence();
-        f32x4 wt;
+        f32x4 wt, wtn;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) wt[rr] = S[li * 17 + 4 * lq + rr];
+        for (int rr = 0; rr < 4; ++rr) {
+            wt[rr] = S[li * 17 + 4 * lq + rr];
+            wtn[rr] = -wt[rr];
+        }
         T[tidx(J, J)] = wt;
 #pragma unroll
-        for (int I = J + 1; I < NB; ++I) {
-            const float* tij = tiles + tidx(I, J) * 256;
-            f32x4 ct;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) ct[rr] = tij[toT[rr]] - bacc[I][rr];
-            T[tidx(I, J)] = mm_tn(wt, ct, zero);    // L_IJ' = W_J C_IJ'
-        }
+        for (int I = J + 1; I < NB; ++I) T[tidx(I, J)] = mm_tn(wtn, bacc[I], zero);    // L_IJ' = W_J (H_IJ' - sum) = -W_J bacc
     }
-    if constexpr (J + 1 < NB) chol_reg_col<NB, J + 1>(tiles, sigv, S, nb, lane, toT, toC, ok, T, Wd);
+    if constexpr (J + 1 < NB) chol_reg_col<NB, J + 1>(tiles, sigv, S, nb, lane, ok, T, Wd);
 }
 
 template <int NB>
 __device__ __forceinline__ bool chol_reg(const float* tiles, const float* sigv, float* S, int nb, int lane,
                                          f32x4 (&T)[NB * (NB + 1) / 2], f32x4 (&Wd)[NB]) {
-    const int li = lane & 15, lq = lane >> 4;
-    int toT[4], toC[4];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        toT[rr] = toff(li, 4 * lq + rr);   // element (row li, col 4lq+rr): transposed read
-        toC[rr] = toff(4 * lq + rr, li);   // element (row 4lq+rr, col li)
-    }
     bool ok = true;
-    chol_reg_col<NB, 0>(tiles, sigv, S, nb, lane, toT, toC, ok, T, Wd);
+    chol_reg_col<NB, 0>(tiles, sigv, S, nb, lane, ok, T, Wd);
     return __all(ok);
 }
 
@@ -965,8 +948,9 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 if (I <= Imax) {
 #pragma unroll
                     for (int J = 0; J <= I; ++J) {
+                        // tile (I,J) is kept TRANSPOSED, (H_IJ)' = E_J' E_I: the layout the factorisation consumes
 #pragma unroll
-                        for (int s3 = 0; s3 < 3; ++s3) acc[(I * (I + 1)) / 2 + J] = mfma4(E[I][s3], E[J][s3], acc[(I * (I + 1)) / 2 + J]);
+                        for (int s3 = 0; s3 < 3; ++s3) acc[(I * (I + 1)) / 2 + J] = mfma4(E[J][s3], E[I][s3], acc[(I * (I + 1)) / 2 + J]);
                     }
                 }
             STAMP(2);
@@ -995,12 +979,13 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 for (int dJ = 0; dJ < 2; ++dJ) {
                     const int J = I - 1 + dJ;
                     if (J < 0) continue;
-                    const int e2 = 16 * J + li;
-                    const int s2 = s_stg[e2], a2 = s_thr[e2];
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
-                        const int e1 = 16 * I + 4 * lq + rr;
+                        // register rr of lane (lq, li): H[16I + 4lq+rr][16I + li] on the diagonal, H[16I + li][16J + 4lq+rr] below it
+                        const int e1 = (I == J) ? 16 * I + 4 * lq + rr : 16 * I + li;
+                        const int e2 = (I == J) ? 16 * J + li : 16 * J + 4 * lq + rr;
                         const int s1 = s_stg[e1], a1 = s_thr[e1];
+                        const int s2 = s_stg[e2], a2 = s_thr[e2];
                         float add = 0.f;
                         if (s1 != 255 && s1 == s2) {
 #pragma unroll
@@ -1014,7 +999,9 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 }
             }
         {
-            // H -> LDS once; it is never overwritten (the factor lives in registers)
+            // -H -> LDS once, each tile exactly as its lanes hold it (one b128 per lane, conflict free): the
+            // factorisation loads a tile STRAIGHT INTO the MFMA accumulator that collects the Schur terms
+            // (sum T'T - H), so no VALU instruction touches it.  Never overwritten (the factor lives in registers).
             wave_lds_fence();
 #pragma unroll
             for (int I = 0; I < NB; ++I)
@@ -1022,7 +1009,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
 #pragma unroll
                     for (int J = 0; J <= I; ++J) {
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) tiles[((I * (I + 1)) / 2 + J) * 256 + toff(4 * lq + rr, li)] = acc[(I * (I + 1)) / 2 + J][rr];
+                        for (int rr = 0; rr < 4; ++rr) tiles[((I * (I + 1)) / 2 + J) * 256 + 4 * lane + rr] = -acc[(I * (I + 1)) / 2 + J][rr];
                     }
                 }
             wave_lds_fence();
@@ -1047,7 +1034,8 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                     for (int J = 0; J <= I; ++J) {
 #pragma unroll
                         for (int rr = 0; rr < 4; ++rr) {
-                            const int e1 = 16 * I + 4 * lq + rr, e2 = 16 * J + li;
+                            const int e1 = (I == J) ? 16 * I + 4 * lq + rr : 16 * I + li;
+                            const int e2 = (I == J) ? 16 * J + li : 16 * J + 4 * lq + rr;
                             const float h = acc[(I * (I + 1)) / 2 + J][rr];
                             if (I != J || e1 >= e2) {
                                 P.dbg_H[(int64_t)e1 * npadr + e2] = h;
@@ -1131,46 +1119,58 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int e = v * 64 + lane;
-                if (e < npadr) dvp[16 * (e >> 4) + vpos(e & 15)] = dcur[v] - dref[v];
+                if (e < npadr) dvp[e] = dcur[v] - dref[v];
             }
             wave_lds_fence();
             {
-                // per-lane partial sums a[I] cover (row li of block I) x (this lane's 4 columns of block J).
-                // fp32 is enough here: the product only spans the distance to the reference point of the
-                // gradient (float64, see struct_grad), so its rounding is second order.
-                f32x2 am[NB];
+                // Tile (I,J), I >= J, sits in LDS as -(H_IJ)' in register order: lane (q, col) holds
+                // -H[16I + col][16J + 4q + r], r = 0..3.  One read serves both triangles:
+                //   y_I[col]   += sum_r H.. d_J[4q+r]   (per-lane dot, then over the row-groups:  row vector)
+                //   y_J[4q+r]  += H.. d_I[col]          (then over the 16 columns:  column tile; I > J only)
+                // fp32 is enough: the product only spans the distance to the reference point of the gradient.
+                f32x2 arow[NB];
+                f32x4 acol[NB];
 #pragma unroll
-                for (int I = 0; I < NB; ++I) am[I] = f32x2{0.f, 0.f};
+                for (int I = 0; I < NB; ++I) {
+                    arow[I] = f32x2{0.f, 0.f};
+                    acol[I] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
 #pragma unroll
-                for (int J = 0; J < NB; ++J)
-                    if (J < nbr) {
-                        const f32x4 d4 = lds4(dvp + 16 * J + 4 * lq);   // columns {lq,4+lq,8+lq,12+lq} of block J
-                        f32x4 dt;                                      // rows 4lq+rr of block J (transposed use)
+                for (int I = 0; I < NB; ++I) {
+                    const float dI = dvp[16 * I + li];
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) dt[rr] = dvp[16 * J + rr * 4 + lq];
-#pragma unroll
-                        for (int I = 0; I < NB; ++I)
-                            if (I < nbr) {
-                                f32x4 t4;
-                                if (J <= I) {
-                                    t4 = lds4(tiles + ((I * (I + 1)) / 2 + J) * 256 + chunk_off(li, lq));
-                                    am[I] += f32x2{t4.x, t4.y} * f32x2{d4.x, d4.y};
-                                    am[I] += f32x2{t4.z, t4.w} * f32x2{d4.z, d4.w};
-                                } else {
-                                    const float* t = tiles + ((J * (J + 1)) / 2 + I) * 256;
-#pragma unroll
-                                    for (int rr = 0; rr < 4; ++rr) t4[rr] = t[toff(4 * lq + rr, li)];
-                                    am[I] += f32x2{t4.x, t4.y} * f32x2{dt.x, dt.y};
-                                    am[I] += f32x2{t4.z, t4.w} * f32x2{dt.z, dt.w};
-                                }
-                            }
+                    for (int J = 0; J <= I; ++J) {
+                        const f32x4 t4 = lds4(tiles + ((I * (I + 1)) / 2 + J) * 256 + 4 * lane);
+                        const f32x4 d4 = lds4(dvp + 16 * J + 4 * lq);
+                        arow[I] += f32x2{t4.x, t4.y} * f32x2{d4.x, d4.y};
+                        arow[I] += f32x2{t4.z, t4.w} * f32x2{d4.z, d4.w};
+                        if (J < I) acol[J] += t4 * dI;
                     }
+                }
+                // column-tile parts to natural order through LDS (xvp is free here), row parts by lane select
+                wave_lds_fence();
 #pragma unroll
-                for (int I = 0; I < NB; ++I)
-                    if (I < nbr) {
-                        const float a = quad_sum(am[I].x + am[I].y);
-                        if (lq == (I & 3)) grad[I >> 2] = valid[I >> 2] ? (float)((double)a + gref[I >> 2]) : 0.f;
-                    }
+                for (int J = 0; J < NB; ++J) {
+                    f32x4 c4;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) c4[rr] = row_sum16(acol[J][rr]);
+                    if (li == 0) *reinterpret_cast<f32x4*>(xvp + 16 * J + 4 * lq) = c4;
+                }
+                wave_lds_fence();
+                float yrow[NB];
+#pragma unroll
+                for (int I = 0; I < NB; ++I) yrow[I] = quad_sum(arow[I].x + arow[I].y);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (4 * v + j < NB) t = (lq == j) ? yrow[4 * v + j] : t;
+                    const int e = v * 64 + lane;
+                    const float hd = -(t + ((e < npadr) ? xvp[e] : 0.f));      // the tiles hold -H
+                    grad[v] = valid[v] ? (float)((double)hd + gref[v]) : 0.f;
+                }
+                wave_lds_fence();
             }
             }
             STAMP(4);

@@ -53,18 +53,28 @@ __device__ __forceinline__ int tidx(int I, int J) { return (I * (I + 1)) / 2 + J
 __device__ __forceinline__ float readlane_f(float x, int l) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
 }
-__device__ __forceinline__ float wave_sum(float x) {
-    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
-    return x;
+// Whole-wave reductions, result in every lane: four DPP row rotations inside the 16-lane rows, then
+// the two permlane swaps across the four rows (10 VALU, ~80 cycles; the __shfl_xor butterfly compiles to
+// six dependent ds_bpermute round trips through the LDS crossbar, ~500 cycles per reduction).
+struct OpAdd { static __device__ __forceinline__ float f(float a, float b) { return a + b; } };
+struct OpMin { static __device__ __forceinline__ float f(float a, float b) { return fminf(a, b); } };
+struct OpMax { static __device__ __forceinline__ float f(float a, float b) { return fmaxf(a, b); } };
+template <class Op>
+__device__ __forceinline__ float wave_reduce(float x) {
+    x = Op::f(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false)));  // row_ror:8
+    x = Op::f(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xf, 0xf, false)));  // row_ror:4
+    x = Op::f(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x122, 0xf, 0xf, false)));  // row_ror:2
+    x = Op::f(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xf, 0xf, false)));  // row_ror:1
+    unsigned a = __builtin_bit_cast(unsigned, x), b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));   // a = [r0,r1,r0,r1], b = [r2,r3,r2,r3]
+    const float s = Op::f(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+    unsigned c = __builtin_bit_cast(unsigned, s), d = c;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(c), "+v"(d));   // c = [s0,s0,s2,s2], d = [s1,s1,s3,s3]
+    return Op::f(__builtin_bit_cast(float, c), __builtin_bit_cast(float, d));
 }
-__device__ __forceinline__ float wave_min(float x) {
-    for (int m = 32; m >= 1; m >>= 1) x = fminf(x, __shfl_xor(x, m, 64));
-    return x;
-}
-__device__ __forceinline__ float wave_max(float x) {
-    for (int m = 32; m >= 1; m >>= 1) x = fmaxf(x, __shfl_xor(x, m, 64));
-    return x;
-}
+__device__ __forceinline__ float wave_sum(float x) { return wave_reduce<OpAdd>(x); }
+__device__ __forceinline__ float wave_min(float x) { return wave_reduce<OpMin>(x); }
+__device__ __forceinline__ float wave_max(float x) { return wave_reduce<OpMax>(x); }
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }

@@ -170,6 +170,8 @@ int grow(ftmpc_handle* h, T** p, int64_t count) {
 }
 
 int tiles_of(int nb) { return nb * (nb + 1) / 2; }
+// per-workgroup global slot of the fp32 kernels (layout: ftmpc_common.h): sweep scratch, then the Hessian tiles
+int64_t slot_words(int nb, int N) { return ftmpc::slot_tile_off_words(N) + (int64_t)tiles_of(nb) * 256; }
 
 int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, const double* stuck,
             const double* xref, int64_t xref_stride, const double* uref, int64_t uref_stride,
@@ -231,7 +233,7 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
         const int NBv = 8 + v;
         if (v > 0 && h->nb_max < NBv) break;
         sp.hscratch = h->hs[v];
-        sp.tile_words = (int64_t)tiles_of(NBv) * 256;
+        sp.tile_words = slot_words(NBv, h->dc.N);
         sp.nb_lo = (v == 0) ? 0 : NBv - 1;
         sp.nb_hi_owner = (h->nb_max <= NBv) ? 1 : 0;
         const int grid = (int)std::min<int64_t>(B, h->grid[v]);
@@ -372,9 +374,9 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
               grow(h, &h->d_dbgH64, (int64_t)h->npad_max * h->npad_max) != FTMPC_OK ||
               grow(h, &h->d_dbgv64, 3 * (int64_t)h->npad_max + 4) != FTMPC_OK;
     } else {
-        bad = grow(h, &h->hs[0], (int64_t)h->grid[0] * tiles_of(8) * 256) != FTMPC_OK ||
-              (h->nb_max > 8 && grow(h, &h->hs[1], (int64_t)h->grid[1] * tiles_of(9) * 256) != FTMPC_OK) ||
-              (h->nb_max > 9 && grow(h, &h->hs[2], (int64_t)h->grid[2] * tiles_of(10) * 256) != FTMPC_OK) ||
+        bad = grow(h, &h->hs[0], (int64_t)h->grid[0] * slot_words(8, cfg->N)) != FTMPC_OK ||
+              (h->nb_max > 8 && grow(h, &h->hs[1], (int64_t)h->grid[1] * slot_words(9, cfg->N)) != FTMPC_OK) ||
+              (h->nb_max > 9 && grow(h, &h->hs[2], (int64_t)h->grid[2] * slot_words(10, cfg->N)) != FTMPC_OK) ||
               grow(h, &h->d_dbgH, 4096 * 24 + 160 * 160) != FTMPC_OK || grow(h, &h->d_dbgv, 3 * 160 + 4) != FTMPC_OK;
     }
     if (bad) {

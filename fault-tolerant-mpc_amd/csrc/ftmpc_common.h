@@ -12,6 +12,7 @@
 // (p enters nothing, v only p, the attitude chain (w,q) is autonomous), so only the named
 // blocks are stored.
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace ftmpc {
@@ -37,6 +38,15 @@ enum : int {
 };
 
 constexpr int MAX_NT = 16;
+
+// Per-workgroup global slot of the fp32 solve kernels, in 4-byte words:
+//   doubles [0, 160)            reference gradient (n <= 160)
+//   doubles [160, 160 + 8N)     wrench perturbations of all stages
+//   doubles [160 + 8N, ..+9(N+1)) stage storage of the sweeps when it does not fit in LDS
+//   then, 256-word aligned, the Hessian tiles (used by the instantiations with NB > 8)
+__host__ __device__ constexpr int slot_gens_off() { return 160; }
+__host__ __device__ constexpr int slot_stage_off(int N) { return 160 + 8 * N; }
+__host__ __device__ constexpr int slot_tile_off_words(int N) { return ((2 * (160 + 8 * N + 9 * (N + 1)) + 255) / 256) * 256; }
 
 // constants shared by both kernels (passed by value as kernel argument)
 struct DeviceConsts {

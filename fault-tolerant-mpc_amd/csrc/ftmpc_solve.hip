@@ -79,6 +79,25 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+// The Hessian tiles (register order: word 4*lane + s of a 256-word tile) live in LDS for NB = 8; for the
+// larger instantiations they would cut the residency to 3 or 2 waves per CU, so there they sit in the
+// per-workgroup global slot (L2 / Infinity-Cache resident; every lane re-reads only what it wrote itself).
+typedef __attribute__((address_space(1))) float glb_f32;
+template <bool IN_GLOBAL>
+struct TileStore;
+template <>
+struct TileStore<false> {
+    float* p;
+    __device__ __forceinline__ f32x4 ld(int tile, int lane) const { return *reinterpret_cast<const f32x4*>(p + tile * 256 + 4 * lane); }
+    __device__ __forceinline__ void st(int tile, int lane, f32x4 v) const { *reinterpret_cast<f32x4*>(p + tile * 256 + 4 * lane) = v; }
+};
+template <>
+struct TileStore<true> {
+    glb_f32* p;
+    typedef __attribute__((address_space(1))) f32x4 glb_f32x4;
+    __device__ __forceinline__ f32x4 ld(int tile, int lane) const { return *reinterpret_cast<const glb_f32x4*>(p + tile * 256 + 4 * lane); }
+    __device__ __forceinline__ void st(int tile, int lane, f32x4 v) const { *reinterpret_cast<glb_f32x4*>(p + tile * 256 + 4 * lane) = v; }
+};
 
 // Diagnostic build only (-DFTMPC_STAMPS, never the shipped library): per-phase cycle totals
 // of each instance's wave, written to SolveParams::dbg_H (reused as a u64 buffer).
@@ -331,22 +350,27 @@ __device__ __forceinline__ float row_sum16(float x) {
 // one block column of the register-resident factorisation (template recursion instead of a
 // `#pragma unroll` loop: the barrier inside would otherwise block the unroller and push the
 // tile arrays into scratch).  T[tidx(I,J)] = L_IJ' for I > J, T[tidx(J,J)] = W_J', Wd[J] = W_J.
-template <int NB, int J>
-__device__ __forceinline__ void chol_reg_col(const float* tiles, const float* sigv, float* S, int nb, int lane, bool& ok,
-                                             f32x4 (&T)[NB * (NB + 1) / 2], f32x4 (&Wd)[NB]) {
+template <int NB, int J, bool PREFETCH, class TilesT>
+__device__ __forceinline__ void chol_reg_col(const TilesT& tiles, const float* sigv, float* S, int nb, int lane, bool& ok,
+                                             f32x4 (&T)[NB * (NB + 1) / 2], f32x4 (&Wd)[NB], const f32x4 (&pre)[NB]) {
     const int li = lane & 15, lq = lane >> 4;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     {
-        // every accumulator starts from the LDS tile (-H, register order) and collects  sum_K T_JK' T_IK  on top
-        f32x4 a0 = lds4(tiles + tidx(J, J) * 256 + 4 * lane), a1 = zero;
+        // every accumulator starts from the stored tile (-H, register order) and collects  sum_K T_JK' T_IK  on top.
+        // PREFETCH (tiles in the global slot): the tiles of this column were requested before the previous
+        // column's potrf (`pre`), and the next column's are requested here, a potrf ahead of their use.
+        f32x4 a0 = PREFETCH ? pre[J] : tiles.ld(tidx(J, J), lane), a1 = zero;
+        f32x4 bacc[NB];
+#pragma unroll
+        for (int I = 0; I < NB; ++I) bacc[I] = (I > J) ? (PREFETCH ? pre[I] : tiles.ld(tidx(I, J), lane)) : zero;
+        f32x4 nxt[NB];
+#pragma unroll
+        for (int I = 0; I < NB; ++I) nxt[I] = (PREFETCH && J + 1 < NB && I > J) ? tiles.ld(tidx(I, J + 1), lane) : zero;
 #pragma unroll
         for (int K = 0; K < J; ++K) {
             if (K & 1) a1 = mm_tn(T[tidx(J, K)], T[tidx(J, K)], a1);
             else a0 = mm_tn(T[tidx(J, K)], T[tidx(J, K)], a0);
         }
-        f32x4 bacc[NB];
-#pragma unroll
-        for (int I = 0; I < NB; ++I) bacc[I] = (I > J) ? lds4(tiles + tidx(I, J) * 256 + 4 * lane) : zero;
         const float sg = sigv[16 * J + li];
         f32x4 cd;
 #pragma unroll
@@ -368,15 +392,18 @@ __device__ __forceinline__ void chol_reg_col(const float* tiles, const float* si
         T[tidx(J, J)] = wt;
 #pragma unroll
         for (int I = J + 1; I < NB; ++I) T[tidx(I, J)] = mm_tn(wtn, bacc[I], zero);    // L_IJ' = W_J (H_IJ' - sum) = -W_J bacc
+        if constexpr (J + 1 < NB) chol_reg_col<NB, J + 1, PREFETCH, TilesT>(tiles, sigv, S, nb, lane, ok, T, Wd, nxt);
     }
-    if constexpr (J + 1 < NB) chol_reg_col<NB, J + 1>(tiles, sigv, S, nb, lane, ok, T, Wd);
 }
 
-template <int NB>
-__device__ __forceinline__ bool chol_reg(const float* tiles, const float* sigv, float* S, int nb, int lane,
+template <int NB, bool PREFETCH, class TilesT>
+__device__ __forceinline__ bool chol_reg(const TilesT& tiles, const float* sigv, float* S, int nb, int lane,
                                          f32x4 (&T)[NB * (NB + 1) / 2], f32x4 (&Wd)[NB]) {
     bool ok = true;
-    chol_reg_col<NB, 0>(tiles, sigv, S, nb, lane, ok, T, Wd);
+    f32x4 pre[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) pre[I] = PREFETCH ? tiles.ld(tidx(I, 0), lane) : f32x4{0.f, 0.f, 0.f, 0.f};
+    chol_reg_col<NB, 0, PREFETCH, TilesT>(tiles, sigv, S, nb, lane, ok, T, Wd, pre);
     return __all(ok);
 }
 
@@ -543,7 +570,7 @@ __device__ __noinline__ void struct_grad(const DeviceConsts& C, glb_cf64* recg, 
     const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
     // wrench perturbations gen_k = Da d_k of ALL stages up front, one (stage, component) pair per lane,
     // parked behind the gradient in the global scratch (N x 8 doubles) and prefetched with the records
-    glb_f64* genS = gout + 16 * ((N * na + 15) / 16);
+    glb_f64* genS = gout + slot_gens_off();
     for (int t = lane; t < N * 8; t += 64) {
         const int k = t >> 3, g = t & 7;
         double acc = 0.0;
@@ -741,7 +768,9 @@ template <int NB>
 __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceConsts C, const SolveParams P) {
     using SH = Shape<NB>;
     constexpr int NPAD = SH::NPAD, NV = SH::NV, NTILES = SH::NTILES;
-    __shared__ __attribute__((aligned(16))) float tiles[NTILES * 256];
+    constexpr bool HG = NB > 9;                 // Hessian tiles in the global slot (see TileStore); NB = 9 is faster from LDS at 3 waves/CU
+    constexpr int BUILD_WORDS = 2 * DENSE_WORDS + 256;   // dense stage-matrix images of the build phase; later N*NT output words
+    __shared__ __attribute__((aligned(16))) float tiles[HG ? BUILD_WORDS : NTILES * 256];
     __shared__ __attribute__((aligned(16))) float recbuf[2 * REC_STRIDE + 8];   // two fp32 stage records | one fp64 record + {0,1,dt}
     __shared__ __attribute__((aligned(16))) float work[SH::WORK + SH::SEXTRA];
     __shared__ __attribute__((aligned(16))) float s_Da[6 * MAX_NT];
@@ -754,6 +783,9 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
     const int lane = threadIdx.x;
     const int li = lane & 15, lq = lane >> 4;
     const int N = C.N, NT = C.NT;
+    TileStore<HG> htiles;
+    if constexpr (HG) htiles.p = (glb_f32*)(P.hscratch + (int64_t)blockIdx.x * P.tile_words + slot_tile_off_words(C.N));
+    else htiles.p = tiles;
     const float rho = (float)C.rho;
     const float mu_stop = (float)C.mu_stop;
     float Rf[6];
@@ -1018,8 +1050,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 if (I < nbr) {
 #pragma unroll
                     for (int J = 0; J <= I; ++J) {
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) tiles[((I * (I + 1)) / 2 + J) * 256 + 4 * lane + rr] = -acc[(I * (I + 1)) / 2 + J][rr];
+                        htiles.st((I * (I + 1)) / 2 + J, lane, -acc[(I * (I + 1)) / 2 + J]);
                     }
                 }
             wave_lds_fence();
@@ -1110,7 +1141,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                                 (lds_f64*)reinterpret_cast<double*>(dvp), (glb_f64*)gout, na, lane);
                 else
                     struct_grad(C, (glb_cf64*)recg, (lds_f64*)reinterpret_cast<double*>(recbuf), (lds_cf32*)s_Da, (lds_cf32*)xvp,
-                                (glb_f64*)(sbuf + NPAD + 8 * 64), (glb_f64*)gout, na, lane);
+                                (glb_f64*)(sbuf + slot_stage_off(N)), (glb_f64*)gout, na, lane);
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
                     const int e = v * 64 + lane;
@@ -1150,7 +1181,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                     const float dI = dvp[16 * I + li];
 #pragma unroll
                     for (int J = 0; J <= I; ++J) {
-                        const f32x4 t4 = lds4(tiles + ((I * (I + 1)) / 2 + J) * 256 + 4 * lane);
+                        const f32x4 t4 = htiles.ld((I * (I + 1)) / 2 + J, lane);
                         const f32x4 d4 = lds4(dvp + 16 * J + 4 * lq);
                         arow[I] += f32x2{t4.x, t4.y} * f32x2{d4.x, d4.y};
                         arow[I] += f32x2{t4.z, t4.w} * f32x2{d4.z, d4.w};
@@ -1228,7 +1259,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
             }
             wave_lds_fence();
             STAMP(7);
-            const bool ok = chol_reg<NB>(tiles, dvp, recbuf, nbr, lane, Tt, Wd);
+            const bool ok = chol_reg<NB, HG>(htiles, dvp, recbuf, nbr, lane, Tt, Wd);
             STAMP(5);
             if (__builtin_amdgcn_readfirstlane(!ok)) {
                 status = 2;

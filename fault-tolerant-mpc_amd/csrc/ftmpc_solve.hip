@@ -83,20 +83,23 @@ __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast
 // larger instantiations they would cut the residency to 3 or 2 waves per CU, so there they sit in the
 // per-workgroup global slot (L2 / Infinity-Cache resident; every lane re-reads only what it wrote itself).
 typedef __attribute__((address_space(1))) float glb_f32;
-template <bool IN_GLOBAL>
-struct TileStore;
-template <>
-struct TileStore<false> {
-    float* p;
-    __device__ __forceinline__ f32x4 ld(int tile, int lane) const { return *reinterpret_cast<const f32x4*>(p + tile * 256 + 4 * lane); }
-    __device__ __forceinline__ void st(int tile, int lane, f32x4 v) const { *reinterpret_cast<f32x4*>(p + tile * 256 + 4 * lane) = v; }
-};
-template <>
-struct TileStore<true> {
-    glb_f32* p;
+// NLDS = number of leading tiles (tile number I(I+1)/2 + J, i.e. whole block rows) kept in LDS; the
+// rest sits in the global slot.  Tile numbers are compile-time constants at every call site.
+template <int NLDS>
+struct TileStore {
+    float* p;        // LDS, tiles [0, NLDS)
+    glb_f32* g;      // global slot, tiles [NLDS, ..)
     typedef __attribute__((address_space(1))) f32x4 glb_f32x4;
-    __device__ __forceinline__ f32x4 ld(int tile, int lane) const { return *reinterpret_cast<const glb_f32x4*>(p + tile * 256 + 4 * lane); }
-    __device__ __forceinline__ void st(int tile, int lane, f32x4 v) const { *reinterpret_cast<glb_f32x4*>(p + tile * 256 + 4 * lane) = v; }
+    static constexpr bool is_global(int tile) { return tile >= NLDS; }
+    static constexpr bool any_global(int ntiles) { return ntiles > NLDS; }
+    __device__ __forceinline__ f32x4 ld(int tile, int lane) const {
+        if (tile < NLDS) return *reinterpret_cast<const f32x4*>(p + tile * 256 + 4 * lane);
+        return *reinterpret_cast<const glb_f32x4*>(g + (tile - NLDS) * 256 + 4 * lane);
+    }
+    __device__ __forceinline__ void st(int tile, int lane, f32x4 v) const {
+        if (tile < NLDS) *reinterpret_cast<f32x4*>(p + tile * 256 + 4 * lane) = v;
+        else *reinterpret_cast<glb_f32x4*>(g + (tile - NLDS) * 256 + 4 * lane) = v;
+    }
 };
 
 // Diagnostic build only (-DFTMPC_STAMPS, never the shipped library): per-phase cycle totals
@@ -129,7 +132,7 @@ struct Shape {
     static constexpr int NV = (NPAD + 63) / 64;
     static constexpr int NTILES = NB * (NB + 1) / 2;
     static constexpr int WORK = 2 * NPAD;                               // xvp | dvp
-    static constexpr int SEXTRA = 280;                                  // + stage storage of struct_grad (fills the 40 KiB/wave budget)
+    static constexpr int SEXTRA = (NB == 9) ? 240 : 280;                                  // + stage storage of struct_grad (fills the 40 KiB/wave budget)
 };
 
 // ---- cross-lane primitives on the accumulator layout -------------------------------------
@@ -350,22 +353,22 @@ __device__ __forceinline__ float row_sum16(float x) {
 // one block column of the register-resident factorisation (template recursion instead of a
 // `#pragma unroll` loop: the barrier inside would otherwise block the unroller and push the
 // tile arrays into scratch).  T[tidx(I,J)] = L_IJ' for I > J, T[tidx(J,J)] = W_J', Wd[J] = W_J.
-template <int NB, int J, bool PREFETCH, class TilesT>
+template <int NB, int J, class TilesT>
 __device__ __forceinline__ void chol_reg_col(const TilesT& tiles, const float* sigv, float* S, int nb, int lane, bool& ok,
                                              f32x4 (&T)[NB * (NB + 1) / 2], f32x4 (&Wd)[NB], const f32x4 (&pre)[NB]) {
     const int li = lane & 15, lq = lane >> 4;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     {
         // every accumulator starts from the stored tile (-H, register order) and collects  sum_K T_JK' T_IK  on top.
-        // PREFETCH (tiles in the global slot): the tiles of this column were requested before the previous
-        // column's potrf (`pre`), and the next column's are requested here, a potrf ahead of their use.
-        f32x4 a0 = PREFETCH ? pre[J] : tiles.ld(tidx(J, J), lane), a1 = zero;
+        // Tiles that live in the global slot were requested before the previous column's potrf (`pre`), and
+        // the next column's are requested here, a potrf ahead of their use.
+        f32x4 a0 = TilesT::is_global(tidx(J, J)) ? pre[J] : tiles.ld(tidx(J, J), lane), a1 = zero;
         f32x4 bacc[NB];
 #pragma unroll
-        for (int I = 0; I < NB; ++I) bacc[I] = (I > J) ? (PREFETCH ? pre[I] : tiles.ld(tidx(I, J), lane)) : zero;
+        for (int I = 0; I < NB; ++I) bacc[I] = (I > J) ? (TilesT::is_global(tidx(I, J)) ? pre[I] : tiles.ld(tidx(I, J), lane)) : zero;
         f32x4 nxt[NB];
 #pragma unroll
-        for (int I = 0; I < NB; ++I) nxt[I] = (PREFETCH && J + 1 < NB && I > J) ? tiles.ld(tidx(I, J + 1), lane) : zero;
+        for (int I = 0; I < NB; ++I) nxt[I] = (J + 1 < NB && I > J && TilesT::is_global(tidx(I, J + 1))) ? tiles.ld(tidx(I, J + 1), lane) : zero;
 #pragma unroll
         for (int K = 0; K < J; ++K) {
             if (K & 1) a1 = mm_tn(T[tidx(J, K)], T[tidx(J, K)], a1);
@@ -392,18 +395,18 @@ __device__ __forceinline__ void chol_reg_col(const TilesT& tiles, const float* s
         T[tidx(J, J)] = wt;
 #pragma unroll
         for (int I = J + 1; I < NB; ++I) T[tidx(I, J)] = mm_tn(wtn, bacc[I], zero);    // L_IJ' = W_J (H_IJ' - sum) = -W_J bacc
-        if constexpr (J + 1 < NB) chol_reg_col<NB, J + 1, PREFETCH, TilesT>(tiles, sigv, S, nb, lane, ok, T, Wd, nxt);
+        if constexpr (J + 1 < NB) chol_reg_col<NB, J + 1, TilesT>(tiles, sigv, S, nb, lane, ok, T, Wd, nxt);
     }
 }
 
-template <int NB, bool PREFETCH, class TilesT>
+template <int NB, class TilesT>
 __device__ __forceinline__ bool chol_reg(const TilesT& tiles, const float* sigv, float* S, int nb, int lane,
                                          f32x4 (&T)[NB * (NB + 1) / 2], f32x4 (&Wd)[NB]) {
     bool ok = true;
     f32x4 pre[NB];
 #pragma unroll
-    for (int I = 0; I < NB; ++I) pre[I] = PREFETCH ? tiles.ld(tidx(I, 0), lane) : f32x4{0.f, 0.f, 0.f, 0.f};
-    chol_reg_col<NB, 0, PREFETCH, TilesT>(tiles, sigv, S, nb, lane, ok, T, Wd, pre);
+    for (int I = 0; I < NB; ++I) pre[I] = TilesT::is_global(tidx(I, 0)) ? tiles.ld(tidx(I, 0), lane) : f32x4{0.f, 0.f, 0.f, 0.f};
+    chol_reg_col<NB, 0, TilesT>(tiles, sigv, S, nb, lane, ok, T, Wd, pre);
     return __all(ok);
 }
 
@@ -768,9 +771,12 @@ template <int NB>
 __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceConsts C, const SolveParams P) {
     using SH = Shape<NB>;
     constexpr int NPAD = SH::NPAD, NV = SH::NV, NTILES = SH::NTILES;
-    constexpr bool HG = NB > 9;                 // Hessian tiles in the global slot (see TileStore); NB = 9 is faster from LDS at 3 waves/CU
+    // Hessian tiles kept in LDS (whole block rows; see TileStore): all 36 for NB = 8; the first 8 block rows
+    // (36 tiles) for NB = 9, whose ninth row comes from the global slot one tile per column; the first 35
+    // of 55 for NB = 10.  Each choice leaves 4 resident waves per CU (one per SIMD).
+    constexpr int NLDS = (NB == 8) ? NTILES : (NB == 9 ? 36 : 35);
     constexpr int BUILD_WORDS = 2 * DENSE_WORDS + 256;   // dense stage-matrix images of the build phase; later N*NT output words
-    __shared__ __attribute__((aligned(16))) float tiles[HG ? BUILD_WORDS : NTILES * 256];
+    __shared__ __attribute__((aligned(16))) float tiles[(NLDS * 256 > BUILD_WORDS) ? NLDS * 256 : BUILD_WORDS];
     __shared__ __attribute__((aligned(16))) float recbuf[2 * REC_STRIDE + 8];   // two fp32 stage records | one fp64 record + {0,1,dt}
     __shared__ __attribute__((aligned(16))) float work[SH::WORK + SH::SEXTRA];
     __shared__ __attribute__((aligned(16))) float s_Da[6 * MAX_NT];
@@ -783,9 +789,9 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
     const int lane = threadIdx.x;
     const int li = lane & 15, lq = lane >> 4;
     const int N = C.N, NT = C.NT;
-    TileStore<HG> htiles;
-    if constexpr (HG) htiles.p = (glb_f32*)(P.hscratch + (int64_t)blockIdx.x * P.tile_words + slot_tile_off_words(C.N));
-    else htiles.p = tiles;
+    TileStore<NLDS> htiles;
+    htiles.p = tiles;
+    htiles.g = (glb_f32*)(P.hscratch + (int64_t)blockIdx.x * P.tile_words + slot_tile_off_words(C.N));
     const float rho = (float)C.rho;
     const float mu_stop = (float)C.mu_stop;
     float Rf[6];
@@ -1259,7 +1265,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
             }
             wave_lds_fence();
             STAMP(7);
-            const bool ok = chol_reg<NB, HG>(htiles, dvp, recbuf, nbr, lane, Tt, Wd);
+            const bool ok = chol_reg<NB>(htiles, dvp, recbuf, nbr, lane, Tt, Wd);
             STAMP(5);
             if (__builtin_amdgcn_readfirstlane(!ok)) {
                 status = 2;

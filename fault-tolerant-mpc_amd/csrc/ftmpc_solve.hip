@@ -242,9 +242,11 @@ template <int J>
 struct StepMasks {
     static constexpr unsigned long long grp = lane_mask([](int q, int) { return q == (J >> 2); });
 };
-// `work.run<S>()` is called at 80 points of the potrf + inverse (S = 0..79): the caller issues ONE
-// independent MFMA per slot, which then executes in the shadow of this VALU chain (issue is in
-// order, so the two instruction streams must alternate in program order).
+// `work.run<S>()` is called at 80 points of the potrf + inverse (S = 0..79): the caller may issue one
+// independent MFMA per slot.  This does NOT buy overlap -- a wave cannot issue VALU work while one of its
+// own MFMAs executes (scripts/ubench_mfma.hip: 32 + 5k cycles for an MFMA and k independent v_fma), and
+// the scheduler moves the MFMAs where it likes anyway -- it only gives the off-diagonal Schur products a
+// place in program order where their operands are already there and their results not yet needed.
 template <int J, class Work>
 __device__ __forceinline__ void potrf_inv_step(float (&c)[4], float (&e)[4], float (&w)[4], const Work& work) {
     constexpr int QJ = J >> 2, RJ = J & 3;

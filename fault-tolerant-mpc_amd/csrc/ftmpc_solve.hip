@@ -766,6 +766,38 @@ constexpr DensePosTable make_dense_pos() {
     return t;
 }
 __device__ const DensePosTable k_dense_pos = make_dense_pos();
+// compile-time checks of the scatter: every Jacobian word has its own cell, none lands on a constant
+// entry (I, dt I) of the A image, and the non-matrix words (W e, R ut, padding) go to the dump word
+constexpr bool dense_pos_ok() {
+    bool used[DENSE_WORDS] = {};
+    for (int a = 0; a < 3; ++a) {
+        used[16 * tile_row(a) + tile_row(a)] = true;          // d p / d p
+        used[16 * tile_row(a) + tile_row(3 + a)] = true;      // d p / d v = dt
+        used[16 * tile_row(3 + a) + tile_row(3 + a)] = true;  // d v / d v
+    }
+    for (int w = 0; w < REC_STRIDE; ++w) {
+        const int p = dense_pos(w);
+        if (w >= REC_WE) {
+            if (p != DENSE_DUMP) return false;
+            continue;
+        }
+        if (p < 0 || p >= DENSE_DUMP || used[p]) return false;
+        used[p] = true;
+    }
+    return true;
+}
+static_assert(dense_pos_ok(), "stage-record scatter table is inconsistent");
+constexpr bool tile_row_ok() {
+    bool seen[16] = {};
+    for (int r = 0; r < 13; ++r) {
+        const int t = tile_row(r);
+        if (t < 0 || t > 15 || seen[t]) return false;
+        seen[t] = true;
+        if (r < 9 && ((t & 3) > 2 || (t >> 2) > 2)) return false;   // costed components: registers 0..2 of row-groups 0..2
+    }
+    return true;
+}
+static_assert(tile_row_ok(), "state-component permutation of the sensitivity tiles is inconsistent");
 
 }  // namespace
 

@@ -197,11 +197,17 @@ def main():
             ref = c_oracle.solve_batch(qcfg, x0[:sample], ub[:sample], stuck[:sample], xref, nthreads=cores, **kw)
             cpu_t = time.perf_counter() - t1
             err = float(np.abs(ref["u0"] - u0_gpu[:sample]).max() / 3.4)
+            # the same port on ONE host thread (small sample, ~2 s)
+            n1 = int(min(sample, 2048))
+            t1 = time.perf_counter()
+            c_oracle.solve_batch(qcfg, x0[:n1], ub[:n1], stuck[:n1], xref, nthreads=1, **kw)
+            one_t = time.perf_counter() - t1
             line["cpu_baseline"] = {"value": sample / cpu_t, "unit": "QP-steps/s", "cores": cores, "kind": "port",
                                     "sample": f"first {sample} instances of the same batch, C float64 restatement "
                                               f"(oracle/ftmpc_oracle.c), {cores} threads, {cpu_t:.1f} s; "
                                               f"reference IPOPT path not runnable offline",
-                                    "gpu_vs_port_max_u0_err_over_fmax": err}
+                                    "gpu_vs_port_max_u0_err_over_fmax": err,
+                                    "single_thread": {"value": n1 / one_t, "unit": "QP-steps/s", "sample": f"first {n1} instances, 1 thread, {one_t:.1f} s"}}
         print(json.dumps(line))
     mpc.close()
     if world > 1:

@@ -934,11 +934,6 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                     const float wv = (float)P.warmU[(inst * N + kcol[v]) * NT + t];
                     ubar[v] = fminf(fmaxf(wv, 0.f), ubv[v]);
                 }
-                // input-cost gradient of the column's own stage: Da[:, a]' (R .* ut_k)
-                float gr = 0.f;
-#pragma unroll
-                for (int g = 0; g < 6; ++g) gr += s_Da[g * MAX_NT + acol[v]] * (float)recg[kcol[v] * REC_STRIDE + REC_RUT + g];
-                gacc[v] = gr;
             }
         }
         // the sensitivity G = d c_{k+1} / d U as accumulator tiles: G[X] reg s of lane (q, col) is row 4q+s
@@ -986,6 +981,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
             float we[3];
 #pragma unroll
             for (int s3 = 0; s3 < 3; ++s3) we[s3] = (lq < 3) ? rb[REC_WE + 3 * s3 + lq] : 0.f;
+            const float rut0 = rb[REC_RUT + lq], rut1 = (lq < 2) ? rb[REC_RUT + 4 + lq] : 0.f;
             const int Imax = ((k + 1) * na - 1) >> 4;
             const int Xnew = (k * na) >> 4;
             float E[NB][3];
@@ -996,8 +992,10 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                     f32x4 o = zero4;
                     if (X >= Xnew) {
                         const bool mine = (kX[X] == k);
-                        o = mfma4(b0, mine ? DaB[X][0] : 0.f, o);
-                        o = mfma4(b1, mine ? DaB[X][1] : 0.f, o);
+                        const float d0 = mine ? DaB[X][0] : 0.f, d1 = mine ? DaB[X][1] : 0.f;
+                        o = mfma4(b0, d0, o);
+                        o = mfma4(b1, d1, o);
+                        gpart[X] += d0 * rut0 + d1 * rut1;   // input-cost gradient of the new columns, Da[:, a]' (R .* ut_k): rows g = lq, 4+lq
                     }
                     o = mfma4(a4.x, G[X].x, o);
                     o = mfma4(a4.y, G[X].y, o);

@@ -673,9 +673,10 @@ int ftmpc_simulate_batch(ftmpc_handle* h, int64_t B, int32_t T, double* x, const
 /* diagnostic build only: copies the per-instance phase cycle totals (12 u64 per instance, first
  * `count` <= 4096 instances) of the last fp32 solve */
 int ftmpc_debug_read_stamps(ftmpc_handle* h, int64_t count, unsigned long long* out) {
-    if (!h || !out || count < 0 || count > 4096 || !h->d_dbgH) return FTMPC_ERR_ARG;
+    const void* src = h ? (h->use_f64 ? (const void*)h->d_dbgH64 : (const void*)h->d_dbgH) : nullptr;
+    if (!h || !out || count < 0 || count > 4096 || !src || (h->use_f64 && count > 512)) return FTMPC_ERR_ARG;
     HIP_TRY(h, hipDeviceSynchronize());
-    HIP_TRY(h, hipMemcpy(out, h->d_dbgH, (size_t)count * 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(out, src, (size_t)count * 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return FTMPC_OK;
 }
 #endif

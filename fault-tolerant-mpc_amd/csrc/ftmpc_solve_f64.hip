@@ -26,6 +26,8 @@ constexpr int WG = 256;       // threads per workgroup
 constexpr int NWAVE = 4;
 constexpr int NVT = 4;        // columns per thread (n <= 1024)
 constexpr int NMAX = WG * NVT;
+constexpr int RPF = 10;                  // block rows (columns) per wave whose tiles are prefetched in the sweeps (n <= 640)
+constexpr int RMAXW = NMAX / 16 / NWAVE;  // block rows per wave at n = 1024; rows beyond RPF load their tiles at use
 
 // operand layout of a 16x16 tile in global memory: the four k-steps a lane needs are contiguous
 __device__ __forceinline__ int t64off(int r, int c) { return 16 * r + 4 * (c & 3) + (c >> 2); }
@@ -43,6 +45,8 @@ __device__ __forceinline__ double quad_sum64(double x) {
     x += __shfl_xor(x, 32, 64);
     return x;
 }
+// barrier for exchanges that go through LDS only: does not drain the outstanding global loads
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ f64x4 mfma(double a, double b, f64x4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
@@ -81,7 +85,11 @@ __device__ __forceinline__ bool potrf_inv16_f64(const double* S, int li, double 
     for (int j = 0; j < 16; ++j) {
         const double djj = readlane_d(a[j], j);
         ok = ok && (djj > 0.0);
-        const double inv = 1.0 / sqrt(djj);
+        // 1/sqrt: hardware seed (v_rsq_f64, ~26 bits) + two Newton steps instead of the IEEE sqrt and divide
+        // sequences (~70 instructions on the serial pivot chain of the one wave everybody waits for)
+        double inv = __builtin_amdgcn_rsq(djj);
+        inv = inv * (1.5 - 0.5 * djj * inv * inv);
+        inv = inv * (1.5 - 0.5 * djj * inv * inv);
         invs[j] = inv;
         a[j] *= inv;
 #pragma unroll
@@ -114,6 +122,16 @@ struct Solve64Params {
     double* dbg_vec;      // [3*npad_max + 4]
 };
 
+// (diagnostic build only) per-phase cycle counters of wave 0, see scripts/stamps64.py
+#ifdef FTMPC_STAMPS
+#define S64_DECL unsigned long long s64_t0 = 0, s64_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define S64_START() s64_t0 = __builtin_amdgcn_s_memtime()
+#define S64(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); s64_acc[i] += t_ - s64_t0; s64_t0 = t_; } while (0)
+#else
+#define S64_DECL
+#define S64_START()
+#define S64(i)
+#endif
 __global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const DeviceConsts C, const Solve64Params Q) {
     using namespace f64k;
     const SolveParams& P = Q.base;
@@ -141,6 +159,8 @@ __global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const Devi
 
     for (int64_t inst = blockIdx.x; inst < P.B; inst += gridDim.x) {
         __syncthreads();
+        S64_DECL;
+        S64_START();
         // ---------------- prologue ----------------
         if (tid == 0) {
             int na0 = 0;
@@ -203,6 +223,7 @@ __global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const Devi
             for (int r = 0; r < 13; ++r) G[r][v] = 0.0;
         }
 
+        S64(0);
         // ---------------- phase 1: condense, E panels of every stage -> global ----------------
         for (int k = 0; k < N; ++k) {
             __syncthreads();
@@ -302,6 +323,7 @@ __global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const Devi
         }
         __syncthreads();  // E panels visible to the whole workgroup
 
+        S64(1);
         // ---------------- phase 2: H tiles on f64 MFMA (tiles round-robin over the waves) ----------------
         const int ntl = (nb * (nb + 1)) / 2;
         for (int t = wave; t < ntl; t += NWAVE) {
@@ -379,19 +401,23 @@ __global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const Devi
             }
         }
 
+        S64(2);
         // ---------------- interior-point iterations ----------------
         int status = 1, nit = 0;
         bool first = true;
         const double inv2n = 1.0 / (double)(2 * n);
         for (int it = 0; it <= C.max_iters; ++it) {
             __syncthreads();
+            // gradient H d + g by a tile mat-vec only at the start point; afterwards it follows the step through
+            // the Newton system just solved, H dd = rhs - Sigma dd (see the update at the end of the iteration)
+            if (it == 0) {
 #pragma unroll
             for (int v = 0; v < NVT; ++v) {
                 const int e = v * WG + tid;
                 if (e < npad) dv[16 * (e >> 4) + v64pos(e & 15)] = valid[v] ? ((sl[v] < su[v]) ? lo[v] + sl[v] : hi[v] - su[v]) : 0.0;
             }
             __syncthreads();
-            // gradient H d + g: block rows round-robin over the waves, result via xv
+            // block rows round-robin over the waves, result via xv
             for (int I = wave; I < nb; I += NWAVE) {
                 double a = 0.0;
                 for (int J = 0; J < nb; ++J) {
@@ -413,6 +439,7 @@ __global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const Devi
             for (int v = 0; v < NVT; ++v) {
                 const int e = v * WG + tid;
                 grad[v] = (e < npad && valid[v]) ? xv[e] + gv[v] : 0.0;
+            }
             }
             if (first) {
                 double gm = 0.0, wm = 0.0;
@@ -443,22 +470,18 @@ __global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const Devi
             }
             if (it == C.max_iters) break;
             ++nit;
-            // KKT matrix into the factor slot: L <- H, diagonal += Sigma
-            __syncthreads();
-            for (int64_t i = tid; i < (int64_t)ntl * 64; i += WG)
-                *reinterpret_cast<f64x4*>(Ls + 4 * i) = ld4(Hs + 4 * i);
+            // KKT matrix H + Sigma: the factorisation reads each Hessian tile where it needs it (no copy of the
+            // 2 KiB tiles into the factor slot); Sigma goes through LDS (dv is free between the gradient and here)
             __syncthreads();
             double Sig[NVT];
 #pragma unroll
             for (int v = 0; v < NVT; ++v) {
                 Sig[v] = valid[v] ? zl[v] / sl[v] + zu[v] / su[v] : 0.0;
                 const int e = v * WG + tid;
-                if (e < npad) {
-                    const int I = e >> 4, r = e & 15;
-                    Ls[(int64_t)t64idx(I, I) * 256 + t64off(r, r)] += Sig[v];
-                }
+                if (e < npad) dv[e] = Sig[v];
             }
             __syncthreads();
+            S64(4);
             // ---- blocked left-looking Cholesky; block rows round-robin over the waves ----
             if (tid == 0) s_flag = 1;
             for (int J = 0; J < nb; ++J) {
@@ -468,7 +491,24 @@ __global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const Devi
                     const double* rowI = Ls + (int64_t)t64idx(I, 0) * 256 + 16 * li + 4 * lq;
                     const double* rowJ = Ls + (int64_t)t64idx(J, 0) * 256 + 16 * li + 4 * lq;
                     int K = 0;
-                    for (; K + 1 < J; K += 2) {   // two tile pairs in flight
+                    // the tiles come from L2 (~800 cycles): four tile pairs in flight, two accumulators
+                    f64x4 acc2 = {0.0, 0.0, 0.0, 0.0};
+                    for (; K + 3 < J; K += 4) {
+                        const f64x4 a0 = ld4(rowI + K * 256), b0 = ld4(rowJ + K * 256);
+                        const f64x4 a1 = ld4(rowI + (K + 1) * 256), b1 = ld4(rowJ + (K + 1) * 256);
+                        const f64x4 a2 = ld4(rowI + (K + 2) * 256), b2 = ld4(rowJ + (K + 2) * 256);
+                        const f64x4 a3 = ld4(rowI + (K + 3) * 256), b3 = ld4(rowJ + (K + 3) * 256);
+                        acc = mfma(a0.x, b0.x, acc); acc2 = mfma(a1.x, b1.x, acc2);
+                        acc = mfma(a0.y, b0.y, acc); acc2 = mfma(a1.y, b1.y, acc2);
+                        acc = mfma(a0.z, b0.z, acc); acc2 = mfma(a1.z, b1.z, acc2);
+                        acc = mfma(a0.w, b0.w, acc); acc2 = mfma(a1.w, b1.w, acc2);
+                        acc = mfma(a2.x, b2.x, acc); acc2 = mfma(a3.x, b3.x, acc2);
+                        acc = mfma(a2.y, b2.y, acc); acc2 = mfma(a3.y, b3.y, acc2);
+                        acc = mfma(a2.z, b2.z, acc); acc2 = mfma(a3.z, b3.z, acc2);
+                        acc = mfma(a2.w, b2.w, acc); acc2 = mfma(a3.w, b3.w, acc2);
+                    }
+                    acc += acc2;
+                    for (; K + 1 < J; K += 2) {
                         const f64x4 a0 = ld4(rowI + K * 256), b0 = ld4(rowJ + K * 256);
                         const f64x4 a1 = ld4(rowI + (K + 1) * 256), b1 = ld4(rowJ + (K + 1) * 256);
                         acc = mfma(a0.x, b0.x, acc); acc = mfma(a0.y, b0.y, acc);
@@ -482,12 +522,17 @@ __global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const Devi
                         acc = mfma(a0.z, b0.z, acc); acc = mfma(a0.w, b0.w, acc);
                     }
                     double* tij = Ls + (int64_t)t64idx(I, J) * 256;
+                    const double* hij = Hs + (int64_t)t64idx(I, J) * 256;
                     double c[4];
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) c[rr] = tij[t64off(lq + 4 * rr, li)] - acc[rr];
+                    for (int rr = 0; rr < 4; ++rr) c[rr] = hij[t64off(lq + 4 * rr, li)] - acc[rr];
                     if (I == J) {   // wave 0 only (I = J + wave)
+                        const double sg = dv[16 * J + li];
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) Sbuf[(lq + 4 * rr) * 17 + li] = c[rr];
+                        for (int rr = 0; rr < 4; ++rr) {
+                            if (lq + 4 * rr == li) c[rr] += sg;
+                            Sbuf[(lq + 4 * rr) * 17 + li] = c[rr];
+                        }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         __builtin_amdgcn_wave_barrier();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -524,49 +569,127 @@ __global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const Devi
                 break;
             }
 
+            S64(5);
             // ---- two KKT solves ----
+            // Right-looking sweeps: wave w keeps the running sums of ITS block rows (forward: rows I = w mod 4;
+            // backward: columns J = w mod 4); the owner of step J finishes block J alone, publishes it in LDS and
+            // everybody folds it into their sums.  One LDS-only barrier per step (the outstanding tile loads stay
+            // in flight across it), every tile requested one step before it is needed.
             auto solve = [&]() {
                 const int myp = v64pos(li);
-                for (int J = 0; J < nb; ++J) {   // forward
-                    double p = 0.0;
-                    for (int K = wave; K < J; K += NWAVE) {
-                        const f64x4 t4 = ld4(Ls + (int64_t)t64idx(J, K) * 256 + 16 * li + 4 * lq);
-                        const double* y4 = xv + 16 * K + 4 * lq;
-                        p += t4.x * y4[0] + t4.y * y4[1] + t4.z * y4[2] + t4.w * y4[3];
+                double* rb = part + wave * 16;            // per-wave 16-vector scratch
+                f64x4 buf[RPF];                            // tiles (I, J) of this wave's rows for the current step
+                f64x4 wdiag = {0.0, 0.0, 0.0, 0.0};
+                double psum[RMAXW];
+#pragma unroll
+                for (int i = 0; i < RMAXW; ++i) psum[i] = 0.0;
+                // ---- forward: L y = b ----
+                auto fetch_f = [&](int J) {               // column J of the factor, rows I = wave + 4 i > J
+#pragma unroll
+                    for (int i = 0; i < RPF; ++i) {
+                        const int I = wave + NWAVE * i;
+                        if (I > J && I < nb) buf[i] = ld4(Ls + (int64_t)t64idx(I, J) * 256 + 16 * li + 4 * lq);
                     }
-                    p = quad_sum64(p);
-                    if (lq == 0) part[wave * 16 + li] = p;
-                    __syncthreads();
-                    if (wave == 0) {
-                        const double r = xv[16 * J + myp] - (part[li] + part[16 + li] + part[32 + li] + part[48 + li]);
-                        const f64x4 w4 = ld4(Ls + (int64_t)t64idx(J, J) * 256 + 16 * li + 4 * lq);
-                        double y = w4.x * __shfl(r, lq, 64) + w4.y * __shfl(r, 4 + lq, 64) + w4.z * __shfl(r, 8 + lq, 64) +
-                                   w4.w * __shfl(r, 12 + lq, 64);
+                };
+                if (wave == 0) wdiag = ld4(Ls + (int64_t)t64idx(0, 0) * 256 + 16 * li + 4 * lq);
+                fetch_f(0);
+                for (int J = 0; J < nb; ++J) {
+                    if (wave == (J & (NWAVE - 1))) {       // owner: r_J = b_J - sum, y_J = W_J r_J
+                        const int i = J / NWAVE;
+                        double p = 0.0;
+#pragma unroll
+                        for (int ii = 0; ii < RMAXW; ++ii) p = (ii == i) ? psum[ii] : p;
+                        const double r = xv[16 * J + myp] - quad_sum64(p);
+                        if (lq == 0) rb[li] = r;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        double y = wdiag.x * rb[lq] + wdiag.y * rb[4 + lq] + wdiag.z * rb[8 + lq] + wdiag.w * rb[12 + lq];
                         y = quad_sum64(y);
                         if (lq == 0) xv[16 * J + myp] = y;
                     }
-                    __syncthreads();
+                    lds_barrier();
+                    if (J + 1 < nb) {
+                        const double* y4 = xv + 16 * J + 4 * lq;
+                        const double y0 = y4[0], y1 = y4[1], y2 = y4[2], y3 = y4[3];
+#pragma unroll
+                        for (int i = 0; i < RPF; ++i) {
+                            const int I = wave + NWAVE * i;
+                            if (I > J && I < nb) psum[i] += buf[i].x * y0 + buf[i].y * y1 + buf[i].z * y2 + buf[i].w * y3;
+                        }
+#pragma unroll
+                        for (int i = RPF; i < RMAXW; ++i) {     // n > 640 only
+                            const int I = wave + NWAVE * i;
+                            if (I > J && I < nb) {
+                                const f64x4 t4 = ld4(Ls + (int64_t)t64idx(I, J) * 256 + 16 * li + 4 * lq);
+                                psum[i] += t4.x * y0 + t4.y * y1 + t4.z * y2 + t4.w * y3;
+                            }
+                        }
+                        fetch_f(J + 1);
+                        if (wave == ((J + 1) & (NWAVE - 1))) wdiag = ld4(Ls + (int64_t)t64idx(J + 1, J + 1) * 256 + 16 * li + 4 * lq);
+                    }
                 }
-                for (int J = nb - 1; J >= 0; --J) {   // backward
-                    double p = 0.0;
-                    for (int I = J + 1 + wave; I < nb; I += NWAVE) {
-                        const double* t = Ls + (int64_t)t64idx(I, J) * 256;
+                // ---- backward: L' x = y ----
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) p += t[t64off(4 * lq + rr, li)] * xv[16 * I + rr * 4 + lq];
+                for (int i = 0; i < RMAXW; ++i) psum[i] = 0.0;
+                auto fetch_b = [&](int I) {               // row I of the factor, columns J = wave + 4 i < I (transposed use)
+#pragma unroll
+                    for (int i = 0; i < RPF; ++i) {
+                        const int J = wave + NWAVE * i;
+                        if (J < I) {
+                            const double* t = Ls + (int64_t)t64idx(I, J) * 256;
+                            buf[i].x = t[t64off(4 * lq + 0, li)];
+                            buf[i].y = t[t64off(4 * lq + 1, li)];
+                            buf[i].z = t[t64off(4 * lq + 2, li)];
+                            buf[i].w = t[t64off(4 * lq + 3, li)];
+                        }
                     }
-                    p = quad_sum64(p);
-                    if (lq == 0) part[wave * 16 + li] = p;
-                    __syncthreads();
-                    if (wave == 0) {
-                        const double r = xv[16 * J + myp] - (part[li] + part[16 + li] + part[32 + li] + part[48 + li]);
-                        const double* t = Ls + (int64_t)t64idx(J, J) * 256;
-                        double x = 0.0;
+                };
+                auto fetch_wt = [&](int I) {
+                    const double* t = Ls + (int64_t)t64idx(I, I) * 256;
+                    wdiag.x = t[t64off(4 * lq + 0, li)];
+                    wdiag.y = t[t64off(4 * lq + 1, li)];
+                    wdiag.z = t[t64off(4 * lq + 2, li)];
+                    wdiag.w = t[t64off(4 * lq + 3, li)];
+                };
+                if (wave == ((nb - 1) & (NWAVE - 1))) fetch_wt(nb - 1);
+                fetch_b(nb - 1);
+                for (int I = nb - 1; I >= 0; --I) {
+                    if (wave == (I & (NWAVE - 1))) {       // owner: r_I = y_I - sum, x_I = W_I' r_I
+                        const int i = I / NWAVE;
+                        double p = 0.0;
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) x += t[t64off(4 * lq + rr, li)] * __shfl(r, 4 * lq + rr, 64);
+                        for (int ii = 0; ii < RMAXW; ++ii) p = (ii == i) ? psum[ii] : p;
+                        const double r = xv[16 * I + myp] - quad_sum64(p);
+                        if (lq == 0) rb[li] = r;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        double x = wdiag.x * rb[4 * lq] + wdiag.y * rb[4 * lq + 1] + wdiag.z * rb[4 * lq + 2] + wdiag.w * rb[4 * lq + 3];
                         x = quad_sum64(x);
-                        if (lq == 0) xv[16 * J + myp] = x;
+                        if (lq == 0) xv[16 * I + myp] = x;
                     }
-                    __syncthreads();
+                    lds_barrier();
+                    if (I > 0) {
+                        const double x0 = xv[16 * I + 0 * 4 + lq], x1 = xv[16 * I + 1 * 4 + lq], x2 = xv[16 * I + 2 * 4 + lq],
+                                     x3 = xv[16 * I + 3 * 4 + lq];      // x_I[4 lq + rr]
+#pragma unroll
+                        for (int i = 0; i < RPF; ++i) {
+                            const int J = wave + NWAVE * i;
+                            if (J < I) psum[i] += buf[i].x * x0 + buf[i].y * x1 + buf[i].z * x2 + buf[i].w * x3;
+                        }
+#pragma unroll
+                        for (int i = RPF; i < RMAXW; ++i) {     // n > 640 only
+                            const int J = wave + NWAVE * i;
+                            if (J < I) {
+                                const double* t = Ls + (int64_t)t64idx(I, J) * 256;
+                                psum[i] += t[t64off(4 * lq + 0, li)] * x0 + t[t64off(4 * lq + 1, li)] * x1 + t[t64off(4 * lq + 2, li)] * x2 +
+                                           t[t64off(4 * lq + 3, li)] * x3;
+                            }
+                        }
+                        fetch_b(I - 1);
+                        if (wave == ((I - 1) & (NWAVE - 1))) fetch_wt(I - 1);
+                    }
                 }
             };
 #pragma unroll
@@ -575,7 +698,9 @@ __global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const Devi
                 if (e < npad) xv[16 * (e >> 4) + v64pos(e & 15)] = -grad[v];
             }
             __syncthreads();
+            S64(7);
             solve();
+            S64(6);
             double da[NVT], dzl_a[NVT], dzu_a[NVT];
             double ap = 1.0, ad = 1.0;
 #pragma unroll
@@ -601,7 +726,7 @@ __global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const Devi
             const double mu_aff = wg_sum(t, red, tid) * inv2n;
             double sigma = mu_aff / mu;
             sigma = fmin(fmax(sigma * sigma * sigma, 0.0), 1.0);
-            double rcl[NVT], rcu[NVT];
+            double rcl[NVT], rcu[NVT], rhsv[NVT];
             __syncthreads();
 #pragma unroll
             for (int v = 0; v < NVT; ++v) {
@@ -612,11 +737,14 @@ __global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const Devi
                     rcu[v] = su[v] * zu[v] - da[v] * dzu_a[v] - sigma * mu;
                     rhs = -(grad[v] - zl[v] + zu[v]) - rcl[v] / sl[v] + rcu[v] / su[v];
                 }
+                rhsv[v] = rhs;
                 const int e = v * WG + tid;
                 if (e < npad) xv[16 * (e >> 4) + v64pos(e & 15)] = rhs;
             }
             __syncthreads();
+            S64(7);
             solve();
+            S64(6);
             double dd[NVT], dzl[NVT], dzu[NVT];
             ap = 1e300;
             ad = 1e300;
@@ -639,6 +767,7 @@ __global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const Devi
 #pragma unroll
             for (int v = 0; v < NVT; ++v)
                 if (valid[v]) {
+                    grad[v] += ap * (rhsv[v] - Sig[v] * dd[v]);   // + ap H dd
                     sl[v] += ap * dd[v];
                     su[v] -= ap * dd[v];
                     zl[v] += ad * dzl[v];
@@ -646,6 +775,7 @@ __global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const Devi
                 }
         }
 
+        S64(7);
         // ---------------- outputs ----------------
         __syncthreads();
         double* ubuf = dv;  // N*NT <= 1024 doubles
@@ -666,6 +796,13 @@ __global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const Devi
             if (P.status) P.status[inst] = status;
             if (P.iters) P.iters[inst] = nit;
         }
+        S64(9);
+#ifdef FTMPC_STAMPS
+        if (tid == 0 && inst < 512 && Q.dbg_H) {
+            unsigned long long* sb = reinterpret_cast<unsigned long long*>(Q.dbg_H) + inst * 12;
+            for (int i = 0; i < 12; ++i) sb[i] = s64_acc[i];
+        }
+#endif
     }
 }
 

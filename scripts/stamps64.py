@@ -1,0 +1,23 @@
+"""Diagnostic: per-phase cycle shares of the float64 solve kernel (stamps build, wave 0 of each workgroup)."""
+import sys, ctypes as C, os
+sys.path.insert(0,'/root/repo/fault-tolerant-mpc_amd'); sys.path.insert(0,'/root/repo')
+import numpy as np
+from pathlib import Path
+from ft_mpc_amd import _lib
+_lib._SO = Path(os.environ["FTMPC_LIB"]) if os.environ.get("FTMPC_LIB") else _lib._HERE / "libftmpc_hip_stamps.so"
+import ft_mpc_amd
+N=int(sys.argv[1]) if len(sys.argv)>1 else 15
+NT=int(sys.argv[2]) if len(sys.argv)>2 else 16
+B=int(sys.argv[3]) if len(sys.argv)>3 else 512
+mpc=ft_mpc_amd.BatchedMPC(N=N,NT=NT,dtype="f64",max_iters=40)
+x0,ub,stuck,xref=ft_mpc_amd.make_synthetic_batch(B,N,NT,2,1003)
+out=mpc.solve(x0,ub,stuck,xref.reshape(-1,order='F'))
+cnt=min(B,512)
+buf=np.zeros((cnt,12),np.uint64)
+f=mpc.lib.ftmpc_debug_read_stamps; f.argtypes=[C.c_void_p,C.c_int64,C.c_void_p]
+assert f(mpc._h,cnt,buf.ctypes.data_as(C.c_void_p))==0
+names=["prologue","phase1: E panels","phase2: H tiles","x3","gradient+mu","chol","solves(2)","elementwise","x8","output","x10","x11"]
+m=buf.astype(np.float64).mean(axis=0); tot=m.sum(); it=out['iters'].mean()
+print("N=%d NT=%d B=%d iters mean %.2f   total ticks/QP %.0f"%(N,NT,B,it,tot))
+for n_,v in zip(names,m):
+    if n_: print("  %-18s %10.0f  %5.1f%%   per-iter %8.0f"%(n_,v,100*v/tot,v/it))

@@ -1,0 +1,216 @@
+// ftmpc_alloc.hip -- batched thruster allocation, the reference's second stage
+// (ControlAllocator.get_physical_input, ft_mpc/controllers/tools/control_allocator.py:27-40,65-94):
+//     min |u|^2   s.t.  D u = tau,  0 <= u <= ub          (NT <= 16 thrusters, 6 wrench components)
+// The thruster-space MPC path does not need it (its QP has the allocation inside); it is the
+// standalone operator for callers that, like the reference, hold a generalized force.
+//
+// One LANE per instance, float64.  Dual form: u(lambda) = clip(D' lambda, 0, ub), and lambda is
+// the minimiser of the convex piecewise-quadratic dual
+//     q(lambda) = sum_i [ v_i u_i - u_i^2 / 2 ] - lambda' tau,   v = D' lambda,   grad q = D u(lambda) - tau,
+// found by a semismooth Newton method (generalised Hessian D_A D_A', A = thrusters strictly inside their
+// bounds) with Armijo backtracking on q.  The dual is piecewise quadratic, so the iteration terminates
+// in a handful of steps; an infeasible request (tau outside the attainable set) leaves a residual
+// and is reported per instance (the reference prints and exit()s, control_allocator.py:88-93).
+#include <hip/hip_runtime.h>
+
+#include "ftmpc_common.h"
+
+namespace ftmpc {
+
+struct AllocParams {
+    int64_t B;
+    const double* tau;   // [B*6]
+    const double* ub;    // [B*NT]  0 for a broken thruster
+    double* out_u;       // [B*NT]
+    int32_t* status;     // [B] or nullptr: 0 solved, 1 iteration cap, 2 infeasible (residual left)
+    int32_t* iters;      // [B] or nullptr
+    int32_t max_iters;
+    double tol;          // |D u - tau|_inf <= tol (1 + |tau|_inf)
+};
+
+namespace {
+
+__device__ inline double alloc_dual(const DeviceConsts& C, int NT, const double lam[6], const double tau[6], const double* ubv,
+                                    double u[MAX_NT], double F[6]) {
+    double q = 0.0;
+#pragma unroll
+    for (int g = 0; g < 6; ++g) F[g] = -tau[g];
+#pragma unroll
+    for (int i = 0; i < MAX_NT; ++i) {
+        u[i] = 0.0;
+        if (i < NT) {
+            double v = 0.0;
+#pragma unroll
+            for (int g = 0; g < 6; ++g) v += C.D[g * MAX_NT + i] * lam[g];
+            const double ui = fmin(fmax(v, 0.0), ubv[i]);
+            u[i] = ui;
+            q += v * ui - 0.5 * ui * ui;
+#pragma unroll
+            for (int g = 0; g < 6; ++g) F[g] += C.D[g * MAX_NT + i] * ui;
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 6; ++g) q -= lam[g] * tau[g];
+    return q;
+}
+
+// solves (J + delta I) x = b for the symmetric positive semi-definite 6x6 J (Cholesky, in place)
+__device__ inline void solve6(double J[6][6], const double b[6], double x[6]) {
+    double tr = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) tr += J[i][i];
+    const double delta = 1e-12 * tr + 1e-300;
+    double L[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double d = J[j][j] + delta;
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k < j) d -= L[j][k] * L[j][k];
+        d = fmax(d, delta);
+        const double inv = 1.0 / sqrt(d);
+        L[j][j] = d * inv;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            if (i > j) {
+                double s = J[i][j];
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if (k < j) s -= L[i][k] * L[j][k];
+                L[i][j] = s * inv;
+            }
+    }
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double s = b[i];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k < i) s -= L[i][k] * y[k];
+        y[i] = s / L[i][i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double s = y[i];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k > i) s -= L[k][i] * x[k];
+        x[i] = s / L[i][i];
+    }
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(64) ftmpc_allocate_kernel(const DeviceConsts C, const AllocParams P) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= P.B) return;
+    const int NT = C.NT;
+    double tau[6], ubv[MAX_NT];
+    double tmax = 0.0;
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+        tau[g] = P.tau[b * 6 + g];
+        tmax = fmax(tmax, fabs(tau[g]));
+    }
+#pragma unroll
+    for (int i = 0; i < MAX_NT; ++i) ubv[i] = (i < NT) ? P.ub[b * NT + i] : 0.0;
+    // start: unconstrained least-norm multiplier (D D') lambda = tau over the healthy thrusters
+    double lam[6], u[MAX_NT], F[6];
+    {
+        double J[6][6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                double s = 0.0;
+#pragma unroll
+                for (int i = 0; i < MAX_NT; ++i)
+                    if (i < NT && ubv[i] > 0.0) s += C.D[r * MAX_NT + i] * C.D[c * MAX_NT + i];
+                J[r][c] = s;
+            }
+        solve6(J, tau, lam);
+    }
+    double q = alloc_dual(C, NT, lam, tau, ubv, u, F);
+    const double tol = P.tol * (1.0 + tmax);
+    int status = 1, it = 0;
+    for (; it < P.max_iters; ++it) {
+        double fmaxabs = 0.0;
+#pragma unroll
+        for (int g = 0; g < 6; ++g) fmaxabs = fmax(fmaxabs, fabs(F[g]));
+        if (fmaxabs <= tol) {
+            status = 0;
+            break;
+        }
+        // an unattainable tau makes the dual unbounded below: the multiplier runs away
+        double lmax = 0.0;
+#pragma unroll
+        for (int g = 0; g < 6; ++g) lmax = fmax(lmax, fabs(lam[g]));
+        if (lmax > 1e9 * (1.0 + tmax)) {
+            status = 2;
+            break;
+        }
+        // generalised Hessian over the thrusters strictly inside their bounds
+        double J[6][6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) J[r][c] = 0.0;
+#pragma unroll
+        for (int i = 0; i < MAX_NT; ++i)
+            if (i < NT && u[i] > 0.0 && u[i] < ubv[i]) {
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) J[r][c] += C.D[r * MAX_NT + i] * C.D[c * MAX_NT + i];
+            }
+        double nF[6], dl[6];
+#pragma unroll
+        for (int g = 0; g < 6; ++g) nF[g] = -F[g];
+        solve6(J, nF, dl);
+        double slope = 0.0;
+#pragma unroll
+        for (int g = 0; g < 6; ++g) slope += F[g] * dl[g];
+        if (!(slope < 0.0)) {   // no descent along the Newton direction: steepest descent
+#pragma unroll
+            for (int g = 0; g < 6; ++g) dl[g] = -F[g];
+            slope = 0.0;
+#pragma unroll
+            for (int g = 0; g < 6; ++g) slope -= F[g] * F[g];
+        }
+        double t = 1.0;
+        double ln[6], un[MAX_NT], Fn[6], qn = q;
+        bool moved = false;
+        for (int ls = 0; ls < 40; ++ls) {
+#pragma unroll
+            for (int g = 0; g < 6; ++g) ln[g] = lam[g] + t * dl[g];
+            qn = alloc_dual(C, NT, ln, tau, ubv, un, Fn);
+            if (qn <= q + 1e-4 * t * slope) {
+                moved = true;
+                break;
+            }
+            t *= 0.5;
+        }
+        if (!moved) break;   // stationary for the line search: the residual that is left is infeasibility
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            lam[g] = ln[g];
+            F[g] = Fn[g];
+        }
+#pragma unroll
+        for (int i = 0; i < MAX_NT; ++i) u[i] = un[i];
+        q = qn;
+    }
+    if (status == 1) {
+        double fmaxabs = 0.0;
+#pragma unroll
+        for (int g = 0; g < 6; ++g) fmaxabs = fmax(fmaxabs, fabs(F[g]));
+        status = (fmaxabs <= tol) ? 0 : (it >= P.max_iters ? 1 : 2);
+    }
+#pragma unroll
+    for (int i = 0; i < MAX_NT; ++i)
+        if (i < NT) P.out_u[b * NT + i] = u[i];
+    if (P.status) P.status[b] = status;
+    if (P.iters) P.iters[b] = it;
+}
+
+}  // namespace ftmpc

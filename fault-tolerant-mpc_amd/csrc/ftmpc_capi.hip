@@ -24,6 +24,7 @@
 #include "ftmpc_solve.hip"
 #include "ftmpc_solve_f64.hip"
 #include "ftmpc_sim.hip"
+#include "ftmpc_alloc.hip"
 
 using ftmpc::DeviceConsts;
 using ftmpc::LinParams;
@@ -47,6 +48,10 @@ struct ftmpc_handle {
     double *d_x0 = nullptr, *d_ub = nullptr, *d_stuck = nullptr, *d_xref = nullptr, *d_uref = nullptr;
     double *d_warm = nullptr, *d_u0 = nullptr, *d_U = nullptr;
     int32_t *d_status = nullptr, *d_iters = nullptr;
+    // allocation operator (ftmpc_allocate_batch)
+    double *d_atau = nullptr, *d_aub = nullptr, *d_au = nullptr;
+    int32_t *d_ast = nullptr, *d_ait = nullptr;
+    int64_t cap_alloc = 0;
     int64_t cap_xref = 0, cap_uref = 0;
     // per-instantiation Hessian slots
     float* hs[3] = {nullptr, nullptr, nullptr};   // NB = 8, 9, 10 instantiations
@@ -392,7 +397,8 @@ int ftmpc_destroy(ftmpc_handle* h) {
     if (!h) return FTMPC_OK;
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->rec, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, h->d_uref, h->d_warm, h->d_u0, h->d_U,
-                    h->d_status, h->d_iters, h->hs[0], h->hs[1], h->hs[2], h->d_dbgH, h->d_dbgv, h->Hs, h->Ls, h->Eall, h->d_dbgH64, h->d_dbgv64};
+                    h->d_status, h->d_iters, h->hs[0], h->hs[1], h->hs[2], h->d_dbgH, h->d_dbgv, h->Hs, h->Ls, h->Eall, h->d_dbgH64, h->d_dbgv64,
+                    h->d_atau, h->d_aub, h->d_au, h->d_ast, h->d_ait};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < 10; ++i)
@@ -503,6 +509,42 @@ int ftmpc_solve_batch_device(ftmpc_handle* h, int64_t B, const double* x0, const
     }
     return enqueue(h, B, x0, ub, stuck, xref, xref_stride, uref, uref_stride, warmU, out_u0, out_U, status, iters,
                    reinterpret_cast<hipStream_t>(stream), -1);
+}
+
+int ftmpc_allocate_batch(ftmpc_handle* h, int64_t B, const double* tau, const double* ub, double* out_u, int32_t* status,
+                         int32_t* iters) {
+    if (!h) return FTMPC_ERR_ARG;
+    if (B < 0 || !tau || !ub || !out_u) return fail(h, FTMPC_ERR_ARG, "null buffer or negative batch");
+    if (B == 0) return FTMPC_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int NT = h->cfg.NT;
+    if (B > h->cap_alloc) {
+        int rc;
+        if ((rc = grow(h, &h->d_atau, B * 6)) != FTMPC_OK || (rc = grow(h, &h->d_aub, B * NT)) != FTMPC_OK ||
+            (rc = grow(h, &h->d_au, B * NT)) != FTMPC_OK || (rc = grow(h, &h->d_ast, B)) != FTMPC_OK ||
+            (rc = grow(h, &h->d_ait, B)) != FTMPC_OK)
+            return rc;
+        h->cap_alloc = B;
+    }
+    hipStream_t s = h->stream;
+    HIP_TRY(h, hipMemcpyAsync(h->d_atau, tau, B * 6 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_aub, ub, B * NT * sizeof(double), hipMemcpyHostToDevice, s));
+    ftmpc::AllocParams ap;
+    ap.B = B;
+    ap.tau = h->d_atau;
+    ap.ub = h->d_aub;
+    ap.out_u = h->d_au;
+    ap.status = h->d_ast;
+    ap.iters = h->d_ait;
+    ap.max_iters = 50;
+    ap.tol = 1e-8;
+    hipLaunchKernelGGL(ftmpc::ftmpc_allocate_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, h->dc, ap);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(out_u, h->d_au, B * NT * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (status) HIP_TRY(h, hipMemcpyAsync(status, h->d_ast, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (iters) HIP_TRY(h, hipMemcpyAsync(iters, h->d_ait, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return FTMPC_OK;
 }
 
 int ftmpc_shift_warm(int64_t B, int32_t N, int32_t NT, double* warmU) {

@@ -19,7 +19,7 @@ MAX_NT = 16
 # every symbol include/ftmpc.h declares (tests check the list against the header)
 SYMBOLS = (
     "ftmpc_default_config", "ftmpc_create", "ftmpc_destroy", "ftmpc_last_error", "ftmpc_reserve",
-    "ftmpc_solve_batch", "ftmpc_solve_batch_device", "ftmpc_simulate_batch", "ftmpc_shift_warm", "ftmpc_set_profiling",
+    "ftmpc_solve_batch", "ftmpc_solve_batch_device", "ftmpc_simulate_batch", "ftmpc_allocate_batch", "ftmpc_shift_warm", "ftmpc_set_profiling",
     "ftmpc_last_kernel_ms", "ftmpc_kernel_name", "ftmpc_debug_build_qp", "ftmpc_version",
 )
 
@@ -78,6 +78,7 @@ def load_library() -> C.CDLL:
     lib.ftmpc_solve_batch.argtypes = [vp, C.c_int64, dp, dp, dp, dp, C.c_int64, dp, C.c_int64, dp, dp, dp, ip, ip]
     lib.ftmpc_solve_batch_device.argtypes = [vp, C.c_int64, vp, vp, vp, vp, C.c_int64, vp, C.c_int64, vp, vp, vp, vp, vp, vp]
     lib.ftmpc_simulate_batch.argtypes = [vp, C.c_int64, C.c_int32, dp, dp, dp, dp, dp, dp, C.c_uint64, dp, ip]
+    lib.ftmpc_allocate_batch.argtypes = [vp, C.c_int64, dp, dp, dp, ip, ip]
     lib.ftmpc_shift_warm.argtypes = [C.c_int64, C.c_int32, C.c_int32, dp]
     lib.ftmpc_set_profiling.argtypes = [vp, C.c_int32]
     lib.ftmpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]

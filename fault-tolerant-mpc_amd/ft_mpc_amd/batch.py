@@ -191,6 +191,22 @@ class BatchedMPC:
                                                   _ptr(nz), C.c_uint64(int(seed)), _ptr(uh), _ptr(bad, C.c_int32)))
         return dict(x=x, u=uh, not_converged=bad)
 
+    # -- standalone thruster allocation (ControlAllocator.get_physical_input, batched) ---------
+    def allocate(self, tau, ub):
+        """min |u|^2 s.t. D u = tau, 0 <= u <= ub for B generalized forces tau [B,6] (reference:
+        controllers/tools/control_allocator.py:27-40,65-94).  Returns dict(u [B,NT], status [B], iters [B]);
+        status 2 = tau not attainable with these bounds (the reference exit()s there)."""
+        NT = self.cfg.NT
+        tau = _f64(tau).reshape(-1, 6)
+        B = tau.shape[0]
+        ub = _f64(ub, (B, NT))
+        u = np.empty((B, NT))
+        status = np.zeros(B, np.int32)
+        iters = np.zeros(B, np.int32)
+        self._check(self.lib.ftmpc_allocate_batch(self._h, B, _ptr(tau), _ptr(ub), _ptr(u), _ptr(status, C.c_int32),
+                                                  _ptr(iters, C.c_int32)))
+        return dict(u=u, status=status, iters=iters)
+
     # -- device-pointer path (HBM-resident inputs; used by bench.py with torch tensors) --
     def solve_device(self, B, x0, ub, stuck, xref, xref_stride, uref, uref_stride, warmU, out_u0, out_U,
                      status, iters, stream=0):

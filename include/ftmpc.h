@@ -135,6 +135,25 @@ int ftmpc_solve_batch_device(ftmpc_handle* h, int64_t B,
                              int32_t* status, int32_t* iters,
                              void* stream);
 
+/*
+ * Batched thruster allocation: the reference's second stage,
+ * ControlAllocator.get_physical_input (ft_mpc/controllers/tools/control_allocator.py:27-40,65-94):
+ *     min |u|^2   s.t.  D u = tau,  0 <= u <= ub
+ * with the handle's D (6 x NT).  The thruster-space MPC step does not call it (its QP allocates
+ * inside); it serves callers that hold a generalized force, as the reference's controller does.
+ * HOST buffers.
+ *   tau     [B*6]    generalized force to realise with the healthy thrusters (the reference passes
+ *                    u_des, i.e. the controller output with the faulty wrench already removed)
+ *   ub      [B*NT]   upper bounds, 0 for a broken thruster (u_ub_physical, sys_model.py:237-240)
+ *   out_u   [B*NT]   thruster forces
+ *   status  NULL or [B]: 0 solved (|D u - tau|_inf <= 1e-8 (1 + |tau|_inf)), 1 iteration cap,
+ *                    2 tau not attainable (least-residual u returned; the reference prints and
+ *                    exit()s here, control_allocator.py:88-93)
+ *   iters   NULL or [B]: Newton steps taken
+ */
+int ftmpc_allocate_batch(ftmpc_handle* h, int64_t B, const double* tau, const double* ub,
+                         double* out_u, int32_t* status, int32_t* iters);
+
 /* Shifts a [B*N*NT] host warm-start buffer by one stage in place, zero-filling the last
  * stage (spiraling_mpc.py:327-329). */
 int ftmpc_shift_warm(int64_t B, int32_t N, int32_t NT, double* warmU);

@@ -1,0 +1,77 @@
+"""TEST INFRASTRUCTURE -- float64 NumPy restatement of the thruster allocation
+    min |u|^2  s.t.  D u = tau,  0 <= u <= ub
+(reference: ft_mpc/controllers/tools/control_allocator.py:27-40,65-94, solved there by cvxpy/OSQP).
+Only tests/ load this.  `allocate` is the same dual semismooth Newton as
+fault-tolerant-mpc_amd/csrc/ftmpc_alloc.hip; `allocate_slsqp` is an independent solver (SciPy SLSQP
+on the primal) used to pin it, and `kkt_residual` certifies a solution without any solver.
+"""
+import numpy as np
+
+
+def _dual(D, lam, tau, ub):
+    v = D.T @ lam
+    u = np.clip(v, 0.0, ub)
+    return float(v @ u - 0.5 * u @ u - lam @ tau), u, D @ u - tau
+
+
+def allocate(D, tau, ub, max_iters=50, tol=1e-8, return_lambda=False):
+    """Returns (u, status, iters[, lambda]): status 0 solved, 1 iteration cap, 2 tau not attainable."""
+    D = np.asarray(D, float)
+    tau = np.asarray(tau, float)
+    ub = np.asarray(ub, float)
+    healthy = ub > 0
+    J0 = D[:, healthy] @ D[:, healthy].T
+    lam = np.linalg.solve(J0 + (1e-12 * np.trace(J0) + 1e-300) * np.eye(6), tau)
+    q, u, F = _dual(D, lam, tau, ub)
+    thr = tol * (1.0 + np.abs(tau).max())
+    status, it = 1, 0
+    for it in range(max_iters):
+        fn = np.abs(F).max()
+        if fn <= thr:
+            status = 0
+            break
+        # an unattainable tau makes the dual unbounded below: the multiplier runs away
+        if np.abs(lam).max() > 1e9 * (1.0 + np.abs(tau).max()):
+            status = 2
+            break
+        A = (u > 0) & (u < ub)
+        J = D[:, A] @ D[:, A].T
+        dl = np.linalg.solve(J + (1e-12 * np.trace(J) + 1e-300) * np.eye(6), -F)
+        slope = float(F @ dl)
+        if not slope < 0:
+            dl = -F
+            slope = -float(F @ F)
+        t, moved = 1.0, False
+        for _ in range(40):
+            qn, un, Fn = _dual(D, lam + t * dl, tau, ub)
+            if qn <= q + 1e-4 * t * slope:
+                moved = True
+                break
+            t *= 0.5
+        if not moved:
+            break
+        lam, q, u, F = lam + t * dl, qn, un, Fn
+    else:
+        it = max_iters
+    if status == 1:
+        status = 0 if np.abs(F).max() <= thr else (1 if it >= max_iters else 2)
+    return (u, status, it, lam) if return_lambda else (u, status, it)
+
+
+def allocate_slsqp(D, tau, ub):
+    from scipy.optimize import minimize
+    D = np.asarray(D, float)
+    nt = D.shape[1]
+    res = minimize(lambda u: float(u @ u), np.clip(np.linalg.pinv(D) @ tau, 0, ub), jac=lambda u: 2 * u,
+                   bounds=[(0.0, float(b)) for b in ub], constraints=[{"type": "eq", "fun": lambda u: D @ u - tau, "jac": lambda u: D}],
+                   method="SLSQP", options={"ftol": 1e-12, "maxiter": 500})
+    return res.x, res.success
+
+
+def kkt_residual(D, tau, ub, u, lam):
+    """KKT certificate with the multiplier lambda of D u = tau: primal feasibility and
+    u = clip(D' lambda, 0, ub) (stationarity + complementarity of the bound multipliers in one)."""
+    D = np.asarray(D, float)
+    prim = max(np.abs(D @ u - tau).max(), (-u).max(), (u - ub).max(), 0.0)
+    stat = np.abs(np.clip(D.T @ lam, 0.0, ub) - u).max()
+    return max(prim, stat)

@@ -343,6 +343,30 @@ struct SchurWork {
     }
 };
 
+// Four row sums at once, written out: left to the compiler the DPP adds of neighbouring registers are
+// paired into v_pk_add_f32, which cannot take a DPP operand, so every step becomes two v_mov_b32_dpp, a
+// packed add and the moves that assemble the pairs (~3x the instructions).  Round-robin over the four
+// registers: the 2 wait states a DPP read needs after a VALU write are filled by the other three adds.
+__device__ __forceinline__ void row_sum16x4(float& a, float& b, float& c, float& d) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_ror:1 row_mask:0xf bank_mask:0xf"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
 // sum over the 16 lanes of a DPP row, result in every lane of the row
 __device__ __forceinline__ float row_sum16(float x) {
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));  // row_ror:8
@@ -435,8 +459,11 @@ __device__ __forceinline__ void solve_reg(const f32x4 (&T)[NB * (NB + 1) / 2], c
     for (int J = 0; J < NB; ++J) {
         float r = xv[16 * J + li];
         if (J > 0) r -= quad_sum(p[J].x + p[J].y);
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) Y[J][s4] = row_sum16(Wd[J][s4] * r);
+        {
+            float y0 = Wd[J].x * r, y1 = Wd[J].y * r, y2 = Wd[J].z * r, y3 = Wd[J].w * r;
+            row_sum16x4(y0, y1, y2, y3);
+            Y[J] = f32x4{y0, y1, y2, y3};
+        }
 #pragma unroll
         for (int I = J + 1; I < NB; ++I) {
             const f32x4& t = T[tidx(I, J)];
@@ -452,10 +479,9 @@ __device__ __forceinline__ void solve_reg(const f32x4 (&T)[NB * (NB + 1) / 2], c
     for (int J = NB - 1; J >= 0; --J) {
         f32x4 r = Y[J];
         if (J < NB - 1) {
-            r.x -= row_sum16(a0[J].x);
-            r.y -= row_sum16(a0[J].y);
-            r.z -= row_sum16(a1[J].x);
-            r.w -= row_sum16(a1[J].y);
+            float s0 = a0[J].x, s1 = a0[J].y, s2 = a1[J].x, s3 = a1[J].y;
+            row_sum16x4(s0, s1, s2, s3);
+            r -= f32x4{s0, s1, s2, s3};
         }
         const f32x2 d2 = f32x2{Wd[J].x, Wd[J].y} * f32x2{r.x, r.y} + f32x2{Wd[J].z, Wd[J].w} * f32x2{r.z, r.w};
         const float xr = quad_sum(d2.x + d2.y);
@@ -1230,9 +1256,9 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 wave_lds_fence();
 #pragma unroll
                 for (int J = 0; J < NB; ++J) {
-                    f32x4 c4;
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) c4[rr] = row_sum16(acol[J][rr]);
+                    float c0 = acol[J].x, c1 = acol[J].y, c2 = acol[J].z, c3 = acol[J].w;
+                    row_sum16x4(c0, c1, c2, c3);
+                    const f32x4 c4 = {c0, c1, c2, c3};
                     if (li == 0) *reinterpret_cast<f32x4*>(xvp + 16 * J + 4 * lq) = c4;
                 }
                 wave_lds_fence();

@@ -984,11 +984,39 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
 #pragma unroll
         for (int t = 0; t < NTILES; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+        // finish tile (I,J): + 2 (Da' R Da + rho I) on the blocks of equal stage, unit pad diagonal, then -H to the tile store,
+        // each tile exactly as its lanes hold it (one b128 per lane, conflict free): the factorisation loads a tile STRAIGHT
+        // INTO the MFMA accumulator that collects the Schur terms (sum T'T - H), so no VALU instruction touches it.
+        auto finish_tile = [&](int I, int J) {     // I, J are constants after unrolling
+            f32x4 h = acc[(I * (I + 1)) / 2 + J];
+            if (J >= I - 1) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    // register rr of lane (lq, li): H[16I + 4lq+rr][16I + li] on the diagonal, H[16I + li][16J + 4lq+rr] below it
+                    const int e1 = (I == J) ? 16 * I + 4 * lq + rr : 16 * I + li;
+                    const int e2 = (I == J) ? 16 * J + li : 16 * J + 4 * lq + rr;
+                    const int s1 = s_stg[e1], a1 = s_thr[e1];
+                    const int s2 = s_stg[e2], a2 = s_thr[e2];
+                    float add = 0.f;
+                    if (s1 != 255 && s1 == s2) {
+#pragma unroll
+                        for (int g = 0; g < 6; ++g) add += s_Da[g * MAX_NT + a1] * Rf[g] * s_Da[g * MAX_NT + a2];
+                        if (a1 == a2) add += rho;
+                        add *= 2.f;
+                    }
+                    if (s1 == 255 && e1 == e2) add = 1.f;
+                    h[rr] += add;
+                }
+            }
+            htiles.st((I * (I + 1)) / 2 + J, lane, -h);
+        };
+
         STAMP(0);
         // ---------------- build: stage loop (everything on the matrix cores) ----------------
         //   G_X <- A_k G_X (+ B_k Da on the columns of stage k),  E_X = sqrt(2W) G_X (rows 0..8),
         //   acc(I,J) += E_I' E_J,   g += G' W e_k
-        for (int k = 0; k < N; ++k) {
+        auto stage = [&](int k, auto TERM) {
+            constexpr bool terminal = decltype(TERM)::value;
             float* rb = recbuf + (k & 1) * REC_STRIDE;
             float* dd = dense + (k & 1) * DENSE_WORDS;
             if (lane < REC_STRIDE / 4) {
@@ -998,10 +1026,9 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 dd[dpos[1]] = pre.y;
                 dd[dpos[2]] = pre.z;
                 dd[dpos[3]] = pre.w;
-                if (k + 1 < N) pre64 = *reinterpret_cast<const f64x4_t*>(recg + (k + 1) * REC_STRIDE + 4 * lane);
+                if (!terminal) pre64 = *reinterpret_cast<const f64x4_t*>(recg + (k + 1) * REC_STRIDE + 4 * lane);
             }
             wave_lds_fence();
-            const bool terminal = (k + 1 == N);
             const f32x4 a4 = lds4(dd + 16 * li + 4 * lq);
             const float b0 = dd[256 + 8 * li + lq], b1 = dd[256 + 8 * li + 4 + lq];
             float we[3];
@@ -1057,10 +1084,23 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                         // tile (I,J) is kept TRANSPOSED, (H_IJ)' = E_J' E_I: the layout the factorisation consumes
 #pragma unroll
                         for (int s3 = 0; s3 < 3; ++s3) acc[(I * (I + 1)) / 2 + J] = mfma4(E[J][s3], E[I][s3], acc[(I * (I + 1)) / 2 + J]);
+                        // last stage (peeled copy of the stage code): the tile is complete -- finish and store it right
+                        // here, so that its accumulator dies now; finishing all 36 after the loop keeps them live across
+                        // that code and costs ~50 scratch round trips
+                        if constexpr (terminal) finish_tile(I, J);
                     }
                 }
             STAMP(2);
-        }
+        };
+        for (int k = 0; k + 1 < N; ++k) stage(k, std::false_type{});
+        stage(N - 1, std::true_type{});
+        // block rows beyond the last stage's columns (tiny problems only): pure identity padding
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+            if (I > ((N * na - 1) >> 4)) {
+#pragma unroll
+                for (int J = 0; J <= I; ++J) finish_tile(I, J);
+            }
         // column gradients back to the column-per-lane order: column 64v + lane sits in tile 4v + lq
         {
             float qs[NB];
@@ -1076,49 +1116,6 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
             }
         }
         wave_lds_fence();   // the dense images in the tile area are dead from here
-
-        // ---------------- finalise H: + 2 (Da' R Da + rho I) per stage block, unit pad diagonal ----
-#pragma unroll
-        for (int I = 0; I < NB; ++I)
-            if (I < nbr) {
-#pragma unroll
-                for (int dJ = 0; dJ < 2; ++dJ) {
-                    const int J = I - 1 + dJ;
-                    if (J < 0) continue;
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        // register rr of lane (lq, li): H[16I + 4lq+rr][16I + li] on the diagonal, H[16I + li][16J + 4lq+rr] below it
-                        const int e1 = (I == J) ? 16 * I + 4 * lq + rr : 16 * I + li;
-                        const int e2 = (I == J) ? 16 * J + li : 16 * J + 4 * lq + rr;
-                        const int s1 = s_stg[e1], a1 = s_thr[e1];
-                        const int s2 = s_stg[e2], a2 = s_thr[e2];
-                        float add = 0.f;
-                        if (s1 != 255 && s1 == s2) {
-#pragma unroll
-                            for (int g = 0; g < 6; ++g) add += s_Da[g * MAX_NT + a1] * Rf[g] * s_Da[g * MAX_NT + a2];
-                            if (a1 == a2) add += rho;
-                            add *= 2.f;
-                        }
-                        if (s1 == 255 && e1 == e2) add = 1.f;
-                        acc[(I * (I + 1)) / 2 + J][rr] += add;
-                    }
-                }
-            }
-        {
-            // -H -> LDS once, each tile exactly as its lanes hold it (one b128 per lane, conflict free): the
-            // factorisation loads a tile STRAIGHT INTO the MFMA accumulator that collects the Schur terms
-            // (sum T'T - H), so no VALU instruction touches it.  Never overwritten (the factor lives in registers).
-            wave_lds_fence();
-#pragma unroll
-            for (int I = 0; I < NB; ++I)
-                if (I < nbr) {
-#pragma unroll
-                    for (int J = 0; J <= I; ++J) {
-                        htiles.st((I * (I + 1)) / 2 + J, lane, -acc[(I * (I + 1)) / 2 + J]);
-                    }
-                }
-            wave_lds_fence();
-        }
 
         // g, bounds, start point
         float gv[NV], lo[NV], hi[NV], sl[NV], su[NV], zl[NV], zu[NV], grad[NV];
@@ -1137,11 +1134,12 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 if (I < nbr) {
 #pragma unroll
                     for (int J = 0; J <= I; ++J) {
+                        const f32x4 ht = htiles.ld((I * (I + 1)) / 2 + J, lane);
 #pragma unroll
                         for (int rr = 0; rr < 4; ++rr) {
                             const int e1 = (I == J) ? 16 * I + 4 * lq + rr : 16 * I + li;
                             const int e2 = (I == J) ? 16 * J + li : 16 * J + 4 * lq + rr;
-                            const float h = acc[(I * (I + 1)) / 2 + J][rr];
+                            const float h = -ht[rr];
                             if (I != J || e1 >= e2) {
                                 P.dbg_H[(int64_t)e1 * npadr + e2] = h;
                                 P.dbg_H[(int64_t)e2 * npadr + e1] = h;

@@ -69,6 +69,22 @@ def test_horizons_not_multiple_of_four(gpu_mpc_factory, N, nfault):
     assert np.abs(out["U"] - ref["U"]).max() / F_MAX <= 2e-3
 
 
+@pytest.mark.parametrize("nfault", [0, 2])
+def test_sixteen_thrusters_short_horizon_on_the_fp32_kernels(gpu_mpc_factory, nfault):
+    """The reference's own 16-thruster allocation matrix with a horizon short enough for the register-resident
+    fp32 kernels (N = 10: n = 160 nominal -> NB = 10, n = 140 with two faults -> NB = 9)."""
+    N, NT, B = 10, 16, 24
+    mpc = gpu_mpc_factory(N=N, NT=NT)
+    x0, ub, stuck, xref = qo.make_batch(B, N, NT, nfault, 3300 + nfault)
+    out = mpc.solve(x0, ub, stuck, xref.reshape(-1, order="F"), return_U=True)
+    assert (out["status"] == 0).all(), out["status"]
+    ref = co.solve_batch(_cfg(N, NT), x0, ub, stuck, xref, nthreads=4, max_iters=60, mu_stop=1e-13)
+    assert (ref["status"] == 0).all()
+    assert np.abs(out["u0"] - ref["u0"]).max() / F_MAX <= 1e-4
+    assert np.abs(out["U"] - ref["U"]).max() / F_MAX <= 2e-3
+    assert (out["u0"][ub == 0] == 0).all()
+
+
 # ---------------------------------------------------------------------------------------------
 # float64 general-size kernel (reference 16-thruster vehicle, long horizons)
 # ---------------------------------------------------------------------------------------------

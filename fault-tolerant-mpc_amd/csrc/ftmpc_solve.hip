@@ -987,6 +987,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
         // finish tile (I,J): + 2 (Da' R Da + rho I) on the blocks of equal stage, unit pad diagonal, then -H to the tile store,
         // each tile exactly as its lanes hold it (one b128 per lane, conflict free): the factorisation loads a tile STRAIGHT
         // INTO the MFMA accumulator that collects the Schur terms (sum T'T - H), so no VALU instruction touches it.
+        float* const mtab = work;     // MAX_NT x MAX_NT words; the vector workspace is idle until the interior-point iterations
         auto finish_tile = [&](int I, int J) {     // I, J are constants after unrolling
             f32x4 h = acc[(I * (I + 1)) / 2 + J];
             if (J >= I - 1) {
@@ -997,13 +998,8 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                     const int e2 = (I == J) ? 16 * J + li : 16 * J + 4 * lq + rr;
                     const int s1 = s_stg[e1], a1 = s_thr[e1];
                     const int s2 = s_stg[e2], a2 = s_thr[e2];
-                    float add = 0.f;
-                    if (s1 != 255 && s1 == s2) {
-#pragma unroll
-                        for (int g = 0; g < 6; ++g) add += s_Da[g * MAX_NT + a1] * Rf[g] * s_Da[g * MAX_NT + a2];
-                        if (a1 == a2) add += rho;
-                        add *= 2.f;
-                    }
+                    // M[a1][a2] = 2 (sum_g Da[g][a1] R_g Da[g][a2] + rho [a1 == a2]), tabulated below (one read instead of twelve)
+                    float add = (s1 != 255 && s1 == s2) ? mtab[((a1 & (MAX_NT - 1)) << 4) | (a2 & (MAX_NT - 1))] : 0.f;
                     if (s1 == 255 && e1 == e2) add = 1.f;
                     h[rr] += add;
                 }
@@ -1093,6 +1089,17 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
             STAMP(2);
         };
         for (int k = 0; k + 1 < N; ++k) stage(k, std::false_type{});
+        for (int t = lane; t < MAX_NT * MAX_NT; t += 64) {
+            const int a1 = t >> 4, a2 = t & (MAX_NT - 1);
+            float m = 0.f;
+            if (a1 < na && a2 < na) {
+#pragma unroll
+                for (int g = 0; g < 6; ++g) m += s_Da[g * MAX_NT + a1] * Rf[g] * s_Da[g * MAX_NT + a2];
+                if (a1 == a2) m += rho;
+            }
+            mtab[t] = 2.f * m;
+        }
+        wave_lds_fence();
         stage(N - 1, std::true_type{});
         // block rows beyond the last stage's columns (tiny problems only): pure identity padding
 #pragma unroll

@@ -241,35 +241,32 @@ __device__ __forceinline__ void fmac4_rowbcast(float (&d)[4], const float (&s)[4
 template <int J>
 struct StepMasks {
     static constexpr unsigned long long grp = lane_mask([](int q, int) { return q == (J >> 2); });
+    static constexpr unsigned long long piv = lane_mask([](int, int col) { return col == J; });
 };
-// `work.run<S>()` is called at 80 points of the potrf + inverse (S = 0..79): the caller may issue one
-// independent MFMA per slot.  This does NOT buy overlap -- a wave cannot issue VALU work while one of its
-// own MFMAs executes (scripts/ubench_mfma.hip: 32 + 5k cycles for an MFMA and k independent v_fma), and
-// the scheduler moves the MFMAs where it likes anyway -- it only gives the off-diagonal Schur products a
-// place in program order where their operands are already there and their results not yet needed.
 template <int J, class Work>
-__device__ __forceinline__ void potrf_inv_step(float (&c)[4], float (&e)[4], float (&w)[4], const Work& work) {
+__device__ __forceinline__ void potrf_inv_step(float (&c)[4], float (&e)[4], float (&w)[4], int bperm_base, const Work& work) {
     constexpr int QJ = J >> 2, RJ = J & 3;
+    // row J of E to every row-group through the LDS crossbar (ds_bpermute: no VALU slot, ~100 cycles of latency that
+    // the pivot chain below covers); row J of the tile itself, which IS on the pivot chain, through the permlane swaps
+    const float ej = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bperm_base + 64 * QJ, __builtin_bit_cast(int, e[RJ])));
     const float d = readlane_f(c[RJ], 16 * QJ + J);
     const float inv = __builtin_amdgcn_rsqf(d);
     const float nrd = -inv * inv;
     work.template run<5 * J + 0>();
-    const float ej = group_bcast<QJ>(e[RJ]);      // E[J][col] in every row-group
-    const float wj = ej * inv;                    // W[J][col]
-    work.template run<5 * J + 1>();
-    w[RJ] = sel<StepMasks<J>::grp>(w[RJ], wj);
     if constexpr (J < 15) {
         const float rowj = group_bcast<QJ>(c[RJ]);    // A[J][col] (= A[col][J]) in every row-group
+        work.template run<5 * J + 1>();
+        // the pivot column itself stays as it is (multiplier 0): the inverse below still needs it unscaled
+        fmac4_rowbcast<J>(c, c, sel<StepMasks<J>::piv>(rowj * nrd, 0.f));
         work.template run<5 * J + 2>();
-        fmac4_rowbcast<J>(e, c, ej * nrd);            // before c's own update: needs the unscaled column J
-        work.template run<5 * J + 3>();
-        fmac4_rowbcast<J>(c, c, rowj * nrd);
-        work.template run<5 * J + 4>();
     } else {
+        work.template run<5 * J + 1>();
         work.template run<5 * J + 2>();
-        work.template run<5 * J + 3>();
-        work.template run<5 * J + 4>();
     }
+    w[RJ] = sel<StepMasks<J>::grp>(w[RJ], ej * inv);   // W[J][col]
+    work.template run<5 * J + 3>();
+    if constexpr (J < 15) fmac4_rowbcast<J>(e, c, ej * nrd);
+    work.template run<5 * J + 4>();
 }
 struct NoWork {
     template <int S>
@@ -284,14 +281,15 @@ __device__ __forceinline__ void potrf_inv16(float (&c)[4], float (&w)[4], int la
         e[rr] = (4 * q + rr == col) ? 1.f : 0.f;
         w[rr] = 0.f;
     }
-    potrf_inv_step<0>(c, e, w, work);   potrf_inv_step<1>(c, e, w, work);
-    potrf_inv_step<2>(c, e, w, work);   potrf_inv_step<3>(c, e, w, work);
-    potrf_inv_step<4>(c, e, w, work);   potrf_inv_step<5>(c, e, w, work);
-    potrf_inv_step<6>(c, e, w, work);   potrf_inv_step<7>(c, e, w, work);
-    potrf_inv_step<8>(c, e, w, work);   potrf_inv_step<9>(c, e, w, work);
-    potrf_inv_step<10>(c, e, w, work);  potrf_inv_step<11>(c, e, w, work);
-    potrf_inv_step<12>(c, e, w, work);  potrf_inv_step<13>(c, e, w, work);
-    potrf_inv_step<14>(c, e, w, work);  potrf_inv_step<15>(c, e, w, work);
+    const int bb = 4 * col;   // ds_bpermute byte address of lane `col` of row-group 0
+    potrf_inv_step<0>(c, e, w, bb, work);   potrf_inv_step<1>(c, e, w, bb, work);
+    potrf_inv_step<2>(c, e, w, bb, work);   potrf_inv_step<3>(c, e, w, bb, work);
+    potrf_inv_step<4>(c, e, w, bb, work);   potrf_inv_step<5>(c, e, w, bb, work);
+    potrf_inv_step<6>(c, e, w, bb, work);   potrf_inv_step<7>(c, e, w, bb, work);
+    potrf_inv_step<8>(c, e, w, bb, work);   potrf_inv_step<9>(c, e, w, bb, work);
+    potrf_inv_step<10>(c, e, w, bb, work);  potrf_inv_step<11>(c, e, w, bb, work);
+    potrf_inv_step<12>(c, e, w, bb, work);  potrf_inv_step<13>(c, e, w, bb, work);
+    potrf_inv_step<14>(c, e, w, bb, work);  potrf_inv_step<15>(c, e, w, bb, work);
 }
 __device__ __forceinline__ void potrf_inv16(float (&c)[4], float (&w)[4], int lane) {
     potrf_inv16(c, w, lane, NoWork{});

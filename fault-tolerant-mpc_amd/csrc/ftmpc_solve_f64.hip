@@ -40,11 +40,9 @@ __device__ __forceinline__ double readlane_d(double x, int l) {
     const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
-__device__ __forceinline__ double quad_sum64(double x) {
-    x += __shfl_xor(x, 16, 64);
-    x += __shfl_xor(x, 32, 64);
-    return x;
-}
+// sum over the four lanes that share lane & 15: permlane swaps on both halves (ftmpc_solve.hip quad_sum_d)
+// instead of four ds_bpermute round trips through the LDS crossbar
+__device__ __forceinline__ double quad_sum64(double x) { return quad_sum_d(x); }
 // barrier for exchanges that go through LDS only: does not drain the outstanding global loads
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ f64x4 mfma(double a, double b, f64x4 c) {

@@ -53,6 +53,23 @@ def test_u0_matches_exact_solution(gpu_mpc_factory, nfault, B):
     assert out["iters"].max() <= 24
 
 
+@pytest.mark.parametrize("nfault,B", [(2, 16384), (1, 4096), (0, 4096)])
+def test_large_batches_against_the_c_oracle(gpu_mpc_factory, nfault, B):
+    """Whole batches through every instantiation (NB = 8 / 9 / 10), every persistent workgroup looping over many
+    instances: scheduling-dependent faults (an instruction hazard inside inline asm once corrupted a few instances
+    per ten thousand) only show up at this size."""
+    import os
+    N, NT = 20, 8
+    mpc = gpu_mpc_factory(N=N, NT=NT)
+    x0, ub, stuck, xref = qo.make_batch(B, N, NT, nfault, 4100 + nfault)
+    out = mpc.solve(x0, ub, stuck, xref.reshape(-1, order="F"), return_U=True)
+    assert (out["status"] == 0).all(), np.bincount(out["status"])
+    ref = co.solve_batch(_cfg(N, NT), x0, ub, stuck, xref, nthreads=min(32, os.cpu_count() or 1), max_iters=60, mu_stop=1e-13)
+    assert (ref["status"] == 0).all()
+    assert np.abs(out["u0"] - ref["u0"]).max() / F_MAX <= 1e-4
+    assert np.abs(out["U"] - ref["U"]).max() / F_MAX <= 2e-3
+
+
 @pytest.mark.parametrize("N,nfault", [(3, 2), (6, 0), (18, 2), (23, 2), (26, 2)])
 def test_horizons_not_multiple_of_four(gpu_mpc_factory, N, nfault):
     """The reference-gradient sweeps run four stages per round with a scalar tail, and the three

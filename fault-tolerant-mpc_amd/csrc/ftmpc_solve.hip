@@ -266,9 +266,10 @@ __device__ __forceinline__ void potrf_inv_step(float (&c)[4], float (&e)[4], flo
     // W[J][col] = E[J][col] / sqrt(d) into row-group QJ only: a DPP multiply with the identity lane pattern whose
     // row_mask enables just that row-group (multiply and select in one instruction; ej comes from the LDS
     // crossbar, not from a VALU write, so the DPP read hazard does not apply)
-    // (the s_nop covers the one wait state a VALU read needs after the transcendental v_rsq that produced `inv`:
-    // the hazard recognizer does not look inside inline asm)
-    asm("s_nop 0\n\tv_mul_f32_dpp %0, %1, %2 quad_perm:[0,1,2,3] row_mask:%3 bank_mask:0xf" : "+v"(w[RJ]) : "v"(ej), "v"(inv), "n"(1 << QJ));
+    // (the s_nop covers the wait state a VALU read needs after the transcendental v_rsq that produced `inv`, and the
+    // two a DPP read needs should the compiler have copied `ej` with a VALU move: the hazard recognizer does not
+    // look inside inline asm)
+    asm("s_nop 1\n\tv_mul_f32_dpp %0, %1, %2 quad_perm:[0,1,2,3] row_mask:%3 bank_mask:0xf" : "+v"(w[RJ]) : "v"(ej), "v"(inv), "n"(1 << QJ));
     work.template run<5 * J + 3>();
     if constexpr (J < 15) fmac4_rowbcast<J>(e, c, ej * nrd);
     work.template run<5 * J + 4>();

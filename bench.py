@@ -188,7 +188,7 @@ def main():
             from oracle import c_oracle, qp_oracle
             cores = os.cpu_count() or 1
             qcfg = qp_oracle.QPConfig(N=N, NT=NT)
-            kw = dict(max_iters=24, mu_stop=1e-11, return_U=False) if peak == F32_PEAK_TFLOPS else dict(max_iters=30, mu_stop=1e-13, return_U=False)
+            kw = dict(max_iters=30, mu_stop=1e-11, return_U=False) if peak == F32_PEAK_TFLOPS else dict(max_iters=30, mu_stop=1e-13, return_U=False)
             t1 = time.perf_counter()
             c_oracle.solve_batch(qcfg, x0[:4 * cores], ub[:4 * cores], stuck[:4 * cores], xref, nthreads=cores, **kw)
             pilot = (time.perf_counter() - t1) / (4 * cores)

@@ -124,7 +124,7 @@ int build_consts(const ftmpc_config& c, DeviceConsts& d, std::string& why) {
     std::memset(&d, 0, sizeof(d));
     d.N = c.N;
     d.NT = c.NT;
-    d.max_iters = c.max_iters > 0 ? c.max_iters : 24;
+    d.max_iters = c.max_iters > 0 ? c.max_iters : 30;
     if ((c.dtype == FTMPC_DTYPE_F64 || c.N * c.NT > 160) && c.max_iters <= 0) d.max_iters = 30;
     d.dt = c.dt;
     d.inv_mass = 1.0 / c.mass;
@@ -268,7 +268,7 @@ int ftmpc_default_config(ftmpc_config* cfg, int32_t N, int32_t NT) {
     cfg->N = N;
     cfg->NT = NT;
     cfg->dtype = FTMPC_DTYPE_F32;
-    cfg->max_iters = 24;
+    cfg->max_iters = 30;
     cfg->device_id = 0;
     cfg->dt = 0.1;                                   // reactive.yaml:2
     cfg->mass = 16.8;                                // sys_model.py:52

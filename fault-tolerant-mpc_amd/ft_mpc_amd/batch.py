@@ -32,7 +32,7 @@ class MPCConfig:
     r: np.ndarray = None
     f_virt: np.ndarray = field(default_factory=lambda: np.array([0.0, 3.5, 0.0]))
     rho: float = 0.05
-    max_iters: int = 0            # <= 0: library default (24 for f32, 30 for f64)
+    max_iters: int = 0            # <= 0: library default (30)
     mu_stop: float = 0.0          # <= 0: library default (1e-11 for f32, 1e-13 for f64)
     device_id: int = 0
     dtype: str = "f32"            # arithmetic of the KKT/IPM solve: "f32" | "f64" (N*NT > 160 always runs f64)

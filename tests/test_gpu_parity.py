@@ -50,7 +50,7 @@ def test_u0_matches_exact_solution(gpu_mpc_factory, nfault, B):
         assert np.abs(out["U"][b] - U).max() / F_MAX < 2e-3
     assert err.max() <= 1e-4, err
     assert (out["u0"][ub == 0] == 0).all()
-    assert out["iters"].max() <= 24
+    assert out["iters"].max() <= 30
 
 
 @pytest.mark.parametrize("nfault,B", [(2, 16384), (1, 4096), (0, 4096)])

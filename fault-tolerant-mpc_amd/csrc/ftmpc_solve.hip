@@ -302,15 +302,14 @@ __device__ __forceinline__ void potrf_inv16(float (&c)[4], float (&w)[4], int la
 }
 
 // =============================================================================================
-// Register-resident factorisation (NB = 8: n <= 128).  The factor never touches LDS: every tile
-// lives in 4 VGPRs per lane in the accumulator layout, and every tile product is
+// Register-resident factorisation (all instantiations).  The factor never touches LDS: every tile
+// lives in 4 registers per lane in the accumulator layout, and every tile product is
 //     mm_tn(X, Y) = X' Y      (k = row index of both accumulator tiles: register s of
 //                              row-group q' is k = 4q'+s, so both MFMA operands ARE registers)
-// Kept per tile pair I > J:  T_IJ = L_IJ'  and  Ln_IJ = L_IJ ; per diagonal block W_J = L_JJ^-1
-// (Ln slot) and Wt_J = W_J' (T slot).  With vectors held as accumulator "column tiles"
-// (lane (q, n): v[4q+rr], replicated over n) the triangular solves are MFMA chains as well:
-//     forward   y_J = Wt_J' (b_J - sum_K T_JK' y_K)        backward  x_J = W_J' (y_J - sum_I Ln_IJ' x_I)
-// H stays in LDS untouched (read for the gradient and as the start of each factorisation).
+// Kept per tile pair I > J:  T_IJ = L_IJ' ; per diagonal block W_J = L_JJ^-1 (Wd) and its transpose
+// Wt_J (the T slot of the diagonal: operand of the panel solve T_IJ = W_J C_IJ').  The triangular
+// solves run on the same registers with packed VALU FMAs (solve_reg).
+// -H stays in the tile store untouched: every accumulator of the factorisation is seeded from it.
 // =============================================================================================
 __device__ __forceinline__ f32x4 mm_tn(const f32x4& X, const f32x4& Y, f32x4 acc) {
     acc = mfma4(X.x, Y.x, acc);

@@ -43,6 +43,8 @@ __device__ __forceinline__ double readlane_d(double x, int l) {
 // sum over the four lanes that share lane & 15: permlane swaps on both halves (ftmpc_solve.hip quad_sum_d)
 // instead of four ds_bpermute round trips through the LDS crossbar
 __device__ __forceinline__ double quad_sum64(double x) { return quad_sum_d(x); }
+// owner wave of tile (J + t, J) of block column J: t = 0 is the diagonal (see the factorisation loop)
+__device__ __forceinline__ int col_owner(int t) { return t == 0 ? 0 : (t <= 6 ? 1 + (t - 1) % 3 : (t - 7) & 3); }
 // barrier for exchanges that go through LDS only: does not drain the outstanding global loads
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ f64x4 mfma(double a, double b, f64x4 c) {
@@ -484,13 +486,35 @@ __global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const Devi
             if (tid == 0) s_flag = 1;
             for (int J = 0; J < nb; ++J) {
                 __syncthreads();
-                for (int I = J + wave; I < nb; I += NWAVE) {
+                // wave 0 takes the diagonal tile and its potrf + inverse (the serial part of the column); the first six
+                // off-diagonal tiles go round-robin over waves 1..3 (about the time of the potrf), the rest over all four
+                for (int I = J; I < nb; ++I) {
+                    if (col_owner(I - J) != wave) continue;
                     f64x4 acc = {0.0, 0.0, 0.0, 0.0};
                     const double* rowI = Ls + (int64_t)t64idx(I, 0) * 256 + 16 * li + 4 * lq;
                     const double* rowJ = Ls + (int64_t)t64idx(J, 0) * 256 + 16 * li + 4 * lq;
                     int K = 0;
                     // the tiles come from L2 (~800 cycles): four tile pairs in flight, two accumulators
                     f64x4 acc2 = {0.0, 0.0, 0.0, 0.0};
+                    if (I == J) {   // diagonal tile: both operands are the same row, load it once
+                        for (; K + 3 < J; K += 4) {
+                            const f64x4 a0 = ld4(rowI + K * 256), a1 = ld4(rowI + (K + 1) * 256);
+                            const f64x4 a2 = ld4(rowI + (K + 2) * 256), a3 = ld4(rowI + (K + 3) * 256);
+                            acc = mfma(a0.x, a0.x, acc); acc2 = mfma(a1.x, a1.x, acc2);
+                            acc = mfma(a0.y, a0.y, acc); acc2 = mfma(a1.y, a1.y, acc2);
+                            acc = mfma(a0.z, a0.z, acc); acc2 = mfma(a1.z, a1.z, acc2);
+                            acc = mfma(a0.w, a0.w, acc); acc2 = mfma(a1.w, a1.w, acc2);
+                            acc = mfma(a2.x, a2.x, acc); acc2 = mfma(a3.x, a3.x, acc2);
+                            acc = mfma(a2.y, a2.y, acc); acc2 = mfma(a3.y, a3.y, acc2);
+                            acc = mfma(a2.z, a2.z, acc); acc2 = mfma(a3.z, a3.z, acc2);
+                            acc = mfma(a2.w, a2.w, acc); acc2 = mfma(a3.w, a3.w, acc2);
+                        }
+                        for (; K < J; ++K) {
+                            const f64x4 a0 = ld4(rowI + K * 256);
+                            acc = mfma(a0.x, a0.x, acc); acc = mfma(a0.y, a0.y, acc);
+                            acc = mfma(a0.z, a0.z, acc); acc = mfma(a0.w, a0.w, acc);
+                        }
+                    }
                     for (; K + 3 < J; K += 4) {
                         const f64x4 a0 = ld4(rowI + K * 256), b0 = ld4(rowJ + K * 256);
                         const f64x4 a1 = ld4(rowI + (K + 1) * 256), b1 = ld4(rowJ + (K + 1) * 256);
@@ -548,8 +572,8 @@ __global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const Devi
                 }
                 __syncthreads();
                 const f64x4 w4 = ld4(Ls + (int64_t)t64idx(J, J) * 256 + 16 * li + 4 * lq);
-                for (int I = J + wave; I < nb; I += NWAVE) {   // same wave that produced C_IJ
-                    if (I == J) continue;
+                for (int I = J + 1; I < nb; ++I) {   // same wave that produced C_IJ
+                    if (col_owner(I - J) != wave) continue;
                     double* tij = Ls + (int64_t)t64idx(I, J) * 256;
                     const f64x4 a4 = ld4(tij + 16 * li + 4 * lq);
                     f64x4 x = {0.0, 0.0, 0.0, 0.0};

@@ -223,7 +223,10 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
         q.dbg_vec = h->d_dbgv64;
         const int grid = (int)std::min<int64_t>(B, h->grid64);
         if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[8], s));
-        hipLaunchKernelGGL(ftmpc::ftmpc_solve_f64_kernel, dim3(grid), dim3(ftmpc::f64k::WG), 0, s, h->dc, q);
+        if (h->npad_max <= 256)
+            hipLaunchKernelGGL(ftmpc::ftmpc_solve_f64_kernel<4>, dim3(grid), dim3(ftmpc::f64k::WG), 0, s, h->dc, q);
+        else
+            hipLaunchKernelGGL(ftmpc::ftmpc_solve_f64_kernel<ftmpc::f64k::RPF>, dim3(grid), dim3(ftmpc::f64k::WG), 0, s, h->dc, q);
         HIP_TRY(h, hipGetLastError());
         if (h->profiling) {
             HIP_TRY(h, hipEventRecord(h->ev[9], s));
@@ -366,7 +369,7 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per[2], ftmpc::ftmpc_solve_f32_kernel<10>, 64, 0);
     for (int v = 0; v < 3; ++v) h->grid[v] = h->num_cu * (per[v] < 1 ? 1 : per[v]);
     int per64 = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per64, ftmpc::ftmpc_solve_f64_kernel, ftmpc::f64k::WG, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per64, ftmpc::ftmpc_solve_f64_kernel<ftmpc::f64k::RPF>, ftmpc::f64k::WG, 0);
     if (per64 < 1) per64 = 1;
     if (per64 > 2) per64 = 2;
     h->grid64 = h->num_cu * per64;

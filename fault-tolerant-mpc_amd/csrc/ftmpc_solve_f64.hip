@@ -14,6 +14,8 @@
 // controllers/tools/control_allocator.py:65-94 (see DESIGN.md QP-spec).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "ftmpc_common.h"
 
 namespace ftmpc {
@@ -132,6 +134,9 @@ struct Solve64Params {
 #define S64_START()
 #define S64(i)
 #endif
+// SWEEP_ROWS: block rows per wave whose tiles the triangular sweeps prefetch.  4 serves n <= 256 (the reference
+// vehicle) with small register arrays, f64k::RPF everything up to 640; the host picks by the handle's N * NT.
+template <int SWEEP_ROWS>
 __global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const DeviceConsts C, const Solve64Params Q) {
     using namespace f64k;
     const SolveParams& P = Q.base;
@@ -597,18 +602,20 @@ __global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const Devi
             // backward: columns J = w mod 4); the owner of step J finishes block J alone, publishes it in LDS and
             // everybody folds it into their sums.  One LDS-only barrier per step (the outstanding tile loads stay
             // in flight across it), every tile requested one step before it is needed.
-            auto solve = [&]() {
+            auto solve = [&](auto RPC) {
+                constexpr int RP = decltype(RPC)::value;
+                constexpr int RM = (RP < RPF) ? RP : RMAXW;
                 const int myp = v64pos(li);
                 double* rb = part + wave * 16;            // per-wave 16-vector scratch
-                f64x4 buf[RPF];                            // tiles (I, J) of this wave's rows for the current step
+                f64x4 buf[RP];                            // tiles (I, J) of this wave's rows for the current step
                 f64x4 wdiag = {0.0, 0.0, 0.0, 0.0};
-                double psum[RMAXW];
+                double psum[RM];
 #pragma unroll
-                for (int i = 0; i < RMAXW; ++i) psum[i] = 0.0;
+                for (int i = 0; i < RM; ++i) psum[i] = 0.0;
                 // ---- forward: L y = b ----
                 auto fetch_f = [&](int J) {               // column J of the factor, rows I = wave + 4 i > J
 #pragma unroll
-                    for (int i = 0; i < RPF; ++i) {
+                    for (int i = 0; i < RP; ++i) {
                         const int I = wave + NWAVE * i;
                         if (I > J && I < nb) buf[i] = ld4(Ls + (int64_t)t64idx(I, J) * 256 + 16 * li + 4 * lq);
                     }
@@ -721,7 +728,7 @@ __global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const Devi
             }
             __syncthreads();
             S64(7);
-            solve();
+            solve(std::integral_constant<int, SWEEP_ROWS>{});
             S64(6);
             double da[NVT], dzl_a[NVT], dzu_a[NVT];
             double ap = 1.0, ad = 1.0;
@@ -765,7 +772,7 @@ __global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const Devi
             }
             __syncthreads();
             S64(7);
-            solve();
+            solve(std::integral_constant<int, SWEEP_ROWS>{});
             S64(6);
             double dd[NVT], dzl[NVT], dzu[NVT];
             ap = 1e300;
@@ -827,5 +834,8 @@ __global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const Devi
 #endif
     }
 }
+
+template __global__ void ftmpc_solve_f64_kernel<4>(const DeviceConsts, const Solve64Params);
+template __global__ void ftmpc_solve_f64_kernel<f64k::RPF>(const DeviceConsts, const Solve64Params);
 
 }  // namespace ftmpc

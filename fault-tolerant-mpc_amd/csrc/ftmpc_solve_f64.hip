@@ -26,8 +26,8 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WG = 256;       // threads per workgroup
 constexpr int NWAVE = 4;
-constexpr int NVT = 4;        // columns per thread (n <= 1024)
-constexpr int NMAX = WG * NVT;
+constexpr int NVT_MAX = 4;    // columns per thread at n = 1024
+constexpr int NMAX = WG * NVT_MAX;
 constexpr int RPF = 10;                  // block rows (columns) per wave whose tiles are prefetched in the sweeps (n <= 640)
 constexpr int RMAXW = NMAX / 16 / NWAVE;  // block rows per wave at n = 1024; rows beyond RPF load their tiles at use
 
@@ -139,6 +139,7 @@ struct Solve64Params {
 template <int SWEEP_ROWS>
 __global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const DeviceConsts C, const Solve64Params Q) {
     using namespace f64k;
+    constexpr int NVT = (SWEEP_ROWS == 4) ? 1 : NVT_MAX;   // columns per thread: the n <= 256 instantiation needs one
     const SolveParams& P = Q.base;
     __shared__ double recbuf[REC_STRIDE];
     __shared__ double dv[NMAX];        // d (permuted per 16-block) for the gradient mat-vec

@@ -369,7 +369,10 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per[2], ftmpc::ftmpc_solve_f32_kernel<10>, 64, 0);
     for (int v = 0; v < 3; ++v) h->grid[v] = h->num_cu * (per[v] < 1 ? 1 : per[v]);
     int per64 = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per64, ftmpc::ftmpc_solve_f64_kernel<ftmpc::f64k::RPF>, ftmpc::f64k::WG, 0);
+    if (16 * h->nb_max <= 256)
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per64, ftmpc::ftmpc_solve_f64_kernel<4>, ftmpc::f64k::WG, 0);
+    else
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per64, ftmpc::ftmpc_solve_f64_kernel<ftmpc::f64k::RPF>, ftmpc::f64k::WG, 0);
     if (per64 < 1) per64 = 1;
     if (per64 > 2) per64 = 2;
     h->grid64 = h->num_cu * per64;

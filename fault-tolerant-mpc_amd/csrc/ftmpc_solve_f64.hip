@@ -137,7 +137,7 @@ struct Solve64Params {
 // SWEEP_ROWS: block rows per wave whose tiles the triangular sweeps prefetch.  4 serves n <= 256 (the reference
 // vehicle) with small register arrays, f64k::RPF everything up to 640; the host picks by the handle's N * NT.
 template <int SWEEP_ROWS>
-__global__ void __launch_bounds__(f64k::WG, 1) ftmpc_solve_f64_kernel(const DeviceConsts C, const Solve64Params Q) {
+__global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4) ? 2 : 1) ftmpc_solve_f64_kernel(const DeviceConsts C, const Solve64Params Q) {
     using namespace f64k;
     constexpr int NVT = (SWEEP_ROWS == 4) ? 1 : NVT_MAX;   // columns per thread: the n <= 256 instantiation needs one
     const SolveParams& P = Q.base;

@@ -224,9 +224,11 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
         const int grid = (int)std::min<int64_t>(B, h->grid64);
         if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[8], s));
         if (h->npad_max <= 256)
-            hipLaunchKernelGGL(ftmpc::ftmpc_solve_f64_kernel<4>, dim3(grid), dim3(ftmpc::f64k::WG), 0, s, h->dc, q);
+            hipLaunchKernelGGL((ftmpc::ftmpc_solve_f64_kernel<4, 1>), dim3(grid), dim3(ftmpc::f64k::WG), 0, s, h->dc, q);
+        else if (h->npad_max <= 640)
+            hipLaunchKernelGGL((ftmpc::ftmpc_solve_f64_kernel<ftmpc::f64k::RPF, 3>), dim3(grid), dim3(ftmpc::f64k::WG), 0, s, h->dc, q);
         else
-            hipLaunchKernelGGL(ftmpc::ftmpc_solve_f64_kernel<ftmpc::f64k::RPF>, dim3(grid), dim3(ftmpc::f64k::WG), 0, s, h->dc, q);
+            hipLaunchKernelGGL((ftmpc::ftmpc_solve_f64_kernel<ftmpc::f64k::RPF, ftmpc::f64k::NVT_MAX>), dim3(grid), dim3(ftmpc::f64k::WG), 0, s, h->dc, q);
         HIP_TRY(h, hipGetLastError());
         if (h->profiling) {
             HIP_TRY(h, hipEventRecord(h->ev[9], s));
@@ -370,9 +372,11 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
     for (int v = 0; v < 3; ++v) h->grid[v] = h->num_cu * (per[v] < 1 ? 1 : per[v]);
     int per64 = 0;
     if (16 * h->nb_max <= 256)
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per64, ftmpc::ftmpc_solve_f64_kernel<4>, ftmpc::f64k::WG, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per64, ftmpc::ftmpc_solve_f64_kernel<4, 1>, ftmpc::f64k::WG, 0);
+    else if (16 * h->nb_max <= 640)
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per64, ftmpc::ftmpc_solve_f64_kernel<ftmpc::f64k::RPF, 3>, ftmpc::f64k::WG, 0);
     else
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per64, ftmpc::ftmpc_solve_f64_kernel<ftmpc::f64k::RPF>, ftmpc::f64k::WG, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per64, ftmpc::ftmpc_solve_f64_kernel<ftmpc::f64k::RPF, ftmpc::f64k::NVT_MAX>, ftmpc::f64k::WG, 0);
     if (per64 < 1) per64 = 1;
     if (per64 > 2) per64 = 2;
     h->grid64 = h->num_cu * per64;

@@ -136,10 +136,10 @@ struct Solve64Params {
 #endif
 // SWEEP_ROWS: block rows per wave whose tiles the triangular sweeps prefetch.  4 serves n <= 256 (the reference
 // vehicle) with small register arrays, f64k::RPF everything up to 640; the host picks by the handle's N * NT.
-template <int SWEEP_ROWS>
+template <int SWEEP_ROWS, int NVT>   // NVT: columns per thread (n <= 256 NVT)
 __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4) ? 2 : 1) ftmpc_solve_f64_kernel(const DeviceConsts C, const Solve64Params Q) {
     using namespace f64k;
-    constexpr int NVT = (SWEEP_ROWS == 4) ? 1 : NVT_MAX;   // columns per thread: the n <= 256 instantiation needs one
+    static_assert(NVT >= 1 && NVT <= NVT_MAX, "columns per thread");
     const SolveParams& P = Q.base;
     __shared__ double recbuf[REC_STRIDE];
     __shared__ double dv[NMAX];        // d (permuted per 16-block) for the gradient mat-vec
@@ -836,7 +836,8 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4) ? 2 : 1) ftmpc_sol
     }
 }
 
-template __global__ void ftmpc_solve_f64_kernel<4>(const DeviceConsts, const Solve64Params);
-template __global__ void ftmpc_solve_f64_kernel<f64k::RPF>(const DeviceConsts, const Solve64Params);
+template __global__ void ftmpc_solve_f64_kernel<4, 1>(const DeviceConsts, const Solve64Params);                      // n <= 256
+template __global__ void ftmpc_solve_f64_kernel<f64k::RPF, 3>(const DeviceConsts, const Solve64Params);              // n <= 640
+template __global__ void ftmpc_solve_f64_kernel<f64k::RPF, f64k::NVT_MAX>(const DeviceConsts, const Solve64Params);  // n <= 1024
 
 }  // namespace ftmpc

@@ -146,6 +146,19 @@ def test_f64_kernel_config5_shape(gpu_mpc_factory):
     assert np.abs(out["U"] - ref["U"]).max() / F_MAX < 1e-6
 
 
+def test_f64_kernel_beyond_640_variables(gpu_mpc_factory):
+    """The float64 kernel has three instantiations (n <= 256, <= 640, <= 1024); N = 52 with all 16 thrusters healthy is
+    n = 832: four columns per thread and block rows beyond the prefetched ones in the triangular sweeps."""
+    N, NT, B = 52, 16, 2
+    mpc = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40)
+    x0, ub, stuck, xref = qo.make_batch(B, N, NT, 0, 1006)
+    out = mpc.solve(x0, ub, stuck, xref.reshape(-1, order="F"), return_U=True)
+    ref = co.solve_batch(_cfg(N, NT), x0, ub, stuck, xref, nthreads=2, max_iters=60)
+    assert (out["status"] == 0).all(), out["status"]
+    assert np.abs(out["u0"] - ref["u0"]).max() / F_MAX < 1e-7
+    assert np.abs(out["U"] - ref["U"]).max() / F_MAX < 1e-6
+
+
 def test_f64_dtype_on_small_problem_and_warm_start(gpu_mpc_factory):
     """dtype='f64' routes n<=160 problems through the float64 kernel too; warm start + uref."""
     d = np.load(__import__("pathlib").Path(__file__).parent / "golden" / "qp_cfg3_warm_uref.npz")

@@ -4,11 +4,21 @@
 A "step" is one pass of the hot path (linearise -> condense -> IPM -> thrust command) over one
 batch of synthetic random-pose / random-double-fault instances already resident in HBM.
 Workload = BASELINE.json configs[2]: batch 65536 per GPU, N=20, 8 thrusters, two random
-faulted thrusters, cold start, hover reference.  Batches shard across ranks with no data-path
-collective (weak scaling: every rank owns its own 65536 instances).
+faulted thrusters, cold start, hover reference.  Batches shard across GPUs with no data-path
+collective (weak scaling: every GPU owns its own 65536 instances).
+
+Three ways to run N > 1:
+  * `python bench.py --gpus N`                      this process drives all N GPUs itself through the library's
+                                                    in-process multi-GPU driver (include/ftmpc.h ftmpc_multi_*:
+                                                    one host thread + one handle + one stream set per device);
+  * `python -m torch.distributed.run ... bench.py --gpus N`   one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE from
+                                                    the environment), gloo only for the timing bracket;
+  * FTMPC_BENCH_SINGLE_DEVICE=1 (tests)             either of the above with every rank / slot on device 0.
 """
 import argparse
+import hashlib
 import json
+import math
 import os
 import sys
 import time
@@ -22,6 +32,7 @@ sys.path.insert(0, str(ROOT / "fault-tolerant-mpc_amd"))
 
 F32_PEAK_TFLOPS = 157.3  # MI355X fp32 MFMA == fp32 vector peak (MI355X_MICROARCH.md)
 F64_PEAK_TFLOPS = 78.6   # fp64 vector/matrix peak
+METRIC = "MPC QP steps/s (whole node) at N=20, 8 thrusters, batch 65536"
 
 
 def algorithmic_flops(N, na, iters):
@@ -37,19 +48,181 @@ def algorithmic_flops(N, na, iters):
     return f_lin + f_cond + f_h + f_g + iters * f_it
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
-    ap.add_argument("--horizon", type=int, default=20)
-    ap.add_argument("--thrusters", type=int, default=8)
-    ap.add_argument("--faults", type=int, default=2)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="arithmetic of the KKT/IPM solve")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def batch_flops(N, ub, iters):
+    na = (ub > 0).sum(axis=1)
+    tot = 0.0
+    for a in np.unique(na):
+        sel = na == a
+        tot += float(algorithmic_flops(N, int(a), 0)) * int(sel.sum()) + float(algorithmic_flops(N, int(a), 1) - algorithmic_flops(N, int(a), 0)) * float(iters[sel].sum())
+    return tot
 
+
+def csrc_hash():
+    """sha256 over the kernel sources: the committed PMC traffic figure is only quoted for the code it was measured on."""
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "fault-tolerant-mpc_amd" / "csrc").glob("*")):
+        if f.suffix in (".hip", ".h"):
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def host_cpu_info():
+    """Cores this process may actually use: the scheduler affinity mask, capped by the cgroup CPU quota."""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        t = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if t[0] != "max":
+            quota = float(t[0]) / float(t[1])
+    except Exception:
+        try:
+            q = float(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+            p = float(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            if q > 0:
+                quota = q / p
+        except Exception:
+            pass
+    usable = aff if quota is None else max(1, min(aff, int(math.floor(quota + 1e-9))))
+    return {"os_cpu_count": os.cpu_count(), "sched_affinity": aff, "cgroup_quota_cpus": quota, "usable": usable}
+
+
+def traffic_for(dom, B, N, NT):
+    tfile = ROOT / "profiles" / "traffic_latest.json"
+    if not tfile.exists():
+        return None, None
+    tj = json.loads(tfile.read_text())
+    if tj.get("kernel") == dom and tj.get("batch") == B and tj.get("horizon") == N and tj.get("thrusters") == NT:
+        if tj.get("csrc_sha") == csrc_hash():
+            return tj["bytes_per_launch"], tj["source"]
+        return None, f"stale: {tj.get('source')} was measured on csrc {tj.get('csrc_sha')}, this is {csrc_hash()}"
+    return None, None
+
+
+def cpu_baseline(N, NT, x0, ub, stuck, xref, u0_gpu, f32):
+    """The C float64 restatement (oracle/ftmpc_oracle.c) on this box's usable host cores, on a bounded prefix of the
+    same batch (about 12 s of CPU work), plus the same port on one thread."""
+    from oracle import c_oracle, qp_oracle
+    info = host_cpu_info()
+    cores = info["usable"]
+    B = x0.shape[0]
+    qcfg = qp_oracle.QPConfig(N=N, NT=NT)
+    kw = dict(max_iters=30, mu_stop=1e-11 if f32 else 1e-13, return_U=False)
+    npilot = min(B, 4 * cores)
+    t1 = time.perf_counter()
+    c_oracle.solve_batch(qcfg, x0[:npilot], ub[:npilot], stuck[:npilot], xref, nthreads=cores, **kw)
+    pilot = (time.perf_counter() - t1) / npilot
+    sample = int(min(B, max(8 * cores, 12.0 / max(pilot, 1e-6))))
+    t1 = time.perf_counter()
+    ref = c_oracle.solve_batch(qcfg, x0[:sample], ub[:sample], stuck[:sample], xref, nthreads=cores, **kw)
+    cpu_t = time.perf_counter() - t1
+    err = float(np.abs(ref["u0"] - u0_gpu[:sample]).max() / 3.4)
+    n1 = int(min(sample, 2048))
+    t1 = time.perf_counter()
+    c_oracle.solve_batch(qcfg, x0[:n1], ub[:n1], stuck[:n1], xref, nthreads=1, **kw)
+    one_t = time.perf_counter() - t1
+    return {"value": sample / cpu_t, "unit": "QP-steps/s", "cores": cores, "kind": "port",
+            "sample": f"first {sample} instances of the same batch, C float64 restatement (oracle/ftmpc_oracle.c), "
+                      f"{cores} threads, {cpu_t:.1f} s; reference IPOPT path not runnable offline",
+            "host": info,
+            "gpu_vs_port_max_u0_err_over_fmax": err,
+            "single_thread": {"value": n1 / one_t, "unit": "QP-steps/s", "sample": f"first {n1} instances, 1 thread, {one_t:.1f} s"},
+            "parallel_speedup": (sample / cpu_t) / (n1 / one_t)}
+
+
+def make_line(args, world, elapsed, B, N, NT, iters, status, ub, kernel_ms, parallelism):
+    lin_ms = kernel_ms.pop("ftmpc_linearize_kernel", 0.0)
+    dom = max(kernel_ms, key=kernel_ms.get)
+    sol_ms = kernel_ms[dom]
+    flops = batch_flops(N, ub, iters)
+    f64 = args.dtype == "f64" or N * NT > 160
+    peak = F64_PEAK_TFLOPS if f64 else F32_PEAK_TFLOPS
+    achieved = flops / (sol_ms * 1e-3) / 1e12
+    traffic, traffic_src = traffic_for(dom, B, N, NT)
+    return {
+        "metric": METRIC,
+        "value": args.steps * B * world / elapsed, "unit": "QP-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64" if f64 else "f32", "data": "synthetic",
+        "config": {"workload": f"batch {B}/GPU, N={N}, {NT} thrusters, random {args.faults}-fault Monte-Carlo, "
+                               f"cold start, hover reference (BASELINE configs[2])",
+                   "batch_per_gpu": B, "horizon": N, "thrusters": NT, "faults": args.faults,
+                   "ipm_iters_mean": float(iters.mean()), "ipm_iters_max": int(iters.max()),
+                   "not_converged": int((status != 0).sum()), "parallelism": parallelism},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                     "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": dom, "kernel_ms": sol_ms,
+                     "other_kernels_ms": {"ftmpc_linearize_kernel": lin_ms, **{k: v for k, v in kernel_ms.items() if k != dom}},
+                     "flops_per_launch": flops, "csrc_sha": csrc_hash()},
+    }
+
+
+# ------------------------------------------------------------------------------------------------
+# N > 1 from the plain command: this process drives every GPU through the in-process multi-GPU driver
+# ------------------------------------------------------------------------------------------------
+def run_multi_inprocess(args):
+    import ft_mpc_amd
+    from ft_mpc_amd.sharding import MultiGPUMPC
+    G, N, NT, B = args.gpus, args.horizon, args.thrusters, args.batch
+    devices = [0] * G if os.environ.get("FTMPC_BENCH_SINGLE_DEVICE") == "1" else list(range(G))
+    cfg = ft_mpc_amd.MPCConfig(N=N, NT=NT, dtype=args.dtype)
+    m = MultiGPUMPC(cfg, devices=devices)
+
+    def batch(total, seed0):
+        # device g gets exactly what rank g of the torchrun path generates: its own seeded batch
+        per = total // G
+        parts = [ft_mpc_amd.make_synthetic_batch(per, N, NT, args.faults, seed0 + g) for g in range(G)]
+        return (np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]),
+                np.concatenate([p[2] for p in parts]), parts[0][3])
+
+    def timed(mm, steps):
+        t0 = time.perf_counter()
+        mm.step(steps)            # returns when every device has finished its `steps` steps (max over devices)
+        return time.perf_counter() - t0
+
+    x0, ub, stuck, xref = batch(B * G, 1003)
+    xr = np.ascontiguousarray(xref.reshape(-1, order="F"))
+    m.upload(x0, ub, stuck, xr)
+    m.step(args.warmup)
+    elapsed = timed(m, args.steps)
+    m.set_profiling(True)
+    kms = []
+    for _ in range(3):
+        m.step(1)
+        kms.append(m.last_kernel_ms(0))
+    m.set_profiling(False)
+    med = {k: float(np.median([r.get(k, 0.0) for r in kms])) for k in sorted(kms[0])}
+    out = m.download()
+    lo, hi = m.shard_bounds(B * G, 0)
+    line = make_line(args, G, elapsed, B, N, NT, out["iters"][lo:hi], out["status"], ub[lo:hi], med,
+                     f"batch-sharded x{G}, one process, one host thread + handle + stream per GPU, no collective")
+    line["config"]["ipm_iters_mean"] = float(out["iters"].mean())
+    line["config"]["launcher"] = "in-process (ftmpc_multi_*)"
+    # strong scaling (fixed total work): BASELINE configs[2] total (65 536) and configs[3] (262 144) over the G GPUs, against
+    # the same totals on one GPU of this run; parallel efficiency = rate_G / (G * rate_1)
+    strong = {}
+    one = MultiGPUMPC(cfg, devices=[devices[0]])
+    for total in (65536, 262144):
+        total = (total // G) * G
+        sx0, sub, sst, _ = batch(total, 1004)
+        m.upload(sx0, sub, sst, xr)
+        m.step(1)
+        tG = timed(m, args.steps)
+        one.upload(sx0, sub, sst, xr)
+        one.step(1)
+        t1 = timed(one, args.steps)
+        strong[str(total)] = {"value": args.steps * total / tG, "unit": "QP-steps/s", "ms_per_step": tG / args.steps * 1e3,
+                              "one_gpu_value": args.steps * total / t1, "parallel_efficiency": (t1 / tG) / G}
+    one.close()
+    line["strong_scaling"] = strong
+    print(json.dumps(line))
+    m.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# one rank per GPU (torchrun) and the single-GPU default
+# ------------------------------------------------------------------------------------------------
+def run_rank(args):
     import torch
     import torch.distributed as dist
     import ft_mpc_amd
@@ -57,15 +230,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        sys.exit("bench.py --gpus N (N > 1) must be launched with one rank per GPU: python -m torch.distributed.run "
-                 "--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     if world > 1:
         # The data path has NO collective (independent instances, batch-sharded): torch.distributed is
         # only the timing bracket (barrier + max over ranks), on CPU tensors over gloo.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo")
-    # FTMPC_BENCH_SINGLE_DEVICE=1 (tests only) maps every rank to cuda:0 to rehearse the multi-rank path on a 1-GPU box
     if os.environ.get("FTMPC_BENCH_SINGLE_DEVICE") == "1":
         local = 0
     torch.cuda.set_device(local)
@@ -92,6 +261,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(t):
+        if world > 1:
+            tt = torch.tensor([t], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        return t
+
     for _ in range(args.warmup):
         step()
     barrier()
@@ -99,13 +275,9 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
 
-    # per-kernel device time of one more (untimed) step: hipEvents on the launch stream
+    # per-kernel device time of three more (untimed) steps: hipEvents on the launch stream
     mpc.set_profiling(True)
     kms = []
     for _ in range(3):
@@ -113,11 +285,7 @@ def main():
         torch.cuda.synchronize()
         kms.append(mpc.last_kernel_ms())
     mpc.set_profiling(False)
-    names = sorted(kms[0])
-    med = {k: float(np.median([r.get(k, 0.0) for r in kms])) for k in names}
-    lin_ms = med.pop("ftmpc_linearize_kernel")
-    dom = max(med, key=med.get)          # dominant kernel of the step
-    sol_ms = med[dom]
+    med = {k: float(np.median([r.get(k, 0.0) for r in kms])) for k in sorted(kms[0])}
 
     iters = d_iters.cpu().numpy()
     status = d_status.cpu().numpy()
@@ -143,75 +311,41 @@ def main():
     for _ in range(args.steps):
         step_warm()
     barrier()
-    warm_elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([warm_elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        warm_elapsed = float(t.item())
+    warm_elapsed = max_over_ranks(time.perf_counter() - t0)
     warm_iters = float(d_itw.float().mean().item())
     warm_du0 = float((d_u0w - d_u0).abs().amax(dim=1).median().item() / 3.4)
-    na = (ub > 0).sum(axis=1)
-    flops = float(sum(algorithmic_flops(N, int(a), int(k)) for a, k in zip(na, iters)))
 
     if rank == 0:
-        value = args.steps * B * world / elapsed
-        achieved = flops / (sol_ms * 1e-3) / 1e12
-        peak = F64_PEAK_TFLOPS if (args.dtype == "f64" or N * NT > 160) else F32_PEAK_TFLOPS
-        # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process, so
-        # the committed rocprofv3 --pmc summary of the same command is reported (per launch, with the
-        # gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md); null when no summary matches.
-        traffic, traffic_src = None, None
-        tfile = ROOT / "profiles" / "traffic_latest.json"
-        if tfile.exists():
-            tj = json.loads(tfile.read_text())
-            if tj.get("kernel") == dom and tj.get("batch") == B and tj.get("horizon") == N and tj.get("thrusters") == NT:
-                traffic, traffic_src = tj["bytes_per_launch"], tj["source"]
-        line = {
-            "metric": "MPC QP steps/s (whole node) at N=20, 8 thrusters, batch 65536",
-            "value": value, "unit": "QP-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64" if (args.dtype == "f64" or N * NT > 160) else "f32", "data": "synthetic",
-            "config": {"workload": f"batch {B}/GPU, N={N}, {NT} thrusters, random {args.faults}-fault Monte-Carlo, "
-                                   f"cold start, hover reference (BASELINE configs[2])",
-                       "batch_per_gpu": B, "horizon": N, "thrusters": NT, "faults": args.faults,
-                       "ipm_iters_mean": float(iters.mean()), "ipm_iters_max": int(iters.max()),
-                       "not_converged": int((status != 0).sum()), "parallelism": f"batch-sharded x{world}, no collective"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": dom, "kernel_ms": sol_ms, "other_kernels_ms": {"ftmpc_linearize_kernel": lin_ms, **{k: v for k, v in med.items() if k != dom}},
-                         "flops_per_launch": flops},
-        }
+        line = make_line(args, world, elapsed, B, N, NT, iters, status, ub, med, f"batch-sharded x{world}, no collective")
+        line["config"]["launcher"] = "torch.distributed.run (one rank per GPU)" if world > 1 else "single process"
         line["warm_start"] = {"value": args.steps * B * world / warm_elapsed, "unit": "QP-steps/s", "ipm_iters_mean": warm_iters,
                               "median_u0_change_over_fmax": warm_du0,
                               "note": "same states, linearised about the previous solution shifted by one stage; reported beside the cold-start `value`"}
         if world == 1 and not args.no_cpu_baseline:
-            from oracle import c_oracle, qp_oracle
-            cores = os.cpu_count() or 1
-            qcfg = qp_oracle.QPConfig(N=N, NT=NT)
-            kw = dict(max_iters=30, mu_stop=1e-11, return_U=False) if peak == F32_PEAK_TFLOPS else dict(max_iters=30, mu_stop=1e-13, return_U=False)
-            t1 = time.perf_counter()
-            c_oracle.solve_batch(qcfg, x0[:4 * cores], ub[:4 * cores], stuck[:4 * cores], xref, nthreads=cores, **kw)
-            pilot = (time.perf_counter() - t1) / (4 * cores)
-            sample = int(min(B, max(8 * cores, 12.0 / max(pilot, 1e-6))))
-            t1 = time.perf_counter()
-            ref = c_oracle.solve_batch(qcfg, x0[:sample], ub[:sample], stuck[:sample], xref, nthreads=cores, **kw)
-            cpu_t = time.perf_counter() - t1
-            err = float(np.abs(ref["u0"] - u0_gpu[:sample]).max() / 3.4)
-            # the same port on ONE host thread (small sample, ~2 s)
-            n1 = int(min(sample, 2048))
-            t1 = time.perf_counter()
-            c_oracle.solve_batch(qcfg, x0[:n1], ub[:n1], stuck[:n1], xref, nthreads=1, **kw)
-            one_t = time.perf_counter() - t1
-            line["cpu_baseline"] = {"value": sample / cpu_t, "unit": "QP-steps/s", "cores": cores, "kind": "port",
-                                    "sample": f"first {sample} instances of the same batch, C float64 restatement "
-                                              f"(oracle/ftmpc_oracle.c), {cores} threads, {cpu_t:.1f} s; "
-                                              f"reference IPOPT path not runnable offline",
-                                    "gpu_vs_port_max_u0_err_over_fmax": err,
-                                    "single_thread": {"value": n1 / one_t, "unit": "QP-steps/s", "sample": f"first {n1} instances, 1 thread, {one_t:.1f} s"}}
+            line["cpu_baseline"] = cpu_baseline(N, NT, x0, ub, stuck, xref, u0_gpu, line["dtype"] == "f32")
         print(json.dumps(line))
     mpc.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
+    ap.add_argument("--horizon", type=int, default=20)
+    ap.add_argument("--thrusters", type=int, default=8)
+    ap.add_argument("--faults", type=int, default=2)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="arithmetic of the KKT/IPM solve")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        run_multi_inprocess(args)       # no launcher: fan out inside this process, before anything here touches a GPU
+    else:
+        run_rank(args)
 
 
 if __name__ == "__main__":

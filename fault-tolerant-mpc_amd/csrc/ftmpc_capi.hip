@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -56,6 +57,19 @@ struct ftmpc_handle {
     // per-instantiation Hessian slots
     float* hs[3] = {nullptr, nullptr, nullptr};   // NB = 8, 9, 10 instantiations
     int grid[3] = {0, 0, 0};
+    // work lists of the fp32 instantiations: qlist [3][cap_batch], qctl = {count[3], pad, head[3], pad}
+    int32_t* d_qlist = nullptr;
+    int32_t* d_qctl = nullptr;
+    // pinned staging of the host-buffer entry points (hipHostMalloc; mirrors of the device buffers)
+    struct Pinned {
+        void* p = nullptr;
+        size_t bytes = 0;
+    };
+    Pinned pin_in, pin_out;
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    static constexpr int MAX_CHUNKS = 8;
+    hipEvent_t ev_in[MAX_CHUNKS] = {}, ev_k[MAX_CHUNKS] = {}, ev_out[MAX_CHUNKS] = {};
+    int stage_chunks = 4;
     // float64 general-size path
     bool use_f64 = false;
     int npad_max = 0;
@@ -190,6 +204,11 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
     lp.uref = uref; lp.uref_stride = uref_stride;
     lp.warmU = warmU;
     lp.rec = h->rec;
+    const int nvar = h->use_f64 ? 0 : (h->nb_max <= 8 ? 1 : (h->nb_max == 9 ? 2 : 3));   // fp32 instantiations in use
+    lp.qlist = h->use_f64 ? nullptr : h->d_qlist;
+    lp.qcount = h->d_qctl;
+    lp.qvmax = nvar - 1;
+    if (!h->use_f64) HIP_TRY(h, hipMemsetAsync(h->d_qctl, 0, 8 * sizeof(int32_t), s));
     const int lin_blocks = (int)((B + 63) / 64);
     for (bool& u : h->ev_used) u = false;
     if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[0], s));
@@ -211,8 +230,9 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
         Solve64Params q;
         sp.hscratch = nullptr;
         sp.tile_words = 0;
-        sp.nb_lo = 0;
-        sp.nb_hi_owner = 1;
+        sp.qlist = nullptr;
+        sp.qcount = nullptr;
+        sp.qhead = nullptr;
         q.base = sp;
         q.Hs = h->Hs; q.Ls = h->Ls; q.Eall = h->Eall;
         q.tile_doubles = h->tile_doubles;
@@ -237,15 +257,16 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
         }
         return FTMPC_OK;
     }
-    // fp32 instantiations NB = 8, 9, 10: each owns the instances with nb_lo < ceil(n/16) <= NB
-    // (the first also the empty ones, the last reports shapes beyond every instantiation)
-    for (int v = 0; v < 3; ++v) {
+    // fp32 instantiations NB = 8, 9, 10: each pulls the instances with ceil(n/16) <= NB (the first also the empty
+    // ones, the last also shapes beyond every instantiation, which it reports) from the list the linearise kernel
+    // wrote for it; a launch whose list is empty returns at once
+    for (int v = 0; v < nvar; ++v) {
         const int NBv = 8 + v;
-        if (v > 0 && h->nb_max < NBv) break;
         sp.hscratch = h->hs[v];
         sp.tile_words = slot_words(NBv, h->dc.N);
-        sp.nb_lo = (v == 0) ? 0 : NBv - 1;
-        sp.nb_hi_owner = (h->nb_max <= NBv) ? 1 : 0;
+        sp.qlist = h->d_qlist + (int64_t)v * B;
+        sp.qcount = h->d_qctl + v;
+        sp.qhead = h->d_qctl + 4 + v;
         const int grid = (int)std::min<int64_t>(B, h->grid[v]);
         if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[2 + 2 * v], s));
         if (v == 0) hipLaunchKernelGGL(ftmpc::ftmpc_solve_f32_kernel<8>, dim3(grid), dim3(64), 0, s, h->dc, sp);
@@ -265,7 +286,7 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
 
 extern "C" {
 
-int32_t ftmpc_version(void) { return 100; }
+int32_t ftmpc_version(void) { return 200; }
 
 int ftmpc_default_config(ftmpc_config* cfg, int32_t N, int32_t NT) {
     if (!cfg || N < 1 || N > 64 || NT < 1 || NT > FTMPC_MAX_NT) return FTMPC_ERR_ARG;
@@ -364,6 +385,21 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
         return fail(nullptr, FTMPC_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
     for (int i = 0; i < 10; ++i) (void)hipEventCreate(&h->ev[i]);
+    bool sbad = hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking) != hipSuccess ||
+                hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking) != hipSuccess;
+    for (int i = 0; i < ftmpc_handle::MAX_CHUNKS; ++i)
+        sbad = sbad || hipEventCreateWithFlags(&h->ev_in[i], hipEventDisableTiming) != hipSuccess ||
+               hipEventCreateWithFlags(&h->ev_k[i], hipEventDisableTiming) != hipSuccess ||
+               hipEventCreateWithFlags(&h->ev_out[i], hipEventDisableTiming) != hipSuccess;
+    if (sbad || grow(h, &h->d_qctl, 8) != FTMPC_OK) {
+        g_create_error = "stream / event / work-list allocation failed";
+        ftmpc_destroy(h);
+        return FTMPC_ERR_HIP;
+    }
+    if (const char* e = std::getenv("FTMPC_STAGE_CHUNKS")) {
+        const int c = std::atoi(e);
+        if (c >= 1 && c <= ftmpc_handle::MAX_CHUNKS) h->stage_chunks = c;
+    }
     // persistent grids: resident workgroups per CU from the occupancy query (LDS-bound)
     int per[3] = {0, 0, 0};
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per[0], ftmpc::ftmpc_solve_f32_kernel<8>, 64, 0);
@@ -408,12 +444,21 @@ int ftmpc_destroy(ftmpc_handle* h) {
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->rec, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, h->d_uref, h->d_warm, h->d_u0, h->d_U,
                     h->d_status, h->d_iters, h->hs[0], h->hs[1], h->hs[2], h->d_dbgH, h->d_dbgv, h->Hs, h->Ls, h->Eall, h->d_dbgH64, h->d_dbgv64,
-                    h->d_atau, h->d_aub, h->d_au, h->d_ast, h->d_ait};
+                    h->d_atau, h->d_aub, h->d_au, h->d_ast, h->d_ait, h->d_qlist, h->d_qctl};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (h->pin_in.p) (void)hipHostFree(h->pin_in.p);
+    if (h->pin_out.p) (void)hipHostFree(h->pin_out.p);
     for (int i = 0; i < 10; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    for (int i = 0; i < ftmpc_handle::MAX_CHUNKS; ++i) {
+        if (h->ev_in[i]) (void)hipEventDestroy(h->ev_in[i]);
+        if (h->ev_k[i]) (void)hipEventDestroy(h->ev_k[i]);
+        if (h->ev_out[i]) (void)hipEventDestroy(h->ev_out[i]);
+    }
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->s_in) (void)hipStreamDestroy(h->s_in);
+    if (h->s_out) (void)hipStreamDestroy(h->s_out);
     delete h;
     return FTMPC_OK;
 }
@@ -440,6 +485,7 @@ int ftmpc_reserve(ftmpc_handle* h, int64_t max_batch) {
     if ((rc = grow(h, &h->d_U, B * N * NT)) != FTMPC_OK) return rc;
     if ((rc = grow(h, &h->d_status, B)) != FTMPC_OK) return rc;
     if ((rc = grow(h, &h->d_iters, B)) != FTMPC_OK) return rc;
+    if (!h->use_f64 && (rc = grow(h, &h->d_qlist, 3 * B)) != FTMPC_OK) return rc;
     h->cap_batch = B;
     return FTMPC_OK;
 }
@@ -473,6 +519,22 @@ static int check_strides(ftmpc_handle* h, int64_t xref_stride, int64_t uref_stri
     return FTMPC_OK;
 }
 
+static int pin_grow(ftmpc_handle* h, ftmpc_handle::Pinned& P, size_t bytes) {
+    if (bytes <= P.bytes) return FTMPC_OK;
+    if (P.p) (void)hipHostFree(P.p);
+    P.p = nullptr;
+    P.bytes = 0;
+    const size_t want = bytes + bytes / 8;
+    hipError_t e = hipHostMalloc(&P.p, want, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(h, FTMPC_ERR_ALLOC, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    P.bytes = want;
+    return FTMPC_OK;
+}
+
+// Host-buffer entry: the caller's (pageable) arrays go through PINNED staging buffers in up to `stage_chunks`
+// contiguous instance ranges, each on its way independently: host copy -> H2D on the input stream -> kernels on
+// the compute stream -> D2H on the output stream -> host copy, so that the copies of one range run under the
+// kernels of its neighbours (pinned staging, async H2D -> kernel -> D2H).
 int ftmpc_solve_batch(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, const double* stuck,
                       const double* xref, int64_t xref_stride, const double* uref, int64_t uref_stride,
                       double* warmU, double* out_u0, double* out_U, int32_t* status, int32_t* iters) {
@@ -484,22 +546,76 @@ int ftmpc_solve_batch(ftmpc_handle* h, int64_t B, const double* x0, const double
     HIP_TRY(h, hipSetDevice(h->device));
     if ((rc = ftmpc_reserve(h, B)) != FTMPC_OK) return rc;
     const int N = h->cfg.N, NT = h->cfg.NT;
-    hipStream_t s = h->stream;
-    HIP_TRY(h, hipMemcpyAsync(h->d_x0, x0, B * 13 * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(h, hipMemcpyAsync(h->d_ub, ub, B * NT * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(h, hipMemcpyAsync(h->d_stuck, stuck, B * NT * sizeof(double), hipMemcpyHostToDevice, s));
-    if ((rc = stage_refs(h, B, xref, xref_stride, uref, uref_stride)) != FTMPC_OK) return rc;
-    if (warmU) HIP_TRY(h, hipMemcpyAsync(h->d_warm, warmU, B * N * NT * sizeof(double), hipMemcpyHostToDevice, s));
+    const int64_t nw = (int64_t)N * NT;
     const bool wantU = out_U != nullptr || warmU != nullptr;
-    rc = enqueue(h, B, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, xref_stride, uref ? h->d_uref : nullptr, uref_stride,
-                 warmU ? h->d_warm : nullptr, h->d_u0, wantU ? h->d_U : nullptr, h->d_status, h->d_iters, s, -1);
-    if (rc != FTMPC_OK) return rc;
-    HIP_TRY(h, hipMemcpyAsync(out_u0, h->d_u0, B * NT * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (out_U) HIP_TRY(h, hipMemcpyAsync(out_U, h->d_U, B * N * NT * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (warmU) HIP_TRY(h, hipMemcpyAsync(warmU, h->d_U, B * N * NT * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (status) HIP_TRY(h, hipMemcpyAsync(status, h->d_status, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (iters) HIP_TRY(h, hipMemcpyAsync(iters, h->d_iters, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(h, hipStreamSynchronize(s));
+    // reference windows on the device (shared: once; per instance: with the ranges below)
+    const int64_t nxr = xref_stride == 0 ? 9 * (N + 1) : B * xref_stride;
+    const int64_t nur = !uref ? 0 : (uref_stride == 0 ? 6 * (N + 1) : B * uref_stride);
+    if (nxr > h->cap_xref) {
+        if ((rc = grow(h, &h->d_xref, nxr)) != FTMPC_OK) return rc;
+        h->cap_xref = nxr;
+    }
+    if (nur > h->cap_uref) {
+        if ((rc = grow(h, &h->d_uref, nur)) != FTMPC_OK) return rc;
+        h->cap_uref = nur;
+    }
+    // pinned mirrors: inputs [x0 | ub | stuck | warm | xref | uref], outputs [u0 | U | status | iters]
+    const int64_t o_x0 = 0, o_ub = o_x0 + B * 13, o_st = o_ub + B * NT, o_wm = o_st + B * NT, o_xr = o_wm + (warmU ? B * nw : 0),
+                  o_ur = o_xr + nxr, in_words = o_ur + nur;
+    const int64_t p_u0 = 0, p_U = p_u0 + B * NT, out_words = p_U + (wantU ? B * nw : 0);
+    if ((rc = pin_grow(h, h->pin_in, (size_t)in_words * 8)) != FTMPC_OK) return rc;
+    if ((rc = pin_grow(h, h->pin_out, (size_t)out_words * 8 + (size_t)B * 8)) != FTMPC_OK) return rc;
+    double* pin = static_cast<double*>(h->pin_in.p);
+    double* pout = static_cast<double*>(h->pin_out.p);
+    int32_t* pst = reinterpret_cast<int32_t*>(pout + out_words);
+    int32_t* pit = pst + B;
+    int nch = (int)std::min<int64_t>(h->stage_chunks, (B + 16383) / 16384);
+    if (nch < 1) nch = 1;
+    int64_t edge[ftmpc_handle::MAX_CHUNKS + 1];
+    for (int c = 0; c <= nch; ++c) edge[c] = (c == nch) ? B : ((B * c / nch) / 64) * 64;
+    auto up = [&](double* dst_dev, int64_t poff, const double* src, int64_t off, int64_t cnt) -> hipError_t {
+        std::memcpy(pin + poff + off, src + off, (size_t)cnt * 8);
+        return hipMemcpyAsync(dst_dev + off, pin + poff + off, (size_t)cnt * 8, hipMemcpyHostToDevice, h->s_in);
+    };
+    for (int c = 0; c < nch; ++c) {
+        const int64_t lo = edge[c], cnt = edge[c + 1] - edge[c];
+        if (cnt <= 0) {
+            HIP_TRY(h, hipEventRecord(h->ev_out[c], h->s_out));
+            continue;
+        }
+        HIP_TRY(h, up(h->d_x0, o_x0, x0, lo * 13, cnt * 13));
+        HIP_TRY(h, up(h->d_ub, o_ub, ub, lo * NT, cnt * NT));
+        HIP_TRY(h, up(h->d_stuck, o_st, stuck, lo * NT, cnt * NT));
+        if (warmU) HIP_TRY(h, up(h->d_warm, o_wm, warmU, lo * nw, cnt * nw));
+        if (xref_stride != 0) HIP_TRY(h, up(h->d_xref, o_xr, xref, lo * xref_stride, cnt * xref_stride));
+        else if (c == 0) HIP_TRY(h, up(h->d_xref, o_xr, xref, 0, nxr));
+        if (uref && uref_stride != 0) HIP_TRY(h, up(h->d_uref, o_ur, uref, lo * uref_stride, cnt * uref_stride));
+        else if (uref && c == 0) HIP_TRY(h, up(h->d_uref, o_ur, uref, 0, nur));
+        HIP_TRY(h, hipEventRecord(h->ev_in[c], h->s_in));
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_in[c], 0));
+        rc = enqueue(h, cnt, h->d_x0 + lo * 13, h->d_ub + lo * NT, h->d_stuck + lo * NT, h->d_xref + lo * xref_stride, xref_stride,
+                     uref ? h->d_uref + lo * uref_stride : nullptr, uref_stride, warmU ? h->d_warm + lo * nw : nullptr,
+                     h->d_u0 + lo * NT, wantU ? h->d_U + lo * nw : nullptr, h->d_status + lo, h->d_iters + lo, h->stream, -1);
+        if (rc != FTMPC_OK) return rc;
+        HIP_TRY(h, hipEventRecord(h->ev_k[c], h->stream));
+        HIP_TRY(h, hipStreamWaitEvent(h->s_out, h->ev_k[c], 0));
+        HIP_TRY(h, hipMemcpyAsync(pout + p_u0 + lo * NT, h->d_u0 + lo * NT, (size_t)cnt * NT * 8, hipMemcpyDeviceToHost, h->s_out));
+        if (wantU) HIP_TRY(h, hipMemcpyAsync(pout + p_U + lo * nw, h->d_U + lo * nw, (size_t)cnt * nw * 8, hipMemcpyDeviceToHost, h->s_out));
+        if (status) HIP_TRY(h, hipMemcpyAsync(pst + lo, h->d_status + lo, (size_t)cnt * 4, hipMemcpyDeviceToHost, h->s_out));
+        if (iters) HIP_TRY(h, hipMemcpyAsync(pit + lo, h->d_iters + lo, (size_t)cnt * 4, hipMemcpyDeviceToHost, h->s_out));
+        HIP_TRY(h, hipEventRecord(h->ev_out[c], h->s_out));
+    }
+    for (int c = 0; c < nch; ++c) {
+        const int64_t lo = edge[c], cnt = edge[c + 1] - edge[c];
+        HIP_TRY(h, hipEventSynchronize(h->ev_out[c]));
+        if (cnt <= 0) continue;
+        std::memcpy(out_u0 + lo * NT, pout + p_u0 + lo * NT, (size_t)cnt * NT * 8);
+        if (out_U) std::memcpy(out_U + lo * nw, pout + p_U + lo * nw, (size_t)cnt * nw * 8);
+        if (warmU) std::memcpy(warmU + lo * nw, pout + p_U + lo * nw, (size_t)cnt * nw * 8);
+        if (status) std::memcpy(status + lo, pst + lo, (size_t)cnt * 4);
+        if (iters) std::memcpy(iters + lo, pit + lo, (size_t)cnt * 4);
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     return FTMPC_OK;
 }
 
@@ -734,3 +850,5 @@ int ftmpc_debug_read_stamps(ftmpc_handle* h, int64_t count, unsigned long long* 
 #endif
 
 }  // extern "C"
+
+#include "ftmpc_multi.hip"

@@ -78,6 +78,12 @@ struct LinParams {
     int64_t uref_stride;
     const double* warmU;    // [B*N*NT] or nullptr
     void* rec;              // [B*N*REC_STRIDE] float or double
+    // work lists of the fp32 solve instantiations (nullptr: not built).  Instance b goes to list
+    // v = clamp(ceil(N*na/16), 8, 8 + qvmax) - 8 (na = healthy thrusters; na = 0 -> list 0):
+    // qlist[v*B + i], i < qcount[v].  The counters are zeroed by the host before the launch.
+    int32_t* qlist;
+    int32_t* qcount;        // [3]
+    int32_t qvmax;          // last instantiation this handle launches (0..2)
 };
 
 struct SolveParams {
@@ -92,11 +98,12 @@ struct SolveParams {
     int32_t* iters;         // or nullptr
     float* hscratch;        // [gridDim.x * tile_words] per-workgroup Hessian slot
     int64_t tile_words;     // words per slot
-    // instance routing between instantiations: this launch owns instances with
-    // nb_lo < ceil(N*na/16) <= NB; the launch with nb_hi_owner != 0 also reports shapes
-    // beyond every instantiation (status 2)
-    int32_t nb_lo;
-    int32_t nb_hi_owner;
+    // work list of this launch, written by the linearise kernel (LinParams::qlist): the waves pull
+    // instance numbers from it through the shared cursor *qhead until *qcount are handed out, so a
+    // launch whose list is empty returns at once and slow instances do not leave a static tail
+    const int32_t* qlist;
+    const int32_t* qcount;
+    int32_t* qhead;
     // debug dump (test hook): instance dbg_inst writes its QP here; -1 = off
     int64_t dbg_inst;
     float* dbg_H;           // [npad*npad] row-major

@@ -172,6 +172,24 @@ __global__ void __launch_bounds__(64) ftmpc_linearize_kernel(const DeviceConsts 
         ubv[i] = P.ub[b * NT + i];
         stk[i] = P.stuck[b * NT + i];
     }
+    // ---- work lists of the fp32 solve instantiations: one atomic per wave and list ----
+    if (P.qlist) {
+        int na = 0;
+        for (int i = 0; i < NT; ++i) na += (ubv[i] > 0.0) ? 1 : 0;
+        const int nbk = (N * na + 15) >> 4;
+        int v = (na == 0 || nbk <= 8) ? 0 : nbk - 8;
+        v = v > P.qvmax ? P.qvmax : v;
+        const bool real = b0 + lane < P.B;
+        for (int vv = 0; vv <= P.qvmax; ++vv) {
+            const unsigned long long m = __ballot(real && v == vv);
+            if (m == 0ull) continue;
+            const int leader = __ffsll((long long)m) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(P.qcount + vv, __popcll(m));
+            base = __builtin_amdgcn_readlane(base, leader);
+            if (real && v == vv) P.qlist[(int64_t)vv * P.B + base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)b;
+        }
+    }
     const double* xref = P.xref + b * P.xref_stride;
     const double* uref = P.uref ? P.uref + b * P.uref_stride : nullptr;
     const double dt = C.dt;

@@ -861,7 +861,20 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
 #pragma unroll
     for (int g = 0; g < 6; ++g) Rf[g] = (float)C.R[g];
 
-    for (int64_t inst = blockIdx.x; inst < P.B; inst += gridDim.x) {
+    // the waves pull their instances from this launch's work list (ftmpc_linearize.hip) through a shared cursor; the
+    // next number is requested while the current instance is being solved
+    auto pull = [&]() {
+        int i = 0;
+        if (lane == 0) i = atomicAdd(P.qhead, 1);
+        return i;
+    };
+    const int qn = *P.qcount;
+    int qnext = pull();
+    for (;;) {
+        const int qi = __builtin_amdgcn_readfirstlane(qnext);
+        if (qi >= qn) break;
+        const int64_t inst = P.qlist[qi];
+        qnext = pull();
         STAMP_DECL;
         STAMP_START();
         wave_lds_fence();
@@ -874,8 +887,6 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
         const int nb = (n + 15) >> 4;
         const int npad = nb * 16;
         (void)npad;
-        if (nb <= P.nb_lo && !(na == 0 && P.nb_lo == 0)) continue;  // another instantiation's instance
-        if (nb > NB && P.nb_hi_owner == 0) continue;
         if (na == 0 || nb > NB) {  // nothing to optimise / shape not supported by any instantiation
             if (lane < NT) P.out_u0[inst * NT + lane] = 0.0;
             if (P.out_U)

@@ -21,6 +21,9 @@ SYMBOLS = (
     "ftmpc_default_config", "ftmpc_create", "ftmpc_destroy", "ftmpc_last_error", "ftmpc_reserve",
     "ftmpc_solve_batch", "ftmpc_solve_batch_device", "ftmpc_simulate_batch", "ftmpc_allocate_batch", "ftmpc_shift_warm", "ftmpc_set_profiling",
     "ftmpc_last_kernel_ms", "ftmpc_kernel_name", "ftmpc_debug_build_qp", "ftmpc_version",
+    "ftmpc_multi_create", "ftmpc_multi_destroy", "ftmpc_multi_last_error", "ftmpc_multi_device_count",
+    "ftmpc_multi_shard_bounds", "ftmpc_multi_solve_batch", "ftmpc_multi_upload", "ftmpc_multi_step",
+    "ftmpc_multi_download", "ftmpc_multi_set_profiling", "ftmpc_multi_last_kernel_ms",
 )
 
 
@@ -87,8 +90,22 @@ def load_library() -> C.CDLL:
     lib.ftmpc_debug_build_qp.argtypes = [vp, C.c_int64, dp, dp, dp, dp, C.c_int64, dp, C.c_int64, dp, C.c_int64,
                                          dp, C.c_int64, dp, dp, dp, ip]
     lib.ftmpc_version.restype = C.c_int32
+    lib.ftmpc_multi_create.argtypes = [C.POINTER(ftmpc_config), ip, C.c_int32, C.POINTER(vp)]
+    lib.ftmpc_multi_destroy.argtypes = [vp]
+    lib.ftmpc_multi_last_error.argtypes = [vp]
+    lib.ftmpc_multi_last_error.restype = C.c_char_p
+    lib.ftmpc_multi_device_count.argtypes = [vp]
+    lib.ftmpc_multi_device_count.restype = C.c_int32
+    lib.ftmpc_multi_shard_bounds.argtypes = [vp, C.c_int64, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.ftmpc_multi_solve_batch.argtypes = [vp, C.c_int64, dp, dp, dp, dp, C.c_int64, dp, C.c_int64, dp, dp, dp, ip, ip]
+    lib.ftmpc_multi_upload.argtypes = [vp, C.c_int64, dp, dp, dp, dp, C.c_int64, dp, C.c_int64, dp]
+    lib.ftmpc_multi_step.argtypes = [vp, C.c_int32, C.c_int32]
+    lib.ftmpc_multi_download.argtypes = [vp, dp, dp, ip, ip]
+    lib.ftmpc_multi_set_profiling.argtypes = [vp, C.c_int32]
+    lib.ftmpc_multi_last_kernel_ms.argtypes = [vp, C.c_int32, C.POINTER(C.c_float)]
     for name in SYMBOLS:
-        if name not in ("ftmpc_last_error", "ftmpc_kernel_name", "ftmpc_version"):
+        if name not in ("ftmpc_last_error", "ftmpc_kernel_name", "ftmpc_version", "ftmpc_multi_last_error",
+                        "ftmpc_multi_device_count"):
             getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib

@@ -53,12 +53,11 @@ class BatchedMPC:
     """One handle == one GPU.  Not re-entrant (like the reference controller, which keeps its
     warm start in `self.optimal_solution`); use one instance per host thread / GPU."""
 
-    def __init__(self, cfg: MPCConfig | None = None, **kw):
-        cfg = cfg or MPCConfig(**kw)
-        self.cfg = cfg
-        self.lib = _lib.load_library()
+    @staticmethod
+    def make_c_config(lib, cfg):
+        """MPCConfig -> the C struct of include/ftmpc.h (defaults from ftmpc_default_config)."""
         c = _lib.ftmpc_config()
-        rc = self.lib.ftmpc_default_config(C.byref(c), cfg.N, cfg.NT)
+        rc = lib.ftmpc_default_config(C.byref(c), cfg.N, cfg.NT)
         if rc != 0:
             raise _lib.FtmpcError(rc, "bad N/NT")
         c.dt, c.mass, c.rho, c.mu_stop = cfg.dt, cfg.mass, cfg.rho, cfg.mu_stop
@@ -73,7 +72,6 @@ class BatchedMPC:
         if D is None:
             raise ValueError("MPCConfig.D (6 x NT) is required for NT not in (8, 16)")
         D = _f64(D, (6, cfg.NT))
-        self.D = D
         flat = np.zeros(6 * _lib.MAX_NT)
         flat[:6 * cfg.NT] = D.reshape(-1)
         c.D[:] = list(flat)
@@ -84,6 +82,14 @@ class BatchedMPC:
         if cfg.r is not None:
             c.r[:] = list(_f64(cfg.r, 3))
         c.f_virt[:] = list(_f64(cfg.f_virt, 3))
+        return c
+
+    def __init__(self, cfg: MPCConfig | None = None, **kw):
+        cfg = cfg or MPCConfig(**kw)
+        self.cfg = cfg
+        self.lib = _lib.load_library()
+        c = self.make_c_config(self.lib, cfg)
+        self.D = np.array(list(c.D))[:6 * cfg.NT].reshape(6, cfg.NT)     # the struct packs D at row stride NT
         self.r = np.array(list(c.r))
         self.P = np.array(list(c.P)).reshape(9, 9)
         self._c = c

@@ -200,6 +200,44 @@ int ftmpc_debug_build_qp(ftmpc_handle* h, int64_t B,
                          double* H, int64_t H_cap, double* g, double* lo, double* hi,
                          int32_t* n_out);
 
+/*
+ * The batch axis across the GPUs of one node from ONE process.  The reference
+ * never couples instances (one controller object per vehicle, spiraling_mpc.py:288-317), so device g owns
+ * the contiguous range [B g / G, B (g+1) / G) (ftmpc_multi_shard_bounds); one host thread + one handle + one
+ * stream set per device, no collective, nothing on xGMI: every device reads its slice of the caller's arrays
+ * and writes its slice of the caller's outputs.
+ *   device_ids  NULL (devices 0..n_devices-1) or n_devices ordinals; an ordinal may repeat (several handles
+ *               on one GPU);  n_devices <= 0: every visible device.
+ * ftmpc_multi_solve_batch has the contract of ftmpc_solve_batch (host buffers, pinned staging per device).
+ * ftmpc_multi_upload keeps the shards RESIDENT in each device's HBM; ftmpc_multi_step then runs `steps` MPC
+ * steps over them on every device at once (keep_U != 0: the whole-horizon solution is kept too) and returns
+ * when all devices are idle; ftmpc_multi_download gathers u0 [B*NT], U [B*N*NT] (needs keep_U), status, iters
+ * (each may be NULL) on the host.
+ */
+typedef struct ftmpc_multi ftmpc_multi;
+int ftmpc_multi_create(const ftmpc_config* cfg, const int32_t* device_ids, int32_t n_devices, ftmpc_multi** out);
+int ftmpc_multi_destroy(ftmpc_multi* m);
+const char* ftmpc_multi_last_error(const ftmpc_multi* m); /* m may be NULL: last create error */
+int32_t ftmpc_multi_device_count(const ftmpc_multi* m);
+int ftmpc_multi_shard_bounds(const ftmpc_multi* m, int64_t B, int32_t slot, int64_t* lo, int64_t* hi);
+int ftmpc_multi_solve_batch(ftmpc_multi* m, int64_t B,
+                            const double* x0, const double* ub, const double* stuck,
+                            const double* xref, int64_t xref_stride,
+                            const double* uref, int64_t uref_stride,
+                            double* warmU,
+                            double* out_u0, double* out_U,
+                            int32_t* status, int32_t* iters);
+int ftmpc_multi_upload(ftmpc_multi* m, int64_t B,
+                       const double* x0, const double* ub, const double* stuck,
+                       const double* xref, int64_t xref_stride,
+                       const double* uref, int64_t uref_stride,
+                       const double* warmU);
+int ftmpc_multi_step(ftmpc_multi* m, int32_t steps, int32_t keep_U);
+int ftmpc_multi_download(ftmpc_multi* m, double* out_u0, double* out_U, int32_t* status, int32_t* iters);
+/* per-kernel device timing of device slot `slot` (see ftmpc_set_profiling / ftmpc_last_kernel_ms) */
+int ftmpc_multi_set_profiling(ftmpc_multi* m, int32_t enabled);
+int ftmpc_multi_last_kernel_ms(ftmpc_multi* m, int32_t slot, float ms[5]);
+
 /* Library/ABI version: major*10000 + minor*100 + patch. */
 int32_t ftmpc_version(void);
 

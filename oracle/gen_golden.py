@@ -111,6 +111,35 @@ def reference_fixtures():
     print("reference_pins.npz:", {k: v.shape for k, v in out.items()})
 
 
+def sim_env_fixture():
+    """The reference's own SimulationEnvironment (ft_mpc/simulation/sim_env.py:11-112; imports without
+    casadi) driving the mirror's duck-typed SystemModel + dummy controller for 1 s with the noise switched
+    off: pins set_initial_state, the step order (control -> dynamics -> noise -> renormalise) and the
+    loop count of run_simulation.  tests/test_host_mirror.py compares the mirror's loop with it."""
+    sys.path.insert(0, str(REF))
+    sys.path.insert(0, str(ROOT / "fault-tolerant-mpc_amd"))
+    from ft_mpc.simulation.sim_env import SimulationEnvironment as RefEnv
+    from ft_mpc_amd.controllers.dummy_controller import Controller
+    from ft_mpc_amd.models.sys_model import SystemModel
+    from ft_mpc_amd.util.controller_debug import ControllerDebug
+    from scipy.spatial.transform import Rotation as R
+
+    q = R.from_euler("zyx", [50, 30, -10], degrees=True).as_quat()
+    out = {}
+    for name, dur in (("1s", 1.0), ("2p5s", 2.5)):
+        m = SystemModel(0.1)
+        env = RefEnv(m, Controller(m, ControllerDebug()))
+        env.set_initial_state(position=[1, 0, 1], velocity=[1, .5, 0], orientation=q, angular_velocity=[.3, .8, -.1])
+        x_init = np.array(env.state, float).reshape(-1).copy()
+        for k in env.noise:
+            env.noise[k] = 0.0
+        env.run_simulation(dur)
+        out["state_" + name] = np.array(env.state, float).reshape(-1)
+        out["init_" + name] = x_init
+    np.savez_compressed(OUT / "sim_env_pin.npz", **out)
+    print("sim_env_pin.npz:", {k: v.shape for k, v in out.items()})
+
+
 def qp_fixtures():
     from oracle import qp_oracle as qo
     from oracle import refmath as rm
@@ -152,4 +181,5 @@ def qp_fixtures():
 if __name__ == "__main__":
     OUT.mkdir(parents=True, exist_ok=True)
     reference_fixtures()
+    sim_env_fixture()
     qp_fixtures()

@@ -1,6 +1,8 @@
 """Turns gpurun_out/<tag>/ (scripts/profile_round.sh) into the committed profiles/<tag>_* files."""
 import collections, csv, glob, json, shutil, sys
 from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from bench import csrc_hash
 tag = sys.argv[1]
 src = Path("gpurun_out") / tag
 dst = Path("profiles")
@@ -27,6 +29,7 @@ if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
     cfg = bench["config"]
     (dst / "traffic_latest.json").write_text(json.dumps({
         "kernel": dom, "batch": cfg["batch_per_gpu"], "horizon": cfg["horizon"], "thrusters": cfg["thrusters"],
+        "csrc_sha": csrc_hash(),   # bench.py quotes this figure only for the kernel sources it was measured on
         "bytes_per_launch": b, "fetch_size_kib": pm["FETCH_SIZE"], "write_size_kib": pm["WRITE_SIZE"],
         "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; (2*FETCH+WRITE)*1024)"}, indent=1))
 print(json.dumps({dom: pm}, indent=1))

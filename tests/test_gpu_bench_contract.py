@@ -43,3 +43,19 @@ def test_two_ranks_on_one_gpu():
     j = _last_json(r.stdout)
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and "cpu_baseline" not in j
     assert j["value"] > 1e5
+
+
+def test_gpus_flag_without_a_launcher_fans_out_in_process():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset: the process drives both device slots itself through the
+    library's multi-GPU driver (both on device 0 here) and prints the one JSON line, strong-scaling keys included."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["FTMPC_BENCH_SINGLE_DEVICE"] = "1"
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8192"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _last_json(r.stdout)
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["launcher"].startswith("in-process")
+    assert j["value"] > 1e5 and j["config"]["not_converged"] == 0 and 0 < j["roofline"]["frac"] < 1
+    assert set(j["strong_scaling"]) == {"65536", "262144"}
+    for s in j["strong_scaling"].values():
+        assert s["value"] > 1e5 and s["parallel_efficiency"] > 0

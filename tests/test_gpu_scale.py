@@ -1,0 +1,193 @@
+"""GPU parity at scale: the cases a small batch cannot reach.
+  * the float64 kernel's persistent loop (`inst += gridDim.x`, ftmpc_solve_f64.hip): every instantiation with
+    B >= 2 x its resident grid, so each workgroup re-uses its Hessian / factor / panel slots for later instances
+    (BASELINE configs[4] shard, the reference vehicle of reactive.yaml:26, and n > 640);
+  * per-instance reference windows (xref_stride / uref_stride != 0) on both entry points;
+  * BASELINE configs[2] at its full 65 536 instances;
+  * BASELINE configs[3] (262 144 instances) through ft_mpc_amd.sharding.solve_sharded around the HIP path, two
+    ranks on one device, bitwise equal to the unsharded call.
+Checker: oracle/ftmpc_oracle.c converged to mu 1e-13.  Tolerances: float64 path 1e-7 f_max, fp32 path 1e-4 f_max.
+"""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from oracle import qp_oracle as qo
+from oracle import refmath as rm
+
+pytestmark = pytest.mark.gpu
+F_MAX = rm.F_MAX
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _threads():
+    return max(1, min(16, len(os.sched_getaffinity(0))))
+
+
+def _check_f64(mpc, cfg, x0, ub, stuck, xref):
+    out = mpc.solve(x0, ub, stuck, xref.reshape(-1, order="F"), return_U=True)
+    assert (out["status"] == 0).all(), np.bincount(out["status"])
+    ref = co.solve_batch(cfg, x0, ub, stuck, xref, nthreads=_threads(), max_iters=60)
+    assert (ref["status"] == 0).all()
+    err = np.abs(out["u0"] - ref["u0"]).max(axis=1) / F_MAX
+    assert err.max() <= 1e-7, (err.max(), int(err.argmax()))
+    assert np.abs(out["U"] - ref["U"]).max() / F_MAX <= 1e-6
+    assert (out["u0"][ub == 0] == 0).all()
+    return out
+
+
+def test_f64_persistent_loop_reference_vehicle(gpu_mpc_factory):
+    """<4,1> (n <= 256): N=15, 16 thrusters, two random faults (n = 210), B = 4096 = 8..16 instances per workgroup."""
+    N, NT, B = 15, 16, 4096
+    mpc = gpu_mpc_factory(N=N, NT=NT, max_iters=40)
+    x0, ub, stuck, xref = qo.make_batch(B, N, NT, 2, 5101)
+    out = _check_f64(mpc, qo.QPConfig(N=N, NT=NT), x0, ub, stuck, xref)
+    assert out["iters"].max() <= 40
+
+
+def test_f64_persistent_loop_config5_shard(gpu_mpc_factory):
+    """<10,3> (n <= 640): BASELINE configs[4] shard, N=40, 16 thrusters, two faults (n = 560), 2048 per GPU."""
+    N, NT, B = 40, 16, 2048
+    mpc = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40)
+    x0, ub, stuck, xref = qo.make_batch(B, N, NT, 2, 1005)
+    _check_f64(mpc, qo.QPConfig(N=N, NT=NT), x0, ub, stuck, xref)
+
+
+def test_f64_persistent_loop_beyond_640(gpu_mpc_factory):
+    """<10,4> (n <= 1024): N=44, all 16 thrusters healthy (n = 704), B = 640 > 2 x 256 workgroups."""
+    N, NT, B = 44, 16, 640
+    mpc = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40)
+    x0, ub, stuck, xref = qo.make_batch(B, N, NT, 0, 5103)
+    _check_f64(mpc, qo.QPConfig(N=N, NT=NT), x0, ub, stuck, xref)
+
+
+def _windows(B, N, seed):
+    """Per-instance reference windows: every instance tracks its own stretch of a circle trajectory
+    (get_trajectory.py:125-141 shape) -- different xref AND a non-zero uref per instance."""
+    traj = rm.circle_trajectory(0.1, 40, radius=0.65, s_per_circle=40.0)
+    xr_all, ur_all = rm.assign_trajectory(traj, N)
+    rng = np.random.default_rng(seed)
+    t0 = rng.integers(0, 300, B)
+    xr = np.zeros((B, 9 * (N + 1)))
+    ur = np.zeros((B, 6 * (N + 1)))
+    for b in range(B):
+        xw, uw = rm.trajectory_window(xr_all, ur_all, 0.1 * int(t0[b]), N)
+        xr[b] = xw.reshape(-1, order="F")
+        ur[b] = uw.reshape(-1, order="F")
+    return xr, ur
+
+
+@pytest.mark.parametrize("N,NT,dtype,tol", [(20, 8, "f32", 1e-4), (15, 16, "f32", 1e-7)])
+def test_per_instance_reference_strides_host_and_device_entry(gpu_mpc_factory, N, NT, dtype, tol):
+    """xref_stride = 9(N+1) (+ padding), uref_stride = 6(N+1) (+ padding) on ftmpc_solve_batch and on
+    ftmpc_solve_batch_device, fp32 kernels (N=20, NT=8) and the float64 kernel (N=15, NT=16: n > 160)."""
+    import torch
+    B = 192
+    mpc = gpu_mpc_factory(N=N, NT=NT, dtype=dtype, max_iters=40)
+    x0, ub, stuck, _ = qo.make_batch(B, N, NT, 2, 5200 + N)
+    xr, ur = _windows(B, N, 5300 + N)
+    cfg = qo.QPConfig(N=N, NT=NT)
+    ref = co.solve_batch(cfg, x0, ub, stuck, xr, uref=ur, nthreads=_threads(), max_iters=60)
+    assert (ref["status"] == 0).all()
+    # the windows really differ between instances, and a shared window gives a different answer
+    shared = co.solve_batch(cfg, x0, ub, stuck, xr[0].reshape(9, N + 1, order="F"), uref=ur[0].reshape(6, N + 1, order="F"),
+                            nthreads=_threads(), max_iters=60)
+    assert np.abs(shared["u0"] - ref["u0"]).max() / F_MAX > 1e-3
+    out = mpc.solve(x0, ub, stuck, xr, uref=ur, return_U=True)
+    assert (out["status"] == 0).all()
+    assert np.abs(out["u0"] - ref["u0"]).max() / F_MAX <= tol
+    # padded strides (stride > window length) through the device-pointer entry
+    xs, us = 9 * (N + 1) + 5, 6 * (N + 1) + 3
+    xp = np.full((B, xs), np.nan); xp[:, :9 * (N + 1)] = xr
+    up = np.full((B, us), np.nan); up[:, :6 * (N + 1)] = ur
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_x0, d_ub, d_st, d_xr, d_ur = t(x0), t(ub), t(stuck), t(xp), t(up)
+    d_u0 = torch.zeros(B, NT, dtype=torch.float64, device=dev)
+    d_status = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    d_iters = torch.zeros(B, dtype=torch.int32, device=dev)
+    mpc.solve_device(B, d_x0.data_ptr(), d_ub.data_ptr(), d_st.data_ptr(), d_xr.data_ptr(), xs, d_ur.data_ptr(), us, 0,
+                     d_u0.data_ptr(), 0, d_status.data_ptr(), d_iters.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert (d_status.cpu().numpy() == 0).all()
+    assert np.array_equal(d_u0.cpu().numpy(), out["u0"])
+    # bad strides are refused, not read out of bounds
+    import ft_mpc_amd
+    with pytest.raises(ft_mpc_amd.FtmpcError):
+        mpc.solve_device(B, d_x0.data_ptr(), d_ub.data_ptr(), d_st.data_ptr(), d_xr.data_ptr(), 9 * (N + 1) - 1, 0, 0, 0,
+                         d_u0.data_ptr(), 0, d_status.data_ptr(), d_iters.data_ptr(), 0)
+
+
+def test_config3_full_batch_against_the_c_oracle(gpu_mpc_factory):
+    """BASELINE configs[2] at its full size: 65 536 random double-fault instances, N=20, 8 thrusters, fp32 kernel
+    (what bench.py times), every instance against the C oracle: u0 <= 1e-4 f_max."""
+    N, NT, B = 20, 8, 65536
+    mpc = gpu_mpc_factory(N=N, NT=NT)
+    x0, ub, stuck, xref = qo.make_batch(B, N, NT, 2, 1003)
+    out = mpc.solve(x0, ub, stuck, xref.reshape(-1, order="F"))
+    assert (out["status"] == 0).all(), np.bincount(out["status"])
+    ref = co.solve_batch(qo.QPConfig(N=N, NT=NT), x0, ub, stuck, xref, nthreads=_threads(), max_iters=60, mu_stop=1e-13,
+                         return_U=False)
+    assert (ref["status"] == 0).all()
+    err = np.abs(out["u0"] - ref["u0"]).max(axis=1) / F_MAX
+    assert err.max() <= 1e-4, (err.max(), int(err.argmax()))
+    assert np.median(err) <= 1e-6
+    assert (out["u0"][ub == 0] == 0).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE configs[3]: 262 144 instances sharded over ranks (two ranks on the one device of this box)
+# ---------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shard_worker(rank, world, port, B, q):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "fault-tolerant-mpc_amd"))
+    import torch.distributed as dist
+    import ft_mpc_amd
+    from ft_mpc_amd.sharding import solve_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N, NT = 20, 8
+    x0, ub, stuck, xref = ft_mpc_amd.make_synthetic_batch(B, N, NT, 2, 1004)
+    xr = np.ascontiguousarray(xref.reshape(-1, order="F"))
+    mpc = ft_mpc_amd.BatchedMPC(N=N, NT=NT, device_id=0)     # both ranks on device 0 (a 1-GPU box)
+    fn = lambda a, b, c: mpc.solve(a, b, c, xr)
+    out = solve_sharded(fn, x0, ub, stuck, rank=rank, world=world, dist=dist)
+    dist.barrier()
+    if rank == 0:
+        full = mpc.solve(x0, ub, stuck, xr)
+        same = all(np.array_equal(out[k], full[k]) for k in ("u0", "status", "iters"))
+        q.put((same, out["u0"].shape, int((out["status"] != 0).sum()), float(out["iters"].mean())))
+    else:
+        assert out is None
+    mpc.close()
+    dist.destroy_process_group()
+
+
+def test_config4_sharded_hip_path_two_ranks_bitwise_equal_to_unsharded():
+    import torch.multiprocessing as mp
+    B = 262144
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, B, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    same, shape, bad, iters = q.get(timeout=600)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert same and shape == (B, 8) and bad == 0 and 8.0 < iters < 12.0

@@ -71,21 +71,23 @@ def test_trajectory_generator_against_reference_pins():
 
 
 def test_simulation_loop_with_dummy_controller_matches_reference_sim_env():
-    """The mirror's loop and (when /root/reference is present) the reference's own
-    SimulationEnvironment drive the same duck-typed model/controller to the same states."""
-    def run(env_cls, **kw):
+    """The mirror's loop against the committed capture of the reference's own SimulationEnvironment driving
+    the same duck-typed model/controller (tests/golden/sim_env_pin.npz, made by oracle/gen_golden.py:sim_env_fixture
+    in the build container; checked on every box, /root/reference is not read here)."""
+    pin = np.load(Path(__file__).parent / "golden" / "sim_env_pin.npz")
+
+    def run(dur):
         m = SystemModel(0.1)
-        env = env_cls(m, Controller(m, ControllerDebug()), **kw)
+        env = SimulationEnvironment(m, Controller(m, ControllerDebug()), seed=0)
         env.set_initial_state(position=[1, 0, 1], velocity=[1, .5, 0], orientation=G["ic_quat"], angular_velocity=[.3, .8, -.1])
+        x_init = np.array(env.state, float).reshape(-1).copy()
         for k in env.noise:
             env.noise[k] = 0.0
-        env.run_simulation(1.0)
-        return env.state
-    mine = run(SimulationEnvironment, seed=0)
-    assert abs(np.linalg.norm(mine[6:10]) - 1) < 1e-12 and mine[5] != 0   # thruster 12 pushes along -z
-    ref_root = Path("/root/reference")
-    if ref_root.exists():
-        import sys
-        sys.path.insert(0, str(ref_root))
-        from ft_mpc.simulation.sim_env import SimulationEnvironment as RefEnv   # imports without casadi
-        assert np.allclose(run(RefEnv), mine, atol=1e-13)
+        env.run_simulation(dur)
+        return x_init, np.array(env.state, float).reshape(-1)
+
+    for name, dur in (("1s", 1.0), ("2p5s", 2.5)):
+        x_init, mine = run(dur)
+        assert np.allclose(x_init, pin["init_" + name], atol=1e-15)
+        assert abs(np.linalg.norm(mine[6:10]) - 1) < 1e-12 and mine[5] != 0   # thruster 12 pushes along -z
+        assert np.allclose(mine, pin["state_" + name], atol=1e-13)

@@ -213,4 +213,17 @@ __global__ void __launch_bounds__(64) ftmpc_allocate_kernel(const DeviceConsts C
     if (P.iters) P.iters[b] = it;
 }
 
+// wrench the HEALTHY thrusters have to produce: tau_0 - D stuck (the reference's u_res = u + u_nom + u_comp,
+// spiraling_mpc.py:301-302, i.e. the total wrench minus the uncontrollable part D f_fault)
+__global__ void __launch_bounds__(256) ftmpc_healthy_wrench_kernel(const DeviceConsts C, int64_t B, const double* tau0, const double* stuck,
+                                                                  double* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * 6) return;
+    const int64_t b = i / 6;
+    const int g = (int)(i - 6 * b);
+    double t = tau0[i];
+    for (int k = 0; k < C.NT; ++k) t -= C.D[g * MAX_NT + k] * stuck[b * C.NT + k];
+    out[i] = t;
+}
+
 }  // namespace ftmpc

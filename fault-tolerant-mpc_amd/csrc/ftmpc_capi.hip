@@ -77,6 +77,17 @@ struct ftmpc_handle {
     int64_t tile_doubles = 0, e_doubles = 0;
     double *Hs = nullptr, *Ls = nullptr, *Eall = nullptr;
     double *d_dbgH64 = nullptr, *d_dbgv64 = nullptr;
+    // general-constraint modes of the float64 kernel (terminal set; generalized-force formulation)
+    bool tset = false;
+    double* d_term = nullptr;          // [term_rows*9 | term_rows]
+    double* d_eN = nullptr;            // [cap_batch*9]
+    int grid_gen = 0, npad_gen = 0;
+    int64_t tile_doubles_gen = 0, e_doubles_gen = 0;
+    double *gHs = nullptr, *gLs = nullptr, *gEall = nullptr;     // slots of the wrench formulation (n = 6 N)
+    double *d_hullA = nullptr, *d_hullb = nullptr, *d_warmG = nullptr, *d_tau0 = nullptr, *d_G = nullptr, *d_taud = nullptr;
+    int32_t* d_hullset = nullptr;
+    int32_t* d_ast2 = nullptr;
+    int64_t cap_hullA = 0, cap_wrench = 0;
     // debug
     float *d_dbgH = nullptr, *d_dbgv = nullptr;
     // profiling
@@ -174,6 +185,7 @@ int build_consts(const ftmpc_config& c, DeviceConsts& d, std::string& why) {
         for (int j = 0; j < 9; ++j) d.LPt[9 * i + j] = s2 * L[9 * j + i];  // sqrt(2) L'
     d.rho = c.rho;
     d.mu_stop = c.mu_stop > 0 ? c.mu_stop : ((c.dtype == FTMPC_DTYPE_F64 || c.N * c.NT > 160) ? 1e-13 : 1e-11);
+    if (c.terminal_set && !(c.mu_stop > 0)) d.mu_stop = 1e-10;   // general rows: C' W C ruins the conditioning below that
     d.mu_refine = 1e-3;
     return FTMPC_OK;
 }
@@ -204,6 +216,8 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
     lp.uref = uref; lp.uref_stride = uref_stride;
     lp.warmU = warmU;
     lp.rec = h->rec;
+    lp.warmG = nullptr;
+    lp.out_eN = h->tset ? h->d_eN : nullptr;
     const int nvar = h->use_f64 ? 0 : (h->nb_max <= 8 ? 1 : (h->nb_max == 9 ? 2 : 3));   // fp32 instantiations in use
     lp.qlist = h->use_f64 ? nullptr : h->d_qlist;
     lp.qcount = h->d_qctl;
@@ -241,9 +255,17 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
         q.nb_lo = 0;
         q.dbg_H = h->d_dbgH64;
         q.dbg_vec = h->d_dbgv64;
+        q.warmG = nullptr; q.hullA = nullptr; q.hull_set = nullptr; q.hullb = nullptr; q.out_tau0 = nullptr; q.out_G = nullptr;
+        q.hull_rows = 0;
+        q.termA = h->tset ? h->d_term : nullptr;
+        q.termb = h->tset ? h->d_term + (int64_t)h->cfg.term_rows * 9 : nullptr;
+        q.term_rows = h->tset ? h->cfg.term_rows : 0;
+        q.eN = h->d_eN;
         const int grid = (int)std::min<int64_t>(B, h->grid64);
         if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[8], s));
-        if (h->npad_max <= 256)
+        if (h->tset)
+            hipLaunchKernelGGL((ftmpc::ftmpc_solve_f64_kernel<4, 1, 2>), dim3(grid), dim3(ftmpc::f64k::WG), 0, s, h->dc, q);
+        else if (h->npad_max <= 256)
             hipLaunchKernelGGL((ftmpc::ftmpc_solve_f64_kernel<4, 1>), dim3(grid), dim3(ftmpc::f64k::WG), 0, s, h->dc, q);
         else if (h->npad_max <= 640)
             hipLaunchKernelGGL((ftmpc::ftmpc_solve_f64_kernel<ftmpc::f64k::RPF, 3>), dim3(grid), dim3(ftmpc::f64k::WG), 0, s, h->dc, q);
@@ -372,6 +394,17 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
     // fp32 LDS-resident kernels cover n <= 160; larger problems and dtype F64 use the float64
     // workgroup-per-instance kernel
     h->use_f64 = (cfg->dtype == FTMPC_DTYPE_F64) || h->nb_max > 10;
+    h->tset = cfg->terminal_set != 0;
+    if (h->tset) {
+        const char* why = nullptr;
+        if (cfg->term_rows < 1 || cfg->term_rows > FTMPC_MAX_TERM_ROWS) why = "term_rows out of range 1..80";
+        else if (cfg->dtype != FTMPC_DTYPE_F64) why = "terminal_set needs dtype FTMPC_DTYPE_F64 (the fp32 kernels solve the box-constrained QP only)";
+        else if (16 * h->nb_max > 256) why = "terminal_set needs N * NT <= 256";
+        if (why) {
+            delete h;
+            return fail(nullptr, FTMPC_ERR_ARG, why);
+        }
+    }
     h->npad_max = 16 * h->nb_max;
     h->device = cfg->device_id;
     h->num_cu = prop.multiProcessorCount;
@@ -415,15 +448,25 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per64, ftmpc::ftmpc_solve_f64_kernel<ftmpc::f64k::RPF, ftmpc::f64k::NVT_MAX>, ftmpc::f64k::WG, 0);
     if (per64 < 1) per64 = 1;
     if (per64 > 2) per64 = 2;
+    if (h->tset) per64 = 1;     // the general-constraint instantiations hold ~50 KiB of LDS and one workgroup per CU
     h->grid64 = h->num_cu * per64;
     h->tile_doubles = (int64_t)tiles_of(h->nb_max) * 256;
-    h->e_doubles = (int64_t)cfg->N * 9 * h->npad_max;
+    h->e_doubles = (int64_t)(cfg->N + 2) * 9 * h->npad_max;     // + raw terminal rows GN and the terminal-set panel
     bool bad = false;
     if (h->use_f64) {
         bad = grow(h, &h->Hs, h->grid64 * h->tile_doubles) != FTMPC_OK || grow(h, &h->Ls, h->grid64 * h->tile_doubles) != FTMPC_OK ||
               grow(h, &h->Eall, h->grid64 * h->e_doubles) != FTMPC_OK ||
               grow(h, &h->d_dbgH64, (int64_t)h->npad_max * h->npad_max) != FTMPC_OK ||
               grow(h, &h->d_dbgv64, 3 * (int64_t)h->npad_max + 4) != FTMPC_OK;
+        if (!bad && h->tset) {
+            bad = grow(h, &h->d_term, (int64_t)cfg->term_rows * 10) != FTMPC_OK;
+            if (!bad) {
+                std::vector<double> t((size_t)cfg->term_rows * 10);
+                std::memcpy(t.data(), cfg->term_A, (size_t)cfg->term_rows * 9 * sizeof(double));
+                std::memcpy(t.data() + (size_t)cfg->term_rows * 9, cfg->term_b, (size_t)cfg->term_rows * sizeof(double));
+                bad = hipMemcpy(h->d_term, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess;
+            }
+        }
     } else {
         bad = grow(h, &h->hs[0], (int64_t)h->grid[0] * slot_words(8, cfg->N)) != FTMPC_OK ||
               (h->nb_max > 8 && grow(h, &h->hs[1], (int64_t)h->grid[1] * slot_words(9, cfg->N)) != FTMPC_OK) ||
@@ -444,7 +487,8 @@ int ftmpc_destroy(ftmpc_handle* h) {
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->rec, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, h->d_uref, h->d_warm, h->d_u0, h->d_U,
                     h->d_status, h->d_iters, h->hs[0], h->hs[1], h->hs[2], h->d_dbgH, h->d_dbgv, h->Hs, h->Ls, h->Eall, h->d_dbgH64, h->d_dbgv64,
-                    h->d_atau, h->d_aub, h->d_au, h->d_ast, h->d_ait, h->d_qlist, h->d_qctl};
+                    h->d_atau, h->d_aub, h->d_au, h->d_ast, h->d_ait, h->d_qlist, h->d_qctl, h->d_term, h->d_eN, h->gHs, h->gLs,
+                    h->gEall, h->d_hullA, h->d_hullb, h->d_warmG, h->d_tau0, h->d_G, h->d_taud, h->d_hullset, h->d_ast2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->pin_in.p) (void)hipHostFree(h->pin_in.p);
@@ -486,6 +530,7 @@ int ftmpc_reserve(ftmpc_handle* h, int64_t max_batch) {
     if ((rc = grow(h, &h->d_status, B)) != FTMPC_OK) return rc;
     if ((rc = grow(h, &h->d_iters, B)) != FTMPC_OK) return rc;
     if (!h->use_f64 && (rc = grow(h, &h->d_qlist, 3 * B)) != FTMPC_OK) return rc;
+    if ((rc = grow(h, &h->d_eN, B * 9)) != FTMPC_OK) return rc;
     h->cap_batch = B;
     return FTMPC_OK;
 }
@@ -635,6 +680,131 @@ int ftmpc_solve_batch_device(ftmpc_handle* h, int64_t B, const double* x0, const
     }
     return enqueue(h, B, x0, ub, stuck, xref, xref_stride, uref, uref_stride, warmU, out_u0, out_U, status, iters,
                    reinterpret_cast<hipStream_t>(stream), -1);
+}
+
+int ftmpc_solve_wrench_batch(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, const double* stuck,
+                             const double* hull_A, int32_t n_sets, const int32_t* hull_set, const double* hull_b, int32_t hull_rows,
+                             const double* xref, int64_t xref_stride, const double* uref, int64_t uref_stride, double* warmG,
+                             double* out_u0, double* out_tau0, double* out_G, int32_t* status, int32_t* iters, int32_t* alloc_status) {
+    if (!h) return FTMPC_ERR_ARG;
+    if (B < 0 || !x0 || !ub || !stuck || !xref || !out_u0 || !hull_A || !hull_b)
+        return fail(h, FTMPC_ERR_ARG, "null buffer or negative batch");
+    if (B == 0) return FTMPC_OK;
+    const int N = h->cfg.N, NT = h->cfg.NT;
+    if (6 * N > 256) return fail(h, FTMPC_ERR_ARG, "the generalized-force formulation needs 6 N <= 256");
+    if (hull_rows < 1 || hull_rows > FTMPC_MAX_HULL_ROWS || (int64_t)N * hull_rows > 1024 || n_sets < 1)
+        return fail(h, FTMPC_ERR_ARG, "hull_rows out of range (1..32, N * hull_rows <= 1024) or no hull table");
+    if (h->cfg.terminal_set && (h->cfg.term_rows < 1 || h->cfg.term_rows > FTMPC_MAX_TERM_ROWS)) return fail(h, FTMPC_ERR_ARG, "term_rows out of range");
+    int rc = check_strides(h, xref_stride, uref_stride, uref);
+    if (rc != FTMPC_OK) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if ((rc = ftmpc_reserve(h, B)) != FTMPC_OK) return rc;
+    // per-workgroup slots of the 6N-variable problem (separate from the thruster-space slots of this handle)
+    if (!h->gHs) {
+        const int nbg = (6 * N + 15) / 16;
+        h->npad_gen = 16 * nbg;
+        h->grid_gen = h->num_cu;
+        h->tile_doubles_gen = (int64_t)tiles_of(nbg) * 256;
+        h->e_doubles_gen = (int64_t)(N + 2) * 9 * h->npad_gen;
+        if ((rc = grow(h, &h->gHs, h->grid_gen * h->tile_doubles_gen)) != FTMPC_OK || (rc = grow(h, &h->gLs, h->grid_gen * h->tile_doubles_gen)) != FTMPC_OK ||
+            (rc = grow(h, &h->gEall, h->grid_gen * h->e_doubles_gen)) != FTMPC_OK)
+            return rc;
+        if (h->cfg.terminal_set && !h->d_term) {
+            if ((rc = grow(h, &h->d_term, (int64_t)h->cfg.term_rows * 10)) != FTMPC_OK) return rc;
+            std::vector<double> t((size_t)h->cfg.term_rows * 10);
+            std::memcpy(t.data(), h->cfg.term_A, (size_t)h->cfg.term_rows * 9 * sizeof(double));
+            std::memcpy(t.data() + (size_t)h->cfg.term_rows * 9, h->cfg.term_b, (size_t)h->cfg.term_rows * sizeof(double));
+            HIP_TRY(h, hipMemcpy(h->d_term, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+    }
+    const int64_t nA = (int64_t)n_sets * hull_rows * 6;
+    if (nA > h->cap_hullA) {
+        if ((rc = grow(h, &h->d_hullA, nA)) != FTMPC_OK) return rc;
+        h->cap_hullA = nA;
+    }
+    if (B > h->cap_wrench) {
+        if ((rc = grow(h, &h->d_hullb, B * FTMPC_MAX_HULL_ROWS)) != FTMPC_OK || (rc = grow(h, &h->d_hullset, B)) != FTMPC_OK ||
+            (rc = grow(h, &h->d_warmG, B * N * 6)) != FTMPC_OK || (rc = grow(h, &h->d_tau0, B * 6)) != FTMPC_OK ||
+            (rc = grow(h, &h->d_G, B * N * 6)) != FTMPC_OK || (rc = grow(h, &h->d_taud, B * 6)) != FTMPC_OK || (rc = grow(h, &h->d_ast2, 2 * B)) != FTMPC_OK)
+            return rc;
+        h->cap_wrench = B;
+    }
+    hipStream_t s = h->stream;
+    HIP_TRY(h, hipMemcpyAsync(h->d_x0, x0, B * 13 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_ub, ub, B * NT * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_stuck, stuck, B * NT * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_hullA, hull_A, nA * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_hullb, hull_b, B * hull_rows * sizeof(double), hipMemcpyHostToDevice, s));
+    if (hull_set) HIP_TRY(h, hipMemcpyAsync(h->d_hullset, hull_set, B * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    if ((rc = stage_refs(h, B, xref, xref_stride, uref, uref_stride)) != FTMPC_OK) return rc;
+    if (warmG) HIP_TRY(h, hipMemcpyAsync(h->d_warmG, warmG, B * N * 6 * sizeof(double), hipMemcpyHostToDevice, s));
+    LinParams lp;
+    lp.B = B;
+    lp.x0 = h->d_x0; lp.ub = h->d_ub; lp.stuck = h->d_stuck;
+    lp.xref = h->d_xref; lp.xref_stride = xref_stride;
+    lp.uref = uref ? h->d_uref : nullptr; lp.uref_stride = uref_stride;
+    lp.warmU = nullptr;
+    lp.rec = h->rec;
+    lp.qlist = nullptr; lp.qcount = nullptr; lp.qvmax = -1;
+    lp.warmG = warmG ? h->d_warmG : nullptr;
+    lp.out_eN = h->d_eN;
+    hipLaunchKernelGGL(ftmpc::ftmpc_linearize_kernel<double>, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, h->dc, lp);
+    HIP_TRY(h, hipGetLastError());
+    Solve64Params q;
+    std::memset(&q, 0, sizeof(q));
+    q.base.B = B;
+    q.base.rec = h->rec;
+    q.base.ub = h->d_ub; q.base.stuck = h->d_stuck;
+    q.base.out_u0 = h->d_u0;
+    q.base.status = h->d_status; q.base.iters = h->d_iters;
+    q.base.dbg_inst = -1;
+    q.Hs = h->gHs; q.Ls = h->gLs; q.Eall = h->gEall;
+    q.tile_doubles = h->tile_doubles_gen;
+    q.e_doubles = h->e_doubles_gen;
+    q.npad_max = h->npad_gen;
+    q.warmG = warmG ? h->d_warmG : nullptr;
+    q.hullA = h->d_hullA;
+    q.hull_set = hull_set ? h->d_hullset : nullptr;
+    q.hullb = h->d_hullb;
+    q.hull_rows = hull_rows;
+    q.termA = h->cfg.terminal_set ? h->d_term : nullptr;
+    q.termb = h->cfg.terminal_set ? h->d_term + (int64_t)h->cfg.term_rows * 9 : nullptr;
+    q.term_rows = h->cfg.terminal_set ? h->cfg.term_rows : 0;
+    q.eN = h->d_eN;
+    q.out_tau0 = h->d_tau0;
+    q.out_G = h->d_G;
+    // the wrench problem stops at mu 1e-10 unless the caller asked otherwise (general rows: see ftmpc_config.mu_stop)
+    DeviceConsts dcg = h->dc;
+    if (!(h->cfg.mu_stop > 0)) dcg.mu_stop = 1e-10;
+    const int grid = (int)std::min<int64_t>(B, h->grid_gen);
+    if (h->cfg.terminal_set)
+        hipLaunchKernelGGL((ftmpc::ftmpc_solve_f64_kernel<4, 1, 3>), dim3(grid), dim3(ftmpc::f64k::WG), 0, s, dcg, q);
+    else
+        hipLaunchKernelGGL((ftmpc::ftmpc_solve_f64_kernel<4, 1, 1>), dim3(grid), dim3(ftmpc::f64k::WG), 0, s, dcg, q);
+    HIP_TRY(h, hipGetLastError());
+    // second stage: min-norm allocation of the wrench the healthy thrusters have to produce
+    hipLaunchKernelGGL(ftmpc::ftmpc_healthy_wrench_kernel, dim3((unsigned)((B * 6 + 255) / 256)), dim3(256), 0, s, h->dc, B,
+                       (const double*)h->d_tau0, (const double*)h->d_stuck, h->d_taud);
+    ftmpc::AllocParams ap;
+    ap.B = B;
+    ap.tau = h->d_taud;
+    ap.ub = h->d_ub;
+    ap.out_u = h->d_u0;
+    ap.status = h->d_ast2;
+    ap.iters = h->d_ast2 + B;
+    ap.max_iters = 50;
+    ap.tol = 1e-8;
+    hipLaunchKernelGGL(ftmpc::ftmpc_allocate_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, h->dc, ap);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(out_u0, h->d_u0, B * NT * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (out_tau0) HIP_TRY(h, hipMemcpyAsync(out_tau0, h->d_tau0, B * 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (out_G) HIP_TRY(h, hipMemcpyAsync(out_G, h->d_G, B * N * 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (warmG) HIP_TRY(h, hipMemcpyAsync(warmG, h->d_G, B * N * 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (status) HIP_TRY(h, hipMemcpyAsync(status, h->d_status, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (iters) HIP_TRY(h, hipMemcpyAsync(iters, h->d_iters, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (alloc_status) HIP_TRY(h, hipMemcpyAsync(alloc_status, h->d_ast2, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return FTMPC_OK;
 }
 
 int ftmpc_allocate_batch(ftmpc_handle* h, int64_t B, const double* tau, const double* ub, double* out_u, int32_t* status,

@@ -84,6 +84,10 @@ struct LinParams {
     int32_t* qlist;
     int32_t* qcount;        // [3]
     int32_t qvmax;          // last instantiation this handle launches (0..2)
+    // generalized-force formulation: the linearisation wrench of every stage is given directly
+    // ([B*N*6]; nullptr: D (clip(warmU) + stuck) as above)
+    const double* warmG;
+    double* out_eN;         // nullptr or [B*9]: terminal tracking error c_N[0:9] - xref_N at the linearisation point
 };
 
 struct SolveParams {

@@ -208,6 +208,9 @@ __global__ void __launch_bounds__(64) ftmpc_linearize_kernel(const DeviceConsts 
             const double t = u + stk[i];
             for (int g = 0; g < 6; ++g) gen[g] += C.D[g * MAX_NT + i] * t;
         }
+        if (P.warmG) {
+            for (int g = 0; g < 6; ++g) gen[g] = P.warmG[(b * N + k) * 6 + g];
+        }
         // R .* (gen - ur - [f_virt;0]),  ur = [Rot(q_k)^T uref[0:3]; uref[3:6]]  (spiraling_mpc.py:156-171)
         {
             double ur[6] = {0, 0, 0, 0, 0, 0};
@@ -321,6 +324,9 @@ __global__ void __launch_bounds__(64) ftmpc_linearize_kernel(const DeviceConsts 
             if (k + 1 < N) {
                 for (int a = 0; a < 9; ++a) put(REC_WE - REC_BPF + a, C.Q[a] * e[a]);
             } else {
+                if (P.out_eN && b0 + lane < P.B) {
+                    for (int a = 0; a < 9; ++a) P.out_eN[b * 9 + a] = e[a];
+                }
                 for (int a = 0; a < 9; ++a) {
                     double s = 0.0;
                     for (int c = 0; c < 9; ++c) s += C.P[9 * a + c] * e[c];

@@ -122,6 +122,19 @@ struct Solve64Params {
     int32_t nb_lo;        // instances with ceil(n/16) <= nb_lo belong to the fp32 kernels
     double* dbg_H;        // [npad*npad] or nullptr
     double* dbg_vec;      // [3*npad_max + 4]
+    // general-constraint modes (template MODE: bit 0 = generalized-force variables with the per-stage input-hull
+    // rows, bit 1 = terminal-set rows on e_N); reference: spiraling_mpc.py:133-137,175-177 and :199-202
+    const double* warmG;      // [B*N*6] linearisation wrenches or nullptr (thrusters off: D stuck)
+    const double* hullA;      // [sets][hull_rows*6]
+    const int32_t* hull_set;  // [B] or nullptr (set 0)
+    const double* hullb;      // [B*hull_rows]
+    const double* termA;      // [term_rows*9]
+    const double* termb;      // [term_rows]
+    const double* eN;         // [B*9] terminal tracking error at the linearisation point (ftmpc_linearize.hip)
+    double* out_tau0;         // [B*6]
+    double* out_G;            // [B*N*6] or nullptr
+    int32_t hull_rows;        // <= 32, N * hull_rows <= 1024
+    int32_t term_rows;        // <= 80
 };
 
 // (diagnostic build only) per-phase cycle counters of wave 0, see scripts/stamps64.py
@@ -136,10 +149,12 @@ struct Solve64Params {
 #endif
 // SWEEP_ROWS: block rows per wave whose tiles the triangular sweeps prefetch.  4 serves n <= 256 (the reference
 // vehicle) with small register arrays, f64k::RPF everything up to 640; the host picks by the handle's N * NT.
-template <int SWEEP_ROWS, int NVT>   // NVT: columns per thread (n <= 256 NVT)
-__global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4) ? 2 : 1) ftmpc_solve_f64_kernel(const DeviceConsts C, const Solve64Params Q) {
+template <int SWEEP_ROWS, int NVT, int MODE = 0>   // NVT: columns per thread (n <= 256 NVT); MODE: see Solve64Params
+__global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4 && MODE == 0) ? 2 : 1) ftmpc_solve_f64_kernel(const DeviceConsts C, const Solve64Params Q) {
     using namespace f64k;
     static_assert(NVT >= 1 && NVT <= NVT_MAX, "columns per thread");
+    constexpr bool GEN = (MODE & 1) != 0, TSET = (MODE & 2) != 0;
+    static_assert(MODE == 0 || NVT == 1, "the general-constraint modes are built for n <= 256");
     const SolveParams& P = Q.base;
     __shared__ double recbuf[REC_STRIDE];
     __shared__ double dv[NMAX];        // d (permuted per 16-block) for the gradient mat-vec
@@ -152,6 +167,7 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4) ? 2 : 1) ftmpc_sol
     __shared__ unsigned char s_stg[NMAX], s_thr[NMAX];
     __shared__ int s_act[MAX_NT];
     __shared__ int s_flag;
+    __shared__ double s_ctr[12];     // GEN: hull centre | D stuck
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -170,9 +186,25 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4) ? 2 : 1) ftmpc_sol
         // ---------------- prologue ----------------
         if (tid == 0) {
             int na0 = 0;
-            for (int i = 0; i < NT; ++i)
-                if (P.ub[inst * NT + i] > 0.0) s_act[na0++] = i;
+            if constexpr (GEN) {
+                for (int i = 0; i < 6; ++i) s_act[i] = i;      // the six wrench components are the variables
+                na0 = 6;
+            } else {
+                for (int i = 0; i < NT; ++i)
+                    if (P.ub[inst * NT + i] > 0.0) s_act[na0++] = i;
+            }
             s_flag = na0;
+        }
+        if constexpr (GEN) {
+            // hull centre D (ub/2 + stuck) (the start point: strictly inside every hull row) and the
+            // thrusters-off wrench D stuck (the cold-start linearisation point)
+            if (tid < 12) {
+                const int g = tid % 6;
+                double acc = 0.0;
+                for (int i = 0; i < NT; ++i)
+                    acc += C.D[g * MAX_NT + i] * ((tid < 6 ? 0.5 * P.ub[inst * NT + i] : 0.0) + P.stuck[inst * NT + i]);
+                s_ctr[tid] = acc;
+            }
         }
         __syncthreads();
         const int na = s_flag;
@@ -193,7 +225,8 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4) ? 2 : 1) ftmpc_sol
         }
         if (tid < 6 * MAX_NT) {
             const int g = tid / MAX_NT, a = tid % MAX_NT;
-            s_Da[tid] = (a < na) ? (float)C.D[g * MAX_NT + s_act[a]] : 0.f;
+            if constexpr (GEN) s_Da[tid] = (a == g) ? 1.f : 0.f;
+            else s_Da[tid] = (a < na) ? (float)C.D[g * MAX_NT + s_act[a]] : 0.f;
         }
         for (int e = tid; e < npad; e += WG) {
             const int s = e / na;
@@ -204,8 +237,13 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4) ? 2 : 1) ftmpc_sol
         if (tid < na * na) {
             const int a = tid / na, b = tid % na;
             double t = 0.0;
-            for (int g = 0; g < 6; ++g) t += C.D[g * MAX_NT + s_act[a]] * C.R[g] * C.D[g * MAX_NT + s_act[b]];
-            s_MR[a * MAX_NT + b] = 2.0 * (t + (a == b ? rho : 0.0));
+            if constexpr (GEN) {
+                t = (a == b) ? C.R[a] : 0.0;      // the input cost acts on the wrench itself; no allocation regulariser
+            } else {
+                for (int g = 0; g < 6; ++g) t += C.D[g * MAX_NT + s_act[a]] * C.R[g] * C.D[g * MAX_NT + s_act[b]];
+                t += (a == b ? rho : 0.0);
+            }
+            s_MR[a * MAX_NT + b] = 2.0 * t;
         }
         const double* recg = reinterpret_cast<const double*>(P.rec) + inst * (int64_t)N * REC_STRIDE;
 
@@ -221,9 +259,13 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4) ? 2 : 1) ftmpc_sol
             ubv[v] = 1.0;
             gacc[v] = 0.0;
             if (kcol[v] != 255) {
-                const int t = s_act[acol[v]];
-                ubv[v] = P.ub[inst * NT + t];
-                if (P.warmU) ubar[v] = fmin(fmax(P.warmU[(inst * N + kcol[v]) * NT + t], 0.0), ubv[v]);
+                if constexpr (GEN) {
+                    ubar[v] = Q.warmG ? Q.warmG[(inst * N + kcol[v]) * 6 + acol[v]] : s_ctr[6 + acol[v]];
+                } else {
+                    const int t = s_act[acol[v]];
+                    ubv[v] = P.ub[inst * NT + t];
+                    if (P.warmU) ubar[v] = fmin(fmax(P.warmU[(inst * N + kcol[v]) * NT + t], 0.0), ubv[v]);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 13; ++r) G[r][v] = 0.0;
@@ -280,8 +322,13 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4) ? 2 : 1) ftmpc_sol
                     double F[3], T[3];
 #pragma unroll
                     for (int a = 0; a < 3; ++a) {
-                        F[a] = C.D[a * MAX_NT + s_act[acol[v]]];
-                        T[a] = C.D[(3 + a) * MAX_NT + s_act[acol[v]]];
+                        if constexpr (GEN) {
+                            F[a] = (acol[v] == a) ? 1.0 : 0.0;
+                            T[a] = (acol[v] == 3 + a) ? 1.0 : 0.0;
+                        } else {
+                            F[a] = C.D[a * MAX_NT + s_act[acol[v]]];
+                            T[a] = C.D[(3 + a) * MAX_NT + s_act[acol[v]]];
+                        }
                     }
                     double gr = 0.0;
 #pragma unroll
@@ -323,6 +370,11 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4) ? 2 : 1) ftmpc_sol
 #pragma unroll
                         for (int c = r; c < 9; ++c) s += C.LPt[9 * r + c] * G[c][v];
                         Ek[r * npad + e] = s;
+                    }
+                    if constexpr (TSET) {   // raw terminal sensitivity rows for the terminal-set rows A_T (e_N + GN d)
+                        double* GNs = Eall + (int64_t)N * 9 * npad;
+#pragma unroll
+                        for (int r = 0; r < 9; ++r) GNs[r * npad + e] = G[r][v];
                     }
                 }
             }
@@ -387,7 +439,7 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4) ? 2 : 1) ftmpc_sol
 #pragma unroll
         for (int v = 0; v < NVT; ++v) {
             valid[v] = kcol[v] != 255;
-            gv[v] = valid[v] ? 2.0 * (gacc[v] + rho * ubar[v]) : 0.0;
+            gv[v] = valid[v] ? 2.0 * (gacc[v] + (GEN ? 0.0 : rho * ubar[v])) : 0.0;
             lo[v] = -ubar[v];
             hi[v] = ubv[v] - ubar[v];
             sl[v] = su[v] = 0.5 * ubv[v];
@@ -408,6 +460,262 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4) ? 2 : 1) ftmpc_sol
         }
 
         S64(2);
+        __shared__ double Sblk[GEN ? 43 * 36 : 1];     // hull rows: per-stage blocks of A' W A
+        // ---- blocked left-looking Cholesky of the KKT matrix; block rows round-robin over the waves ----
+        // KKT matrix = H (global tiles) + diag(dv) [box rows] + per-stage 6x6 blocks Sblk [hull rows, MODE & 1]
+        //              + ET' ET [terminal rows, MODE & 2: ET = chol(A_T' W A_T)' GN, 9 x npad, global panel]
+        auto factor = [&]() {
+        // ---- blocked left-looking Cholesky; block rows round-robin over the waves ----
+        if (tid == 0) s_flag = 1;
+        for (int J = 0; J < nb; ++J) {
+            __syncthreads();
+            // wave 0 takes the diagonal tile and its potrf + inverse (the serial part of the column); the first six
+            // off-diagonal tiles go round-robin over waves 1..3 (about the time of the potrf), the rest over all four
+            for (int I = J; I < nb; ++I) {
+                if (col_owner(I - J) != wave) continue;
+                f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+                if constexpr (TSET) {   // acc = sum L L' - ET_I' ET_J, so that c = H - acc carries + ET' ET
+                    const double* ETs = Eall + (int64_t)(N + 1) * 9 * npad;
+#pragma unroll
+                    for (int s3 = 0; s3 < 3; ++s3) {
+                        const int r = 4 * s3 + lq;
+                        const double ea = (r < 9) ? -ETs[r * npad + 16 * I + li] : 0.0;
+                        const double eb = (r < 9) ? ETs[r * npad + 16 * J + li] : 0.0;
+                        acc = mfma(ea, eb, acc);
+                    }
+                }
+                const double* rowI = Ls + (int64_t)t64idx(I, 0) * 256 + 16 * li + 4 * lq;
+                const double* rowJ = Ls + (int64_t)t64idx(J, 0) * 256 + 16 * li + 4 * lq;
+                int K = 0;
+                // the tiles come from L2 (~800 cycles): four tile pairs in flight, two accumulators
+                f64x4 acc2 = {0.0, 0.0, 0.0, 0.0};
+                if (I == J) {   // diagonal tile: both operands are the same row, load it once
+                    for (; K + 3 < J; K += 4) {
+                        const f64x4 a0 = ld4(rowI + K * 256), a1 = ld4(rowI + (K + 1) * 256);
+                        const f64x4 a2 = ld4(rowI + (K + 2) * 256), a3 = ld4(rowI + (K + 3) * 256);
+                        acc = mfma(a0.x, a0.x, acc); acc2 = mfma(a1.x, a1.x, acc2);
+                        acc = mfma(a0.y, a0.y, acc); acc2 = mfma(a1.y, a1.y, acc2);
+                        acc = mfma(a0.z, a0.z, acc); acc2 = mfma(a1.z, a1.z, acc2);
+                        acc = mfma(a0.w, a0.w, acc); acc2 = mfma(a1.w, a1.w, acc2);
+                        acc = mfma(a2.x, a2.x, acc); acc2 = mfma(a3.x, a3.x, acc2);
+                        acc = mfma(a2.y, a2.y, acc); acc2 = mfma(a3.y, a3.y, acc2);
+                        acc = mfma(a2.z, a2.z, acc); acc2 = mfma(a3.z, a3.z, acc2);
+                        acc = mfma(a2.w, a2.w, acc); acc2 = mfma(a3.w, a3.w, acc2);
+                    }
+                    for (; K < J; ++K) {
+                        const f64x4 a0 = ld4(rowI + K * 256);
+                        acc = mfma(a0.x, a0.x, acc); acc = mfma(a0.y, a0.y, acc);
+                        acc = mfma(a0.z, a0.z, acc); acc = mfma(a0.w, a0.w, acc);
+                    }
+                }
+                for (; K + 3 < J; K += 4) {
+                    const f64x4 a0 = ld4(rowI + K * 256), b0 = ld4(rowJ + K * 256);
+                    const f64x4 a1 = ld4(rowI + (K + 1) * 256), b1 = ld4(rowJ + (K + 1) * 256);
+                    const f64x4 a2 = ld4(rowI + (K + 2) * 256), b2 = ld4(rowJ + (K + 2) * 256);
+                    const f64x4 a3 = ld4(rowI + (K + 3) * 256), b3 = ld4(rowJ + (K + 3) * 256);
+                    acc = mfma(a0.x, b0.x, acc); acc2 = mfma(a1.x, b1.x, acc2);
+                    acc = mfma(a0.y, b0.y, acc); acc2 = mfma(a1.y, b1.y, acc2);
+                    acc = mfma(a0.z, b0.z, acc); acc2 = mfma(a1.z, b1.z, acc2);
+                    acc = mfma(a0.w, b0.w, acc); acc2 = mfma(a1.w, b1.w, acc2);
+                    acc = mfma(a2.x, b2.x, acc); acc2 = mfma(a3.x, b3.x, acc2);
+                    acc = mfma(a2.y, b2.y, acc); acc2 = mfma(a3.y, b3.y, acc2);
+                    acc = mfma(a2.z, b2.z, acc); acc2 = mfma(a3.z, b3.z, acc2);
+                    acc = mfma(a2.w, b2.w, acc); acc2 = mfma(a3.w, b3.w, acc2);
+                }
+                acc += acc2;
+                for (; K + 1 < J; K += 2) {
+                    const f64x4 a0 = ld4(rowI + K * 256), b0 = ld4(rowJ + K * 256);
+                    const f64x4 a1 = ld4(rowI + (K + 1) * 256), b1 = ld4(rowJ + (K + 1) * 256);
+                    acc = mfma(a0.x, b0.x, acc); acc = mfma(a0.y, b0.y, acc);
+                    acc = mfma(a0.z, b0.z, acc); acc = mfma(a0.w, b0.w, acc);
+                    acc = mfma(a1.x, b1.x, acc); acc = mfma(a1.y, b1.y, acc);
+                    acc = mfma(a1.z, b1.z, acc); acc = mfma(a1.w, b1.w, acc);
+                }
+                for (; K < J; ++K) {
+                    const f64x4 a0 = ld4(rowI + K * 256), b0 = ld4(rowJ + K * 256);
+                    acc = mfma(a0.x, b0.x, acc); acc = mfma(a0.y, b0.y, acc);
+                    acc = mfma(a0.z, b0.z, acc); acc = mfma(a0.w, b0.w, acc);
+                }
+                double* tij = Ls + (int64_t)t64idx(I, J) * 256;
+                const double* hij = Hs + (int64_t)t64idx(I, J) * 256;
+                double c[4];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) c[rr] = hij[t64off(lq + 4 * rr, li)] - acc[rr];
+                if constexpr (GEN) {   // hull rows: same-stage pairs get their 6x6 block of A' W A (stages straddle tile borders)
+                    if (I - J <= 1) {
+                        const int e2 = 16 * J + li;
+                        const int s2 = s_stg[e2], a2 = s_thr[e2];
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const int e1 = 16 * I + lq + 4 * rr;
+                            const int s1 = s_stg[e1];
+                            if (s1 != 255 && s1 == s2) c[rr] += Sblk[s1 * 36 + s_thr[e1] * 6 + a2];
+                        }
+                    }
+                }
+                if (I == J) {   // wave 0 only (I = J + wave)
+                    const double sg = dv[16 * J + li];
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        if (lq + 4 * rr == li) c[rr] += sg;
+                        Sbuf[(lq + 4 * rr) * 17 + li] = c[rr];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    double w[16];
+                    const bool ok = potrf_inv16_f64(Sbuf, li, w);
+                    if (!ok && lane == 0) s_flag = 0;
+                    if (lq == 0) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) tij[t64off(i, li)] = w[i];
+                    }
+                } else {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) tij[t64off(lq + 4 * rr, li)] = c[rr];
+                }
+            }
+            __syncthreads();
+            const f64x4 w4 = ld4(Ls + (int64_t)t64idx(J, J) * 256 + 16 * li + 4 * lq);
+            for (int I = J + 1; I < nb; ++I) {   // same wave that produced C_IJ
+                if (col_owner(I - J) != wave) continue;
+                double* tij = Ls + (int64_t)t64idx(I, J) * 256;
+                const f64x4 a4 = ld4(tij + 16 * li + 4 * lq);
+                f64x4 x = {0.0, 0.0, 0.0, 0.0};
+                x = mfma(a4.x, w4.x, x); x = mfma(a4.y, w4.y, x);
+                x = mfma(a4.z, w4.z, x); x = mfma(a4.w, w4.w, x);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();   // the whole wave has read C_IJ before it is overwritten
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) tij[t64off(lq + 4 * rr, li)] = x[rr];
+            }
+        }
+        };
+        // ---- KKT solve (the right-hand side comes and the solution goes through xv, permuted layout) ----
+        // Right-looking sweeps: wave w keeps the running sums of ITS block rows (forward: rows I = w mod 4;
+        // backward: columns J = w mod 4); the owner of step J finishes block J alone, publishes it in LDS and
+        // everybody folds it into their sums.  One LDS-only barrier per step (the outstanding tile loads stay
+        // in flight across it), every tile requested one step before it is needed.
+        auto solve = [&](auto RPC) {
+            constexpr int RP = decltype(RPC)::value;
+            constexpr int RM = (RP < RPF) ? RP : RMAXW;
+            const int myp = v64pos(li);
+            double* rb = part + wave * 16;            // per-wave 16-vector scratch
+            f64x4 buf[RP];                            // tiles (I, J) of this wave's rows for the current step
+            f64x4 wdiag = {0.0, 0.0, 0.0, 0.0};
+            double psum[RM];
+#pragma unroll
+            for (int i = 0; i < RM; ++i) psum[i] = 0.0;
+            // ---- forward: L y = b ----
+            auto fetch_f = [&](int J) {               // column J of the factor, rows I = wave + 4 i > J
+#pragma unroll
+                for (int i = 0; i < RP; ++i) {
+                    const int I = wave + NWAVE * i;
+                    if (I > J && I < nb) buf[i] = ld4(Ls + (int64_t)t64idx(I, J) * 256 + 16 * li + 4 * lq);
+                }
+            };
+            if (wave == 0) wdiag = ld4(Ls + (int64_t)t64idx(0, 0) * 256 + 16 * li + 4 * lq);
+            fetch_f(0);
+            for (int J = 0; J < nb; ++J) {
+                if (wave == (J & (NWAVE - 1))) {       // owner: r_J = b_J - sum, y_J = W_J r_J
+                    const int i = J / NWAVE;
+                    double p = 0.0;
+#pragma unroll
+                    for (int ii = 0; ii < RMAXW; ++ii) p = (ii == i) ? psum[ii] : p;
+                    const double r = xv[16 * J + myp] - quad_sum64(p);
+                    if (lq == 0) rb[li] = r;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    double y = wdiag.x * rb[lq] + wdiag.y * rb[4 + lq] + wdiag.z * rb[8 + lq] + wdiag.w * rb[12 + lq];
+                    y = quad_sum64(y);
+                    if (lq == 0) xv[16 * J + myp] = y;
+                }
+                lds_barrier();
+                if (J + 1 < nb) {
+                    const double* y4 = xv + 16 * J + 4 * lq;
+                    const double y0 = y4[0], y1 = y4[1], y2 = y4[2], y3 = y4[3];
+#pragma unroll
+                    for (int i = 0; i < RPF; ++i) {
+                        const int I = wave + NWAVE * i;
+                        if (I > J && I < nb) psum[i] += buf[i].x * y0 + buf[i].y * y1 + buf[i].z * y2 + buf[i].w * y3;
+                    }
+#pragma unroll
+                    for (int i = RPF; i < RMAXW; ++i) {     // n > 640 only
+                        const int I = wave + NWAVE * i;
+                        if (I > J && I < nb) {
+                            const f64x4 t4 = ld4(Ls + (int64_t)t64idx(I, J) * 256 + 16 * li + 4 * lq);
+                            psum[i] += t4.x * y0 + t4.y * y1 + t4.z * y2 + t4.w * y3;
+                        }
+                    }
+                    fetch_f(J + 1);
+                    if (wave == ((J + 1) & (NWAVE - 1))) wdiag = ld4(Ls + (int64_t)t64idx(J + 1, J + 1) * 256 + 16 * li + 4 * lq);
+                }
+            }
+            // ---- backward: L' x = y ----
+#pragma unroll
+            for (int i = 0; i < RMAXW; ++i) psum[i] = 0.0;
+            auto fetch_b = [&](int I) {               // row I of the factor, columns J = wave + 4 i < I (transposed use)
+#pragma unroll
+                for (int i = 0; i < RPF; ++i) {
+                    const int J = wave + NWAVE * i;
+                    if (J < I) {
+                        const double* t = Ls + (int64_t)t64idx(I, J) * 256;
+                        buf[i].x = t[t64off(4 * lq + 0, li)];
+                        buf[i].y = t[t64off(4 * lq + 1, li)];
+                        buf[i].z = t[t64off(4 * lq + 2, li)];
+                        buf[i].w = t[t64off(4 * lq + 3, li)];
+                    }
+                }
+            };
+            auto fetch_wt = [&](int I) {
+                const double* t = Ls + (int64_t)t64idx(I, I) * 256;
+                wdiag.x = t[t64off(4 * lq + 0, li)];
+                wdiag.y = t[t64off(4 * lq + 1, li)];
+                wdiag.z = t[t64off(4 * lq + 2, li)];
+                wdiag.w = t[t64off(4 * lq + 3, li)];
+            };
+            if (wave == ((nb - 1) & (NWAVE - 1))) fetch_wt(nb - 1);
+            fetch_b(nb - 1);
+            for (int I = nb - 1; I >= 0; --I) {
+                if (wave == (I & (NWAVE - 1))) {       // owner: r_I = y_I - sum, x_I = W_I' r_I
+                    const int i = I / NWAVE;
+                    double p = 0.0;
+#pragma unroll
+                    for (int ii = 0; ii < RMAXW; ++ii) p = (ii == i) ? psum[ii] : p;
+                    const double r = xv[16 * I + myp] - quad_sum64(p);
+                    if (lq == 0) rb[li] = r;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    double x = wdiag.x * rb[4 * lq] + wdiag.y * rb[4 * lq + 1] + wdiag.z * rb[4 * lq + 2] + wdiag.w * rb[4 * lq + 3];
+                    x = quad_sum64(x);
+                    if (lq == 0) xv[16 * I + myp] = x;
+                }
+                lds_barrier();
+                if (I > 0) {
+                    const double x0 = xv[16 * I + 0 * 4 + lq], x1 = xv[16 * I + 1 * 4 + lq], x2 = xv[16 * I + 2 * 4 + lq],
+                                 x3 = xv[16 * I + 3 * 4 + lq];      // x_I[4 lq + rr]
+#pragma unroll
+                    for (int i = 0; i < RPF; ++i) {
+                        const int J = wave + NWAVE * i;
+                        if (J < I) psum[i] += buf[i].x * x0 + buf[i].y * x1 + buf[i].z * x2 + buf[i].w * x3;
+                    }
+#pragma unroll
+                    for (int i = RPF; i < RMAXW; ++i) {     // n > 640 only
+                        const int J = wave + NWAVE * i;
+                        if (J < I) {
+                            const double* t = Ls + (int64_t)t64idx(I, J) * 256;
+                            psum[i] += t[t64off(4 * lq + 0, li)] * x0 + t[t64off(4 * lq + 1, li)] * x1 + t[t64off(4 * lq + 2, li)] * x2 +
+                                       t[t64off(4 * lq + 3, li)] * x3;
+                        }
+                    }
+                    fetch_b(I - 1);
+                    if (wave == ((I - 1) & (NWAVE - 1))) fetch_wt(I - 1);
+                }
+            }
+        };
+        if constexpr (MODE == 0) {
         // ---------------- interior-point iterations ----------------
         int status = 1, nit = 0;
         bool first = true;
@@ -488,109 +796,7 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4) ? 2 : 1) ftmpc_sol
             }
             __syncthreads();
             S64(4);
-            // ---- blocked left-looking Cholesky; block rows round-robin over the waves ----
-            if (tid == 0) s_flag = 1;
-            for (int J = 0; J < nb; ++J) {
-                __syncthreads();
-                // wave 0 takes the diagonal tile and its potrf + inverse (the serial part of the column); the first six
-                // off-diagonal tiles go round-robin over waves 1..3 (about the time of the potrf), the rest over all four
-                for (int I = J; I < nb; ++I) {
-                    if (col_owner(I - J) != wave) continue;
-                    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-                    const double* rowI = Ls + (int64_t)t64idx(I, 0) * 256 + 16 * li + 4 * lq;
-                    const double* rowJ = Ls + (int64_t)t64idx(J, 0) * 256 + 16 * li + 4 * lq;
-                    int K = 0;
-                    // the tiles come from L2 (~800 cycles): four tile pairs in flight, two accumulators
-                    f64x4 acc2 = {0.0, 0.0, 0.0, 0.0};
-                    if (I == J) {   // diagonal tile: both operands are the same row, load it once
-                        for (; K + 3 < J; K += 4) {
-                            const f64x4 a0 = ld4(rowI + K * 256), a1 = ld4(rowI + (K + 1) * 256);
-                            const f64x4 a2 = ld4(rowI + (K + 2) * 256), a3 = ld4(rowI + (K + 3) * 256);
-                            acc = mfma(a0.x, a0.x, acc); acc2 = mfma(a1.x, a1.x, acc2);
-                            acc = mfma(a0.y, a0.y, acc); acc2 = mfma(a1.y, a1.y, acc2);
-                            acc = mfma(a0.z, a0.z, acc); acc2 = mfma(a1.z, a1.z, acc2);
-                            acc = mfma(a0.w, a0.w, acc); acc2 = mfma(a1.w, a1.w, acc2);
-                            acc = mfma(a2.x, a2.x, acc); acc2 = mfma(a3.x, a3.x, acc2);
-                            acc = mfma(a2.y, a2.y, acc); acc2 = mfma(a3.y, a3.y, acc2);
-                            acc = mfma(a2.z, a2.z, acc); acc2 = mfma(a3.z, a3.z, acc2);
-                            acc = mfma(a2.w, a2.w, acc); acc2 = mfma(a3.w, a3.w, acc2);
-                        }
-                        for (; K < J; ++K) {
-                            const f64x4 a0 = ld4(rowI + K * 256);
-                            acc = mfma(a0.x, a0.x, acc); acc = mfma(a0.y, a0.y, acc);
-                            acc = mfma(a0.z, a0.z, acc); acc = mfma(a0.w, a0.w, acc);
-                        }
-                    }
-                    for (; K + 3 < J; K += 4) {
-                        const f64x4 a0 = ld4(rowI + K * 256), b0 = ld4(rowJ + K * 256);
-                        const f64x4 a1 = ld4(rowI + (K + 1) * 256), b1 = ld4(rowJ + (K + 1) * 256);
-                        const f64x4 a2 = ld4(rowI + (K + 2) * 256), b2 = ld4(rowJ + (K + 2) * 256);
-                        const f64x4 a3 = ld4(rowI + (K + 3) * 256), b3 = ld4(rowJ + (K + 3) * 256);
-                        acc = mfma(a0.x, b0.x, acc); acc2 = mfma(a1.x, b1.x, acc2);
-                        acc = mfma(a0.y, b0.y, acc); acc2 = mfma(a1.y, b1.y, acc2);
-                        acc = mfma(a0.z, b0.z, acc); acc2 = mfma(a1.z, b1.z, acc2);
-                        acc = mfma(a0.w, b0.w, acc); acc2 = mfma(a1.w, b1.w, acc2);
-                        acc = mfma(a2.x, b2.x, acc); acc2 = mfma(a3.x, b3.x, acc2);
-                        acc = mfma(a2.y, b2.y, acc); acc2 = mfma(a3.y, b3.y, acc2);
-                        acc = mfma(a2.z, b2.z, acc); acc2 = mfma(a3.z, b3.z, acc2);
-                        acc = mfma(a2.w, b2.w, acc); acc2 = mfma(a3.w, b3.w, acc2);
-                    }
-                    acc += acc2;
-                    for (; K + 1 < J; K += 2) {
-                        const f64x4 a0 = ld4(rowI + K * 256), b0 = ld4(rowJ + K * 256);
-                        const f64x4 a1 = ld4(rowI + (K + 1) * 256), b1 = ld4(rowJ + (K + 1) * 256);
-                        acc = mfma(a0.x, b0.x, acc); acc = mfma(a0.y, b0.y, acc);
-                        acc = mfma(a0.z, b0.z, acc); acc = mfma(a0.w, b0.w, acc);
-                        acc = mfma(a1.x, b1.x, acc); acc = mfma(a1.y, b1.y, acc);
-                        acc = mfma(a1.z, b1.z, acc); acc = mfma(a1.w, b1.w, acc);
-                    }
-                    for (; K < J; ++K) {
-                        const f64x4 a0 = ld4(rowI + K * 256), b0 = ld4(rowJ + K * 256);
-                        acc = mfma(a0.x, b0.x, acc); acc = mfma(a0.y, b0.y, acc);
-                        acc = mfma(a0.z, b0.z, acc); acc = mfma(a0.w, b0.w, acc);
-                    }
-                    double* tij = Ls + (int64_t)t64idx(I, J) * 256;
-                    const double* hij = Hs + (int64_t)t64idx(I, J) * 256;
-                    double c[4];
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) c[rr] = hij[t64off(lq + 4 * rr, li)] - acc[rr];
-                    if (I == J) {   // wave 0 only (I = J + wave)
-                        const double sg = dv[16 * J + li];
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) {
-                            if (lq + 4 * rr == li) c[rr] += sg;
-                            Sbuf[(lq + 4 * rr) * 17 + li] = c[rr];
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                        double w[16];
-                        const bool ok = potrf_inv16_f64(Sbuf, li, w);
-                        if (!ok && lane == 0) s_flag = 0;
-                        if (lq == 0) {
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) tij[t64off(i, li)] = w[i];
-                        }
-                    } else {
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) tij[t64off(lq + 4 * rr, li)] = c[rr];
-                    }
-                }
-                __syncthreads();
-                const f64x4 w4 = ld4(Ls + (int64_t)t64idx(J, J) * 256 + 16 * li + 4 * lq);
-                for (int I = J + 1; I < nb; ++I) {   // same wave that produced C_IJ
-                    if (col_owner(I - J) != wave) continue;
-                    double* tij = Ls + (int64_t)t64idx(I, J) * 256;
-                    const f64x4 a4 = ld4(tij + 16 * li + 4 * lq);
-                    f64x4 x = {0.0, 0.0, 0.0, 0.0};
-                    x = mfma(a4.x, w4.x, x); x = mfma(a4.y, w4.y, x);
-                    x = mfma(a4.z, w4.z, x); x = mfma(a4.w, w4.w, x);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                    __builtin_amdgcn_wave_barrier();   // the whole wave has read C_IJ before it is overwritten
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) tij[t64off(lq + 4 * rr, li)] = x[rr];
-                }
-            }
+            factor();
             __syncthreads();
             if (s_flag == 0) {
                 status = 2;
@@ -598,130 +804,6 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4) ? 2 : 1) ftmpc_sol
             }
 
             S64(5);
-            // ---- two KKT solves ----
-            // Right-looking sweeps: wave w keeps the running sums of ITS block rows (forward: rows I = w mod 4;
-            // backward: columns J = w mod 4); the owner of step J finishes block J alone, publishes it in LDS and
-            // everybody folds it into their sums.  One LDS-only barrier per step (the outstanding tile loads stay
-            // in flight across it), every tile requested one step before it is needed.
-            auto solve = [&](auto RPC) {
-                constexpr int RP = decltype(RPC)::value;
-                constexpr int RM = (RP < RPF) ? RP : RMAXW;
-                const int myp = v64pos(li);
-                double* rb = part + wave * 16;            // per-wave 16-vector scratch
-                f64x4 buf[RP];                            // tiles (I, J) of this wave's rows for the current step
-                f64x4 wdiag = {0.0, 0.0, 0.0, 0.0};
-                double psum[RM];
-#pragma unroll
-                for (int i = 0; i < RM; ++i) psum[i] = 0.0;
-                // ---- forward: L y = b ----
-                auto fetch_f = [&](int J) {               // column J of the factor, rows I = wave + 4 i > J
-#pragma unroll
-                    for (int i = 0; i < RP; ++i) {
-                        const int I = wave + NWAVE * i;
-                        if (I > J && I < nb) buf[i] = ld4(Ls + (int64_t)t64idx(I, J) * 256 + 16 * li + 4 * lq);
-                    }
-                };
-                if (wave == 0) wdiag = ld4(Ls + (int64_t)t64idx(0, 0) * 256 + 16 * li + 4 * lq);
-                fetch_f(0);
-                for (int J = 0; J < nb; ++J) {
-                    if (wave == (J & (NWAVE - 1))) {       // owner: r_J = b_J - sum, y_J = W_J r_J
-                        const int i = J / NWAVE;
-                        double p = 0.0;
-#pragma unroll
-                        for (int ii = 0; ii < RMAXW; ++ii) p = (ii == i) ? psum[ii] : p;
-                        const double r = xv[16 * J + myp] - quad_sum64(p);
-                        if (lq == 0) rb[li] = r;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        double y = wdiag.x * rb[lq] + wdiag.y * rb[4 + lq] + wdiag.z * rb[8 + lq] + wdiag.w * rb[12 + lq];
-                        y = quad_sum64(y);
-                        if (lq == 0) xv[16 * J + myp] = y;
-                    }
-                    lds_barrier();
-                    if (J + 1 < nb) {
-                        const double* y4 = xv + 16 * J + 4 * lq;
-                        const double y0 = y4[0], y1 = y4[1], y2 = y4[2], y3 = y4[3];
-#pragma unroll
-                        for (int i = 0; i < RPF; ++i) {
-                            const int I = wave + NWAVE * i;
-                            if (I > J && I < nb) psum[i] += buf[i].x * y0 + buf[i].y * y1 + buf[i].z * y2 + buf[i].w * y3;
-                        }
-#pragma unroll
-                        for (int i = RPF; i < RMAXW; ++i) {     // n > 640 only
-                            const int I = wave + NWAVE * i;
-                            if (I > J && I < nb) {
-                                const f64x4 t4 = ld4(Ls + (int64_t)t64idx(I, J) * 256 + 16 * li + 4 * lq);
-                                psum[i] += t4.x * y0 + t4.y * y1 + t4.z * y2 + t4.w * y3;
-                            }
-                        }
-                        fetch_f(J + 1);
-                        if (wave == ((J + 1) & (NWAVE - 1))) wdiag = ld4(Ls + (int64_t)t64idx(J + 1, J + 1) * 256 + 16 * li + 4 * lq);
-                    }
-                }
-                // ---- backward: L' x = y ----
-#pragma unroll
-                for (int i = 0; i < RMAXW; ++i) psum[i] = 0.0;
-                auto fetch_b = [&](int I) {               // row I of the factor, columns J = wave + 4 i < I (transposed use)
-#pragma unroll
-                    for (int i = 0; i < RPF; ++i) {
-                        const int J = wave + NWAVE * i;
-                        if (J < I) {
-                            const double* t = Ls + (int64_t)t64idx(I, J) * 256;
-                            buf[i].x = t[t64off(4 * lq + 0, li)];
-                            buf[i].y = t[t64off(4 * lq + 1, li)];
-                            buf[i].z = t[t64off(4 * lq + 2, li)];
-                            buf[i].w = t[t64off(4 * lq + 3, li)];
-                        }
-                    }
-                };
-                auto fetch_wt = [&](int I) {
-                    const double* t = Ls + (int64_t)t64idx(I, I) * 256;
-                    wdiag.x = t[t64off(4 * lq + 0, li)];
-                    wdiag.y = t[t64off(4 * lq + 1, li)];
-                    wdiag.z = t[t64off(4 * lq + 2, li)];
-                    wdiag.w = t[t64off(4 * lq + 3, li)];
-                };
-                if (wave == ((nb - 1) & (NWAVE - 1))) fetch_wt(nb - 1);
-                fetch_b(nb - 1);
-                for (int I = nb - 1; I >= 0; --I) {
-                    if (wave == (I & (NWAVE - 1))) {       // owner: r_I = y_I - sum, x_I = W_I' r_I
-                        const int i = I / NWAVE;
-                        double p = 0.0;
-#pragma unroll
-                        for (int ii = 0; ii < RMAXW; ++ii) p = (ii == i) ? psum[ii] : p;
-                        const double r = xv[16 * I + myp] - quad_sum64(p);
-                        if (lq == 0) rb[li] = r;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        double x = wdiag.x * rb[4 * lq] + wdiag.y * rb[4 * lq + 1] + wdiag.z * rb[4 * lq + 2] + wdiag.w * rb[4 * lq + 3];
-                        x = quad_sum64(x);
-                        if (lq == 0) xv[16 * I + myp] = x;
-                    }
-                    lds_barrier();
-                    if (I > 0) {
-                        const double x0 = xv[16 * I + 0 * 4 + lq], x1 = xv[16 * I + 1 * 4 + lq], x2 = xv[16 * I + 2 * 4 + lq],
-                                     x3 = xv[16 * I + 3 * 4 + lq];      // x_I[4 lq + rr]
-#pragma unroll
-                        for (int i = 0; i < RPF; ++i) {
-                            const int J = wave + NWAVE * i;
-                            if (J < I) psum[i] += buf[i].x * x0 + buf[i].y * x1 + buf[i].z * x2 + buf[i].w * x3;
-                        }
-#pragma unroll
-                        for (int i = RPF; i < RMAXW; ++i) {     // n > 640 only
-                            const int J = wave + NWAVE * i;
-                            if (J < I) {
-                                const double* t = Ls + (int64_t)t64idx(I, J) * 256;
-                                psum[i] += t[t64off(4 * lq + 0, li)] * x0 + t[t64off(4 * lq + 1, li)] * x1 + t[t64off(4 * lq + 2, li)] * x2 +
-                                           t[t64off(4 * lq + 3, li)] * x3;
-                            }
-                        }
-                        fetch_b(I - 1);
-                        if (wave == ((I - 1) & (NWAVE - 1))) fetch_wt(I - 1);
-                    }
-                }
-            };
 #pragma unroll
             for (int v = 0; v < NVT; ++v) {
                 const int e = v * WG + tid;
@@ -826,6 +908,442 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4) ? 2 : 1) ftmpc_sol
             if (P.status) P.status[inst] = status;
             if (P.iters) P.iters[inst] = nit;
         }
+        } else {
+            // ================= general-constraint interior-point method (MODE != 0) =================
+            // rows:  box rows of the thruster variables (MODE == 2 only: -d <= ubar, d <= ub - ubar), hull rows
+            //        A_h tau_k <= b_h of every stage (MODE & 1), terminal rows A_T (e_N + GN d) <= b_T (MODE & 2).
+            // Same Mehrotra iteration as the box path with general rows C d + s = h (oracle/qp_oracle.py:ipm_general is
+            // the mirror): the box / hull rows start strictly feasible and stay so, the terminal rows start at
+            // s = max(residual, 0.1) and carry their primal residual r_p, which every step shrinks by (1 - alpha_p).
+            constexpr int NVC = 4;                       // hull rows per thread: N * hull_rows <= 1024
+            __shared__ double cw[NVC * WG], xs[NMAX / NVT_MAX];
+            __shared__ double s_hA[32 * 6];
+            __shared__ double s_tA[80 * 9], s_tbv[80], cwt[80], y9[9], M9[81], C9[81], r9[NWAVE * 9];
+            const int MH = GEN ? Q.hull_rows : 0, MT = TSET ? Q.term_rows : 0;
+            const int mhull = N * MH;
+            const double* GNs = Eall + (int64_t)N * 9 * npad;      // raw terminal sensitivity rows [9][npad]
+            double* ETs = Eall + (int64_t)(N + 1) * 9 * npad;       // chol(A_T' W A_T)' GN        [9][npad]
+            const bool val = valid[0];
+            const int ek = kcol[0], ea = acol[0];
+            const double ub0 = ubv[0], ubar0 = ubar[0];
+            const int xp = 16 * (tid >> 4) + v64pos(tid & 15);      // this thread's slot of the permuted vectors
+            if constexpr (GEN) {
+                const int set = Q.hull_set ? Q.hull_set[inst] : 0;
+                for (int i = tid; i < MH * 6; i += WG) s_hA[i] = Q.hullA[(int64_t)set * MH * 6 + i];
+            }
+            if constexpr (TSET) {
+                for (int i = tid; i < MT * 9; i += WG) s_tA[i] = Q.termA[i];
+                if (tid < MT) s_tbv[tid] = Q.termb[tid];
+            }
+            __syncthreads();
+            double d = 0.0, grd = 0.0;
+            double sl = 1.0, su = 1.0, zl = 0.0, zu = 0.0;
+            double sh[NVC], zh[NVC];
+            int hk[NVC], hr[NVC];
+            bool hv[NVC];
+            double st = 1.0, zt = 0.0, rpt = 0.0;
+            const bool tv = tid < MT;
+            if (val) d = GEN ? s_ctr[ea] - ubar0 : 0.5 * ub0 - ubar0;
+            if constexpr (!GEN) sl = su = 0.5 * ub0;
+#pragma unroll
+            for (int v = 0; v < NVC; ++v) {
+                const int c = v * WG + tid;
+                hv[v] = GEN && c < mhull;
+                hk[v] = hv[v] ? c / MH : 0;
+                hr[v] = hv[v] ? c - hk[v] * MH : 0;
+                sh[v] = 1.0;
+                zh[v] = 0.0;
+                if (hv[v]) {   // b - A centre: the same for every stage
+                    double a = Q.hullb[inst * MH + hr[v]];
+#pragma unroll
+                    for (int g = 0; g < 6; ++g) a -= s_hA[hr[v] * 6 + g] * s_ctr[g];
+                    sh[v] = a;
+                }
+            }
+            auto wg_sum9 = [&](double (&p)[9]) {
+#pragma unroll
+                for (int r = 0; r < 9; ++r)
+                    for (int m = 32; m >= 1; m >>= 1) p[r] += __shfl_xor(p[r], m, 64);
+                __syncthreads();
+                if (lane == 0) {
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) r9[wave * 9 + r] = p[r];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 9; ++r) p[r] = r9[r] + r9[9 + r] + r9[18 + r] + r9[27 + r];
+            };
+            // rows of C x for a vector held one element per thread
+            auto rows_Cx = [&](double xval, double& cl, double& cu, double (&ch)[NVC], double& ct) {
+                __syncthreads();
+                if (tid < npad) xs[tid] = val ? xval : 0.0;
+                double y[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                if constexpr (TSET) {
+                    if (val) {
+#pragma unroll
+                        for (int r = 0; r < 9; ++r) y[r] = GNs[r * npad + tid] * xval;
+                    }
+                    wg_sum9(y);
+                } else {
+                    __syncthreads();
+                }
+                cl = -xval;
+                cu = xval;
+#pragma unroll
+                for (int v = 0; v < NVC; ++v) {
+                    ch[v] = 0.0;
+                    if (hv[v]) {
+#pragma unroll
+                        for (int g = 0; g < 6; ++g) ch[v] += s_hA[hr[v] * 6 + g] * xs[hk[v] * 6 + g];
+                    }
+                }
+                ct = 0.0;
+                if constexpr (TSET) {
+                    if (tv) {
+#pragma unroll
+                        for (int r = 0; r < 9; ++r) ct += s_tA[tid * 9 + r] * y[r];
+                    }
+                }
+            };
+            // element of C' t for per-row values t
+            auto cols_Ct = [&](double tl, double tu, const double (&th)[NVC], double tt) -> double {
+                double out = GEN ? 0.0 : (val ? tu - tl : 0.0);
+                __syncthreads();
+                if constexpr (GEN) {
+#pragma unroll
+                    for (int v = 0; v < NVC; ++v)
+                        if (hv[v]) cw[v * WG + tid] = th[v];
+                }
+                if constexpr (TSET) {
+                    if (tv) cwt[tid] = tt;
+                }
+                __syncthreads();
+                if constexpr (TSET) {
+                    if (tid < 9) {
+                        double a = 0.0;
+                        for (int t = 0; t < MT; ++t) a += s_tA[t * 9 + tid] * cwt[t];
+                        y9[tid] = a;
+                    }
+                }
+                if constexpr (GEN) {
+                    if (val)
+                        for (int r = 0; r < MH; ++r) out += s_hA[r * 6 + ea] * cw[ek * MH + r];
+                }
+                if constexpr (TSET) {
+                    __syncthreads();
+                    if (val) {
+#pragma unroll
+                        for (int r = 0; r < 9; ++r) out += GNs[r * npad + tid] * y9[r];
+                    }
+                }
+                return out;
+            };
+            // the pieces of the KKT matrix beside H: diag (dv), hull blocks (Sblk), terminal panel (ETs)
+            auto form_kkt = [&](double wl, double wu, const double (&wh)[NVC], double wt) {
+                __syncthreads();
+                if (tid < npad) dv[tid] = (!GEN && val) ? wl + wu : 0.0;
+                if constexpr (GEN) {
+#pragma unroll
+                    for (int v = 0; v < NVC; ++v)
+                        if (hv[v]) cw[v * WG + tid] = wh[v];
+                }
+                if constexpr (TSET) {
+                    if (tv) cwt[tid] = wt;
+                }
+                __syncthreads();
+                if constexpr (GEN) {
+                    for (int idx = tid; idx < N * 36; idx += WG) {
+                        const int k = idx / 36, ab = idx - 36 * k, a = ab / 6, b = ab - 6 * a;
+                        double acc = 0.0;
+                        for (int r = 0; r < MH; ++r) acc += cw[k * MH + r] * s_hA[r * 6 + a] * s_hA[r * 6 + b];
+                        Sblk[idx] = acc;
+                    }
+                }
+                if constexpr (TSET) {
+                    if (tid < 81) {
+                        const int r1 = tid / 9, r2 = tid - 9 * r1;
+                        double acc = 0.0;
+                        for (int t = 0; t < MT; ++t) acc += cwt[t] * s_tA[t * 9 + r1] * s_tA[t * 9 + r2];
+                        M9[tid] = acc;
+                    }
+                    __syncthreads();
+                    if (tid == 0) {   // M = C' C, C upper triangular (a zero pivot gives a zero row)
+                        for (int j = 0; j < 9; ++j) {
+                            double dj = M9[9 * j + j];
+                            for (int k = 0; k < j; ++k) dj -= C9[9 * k + j] * C9[9 * k + j];
+                            const double l = dj > 0.0 ? sqrt(dj) : 0.0;
+                            for (int i = 0; i < j; ++i) C9[9 * j + i] = 0.0;
+                            C9[9 * j + j] = l;
+                            for (int i = j + 1; i < 9; ++i) {
+                                double sacc = M9[9 * j + i];
+                                for (int k = 0; k < j; ++k) sacc -= C9[9 * k + j] * C9[9 * k + i];
+                                C9[9 * j + i] = l > 0.0 ? sacc / l : 0.0;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    if (tid < npad) {
+#pragma unroll
+                        for (int r = 0; r < 9; ++r) {
+                            double acc = 0.0;
+                            for (int r2 = r; r2 < 9; ++r2) acc += C9[9 * r + r2] * GNs[r2 * npad + tid];
+                            ETs[r * npad + tid] = acc;
+                        }
+                    }
+                }
+                __syncthreads();
+            };
+            auto pos_step = [](double sv, double dsv) { return (dsv < 0.0) ? -sv / dsv : 1e300; };
+
+            // gradient at the start point: H d + g (tile mat-vec; afterwards the gradient follows the step)
+            __syncthreads();
+            if (tid < npad) dv[xp] = val ? d : 0.0;
+            __syncthreads();
+            for (int I = wave; I < nb; I += NWAVE) {
+                double a = 0.0;
+                for (int J = 0; J < nb; ++J) {
+                    if (J <= I) {
+                        const f64x4 t4 = ld4(Hs + (int64_t)t64idx(I, J) * 256 + 16 * li + 4 * lq);
+                        const double* d4 = dv + 16 * J + 4 * lq;
+                        a += t4.x * d4[0] + t4.y * d4[1] + t4.z * d4[2] + t4.w * d4[3];
+                    } else {
+                        const double* t = Hs + (int64_t)t64idx(J, I) * 256;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) a += t[t64off(4 * lq + rr, li)] * dv[16 * J + rr * 4 + lq];
+                    }
+                }
+                a = quad_sum64(a);
+                if (lq == 0) xv[16 * I + li] = a;
+            }
+            __syncthreads();
+            grd = (tid < npad && val) ? xv[tid] + gv[0] : 0.0;
+            {
+                // terminal rows: residual at the start point, slack and primal residual
+                double cl, cu, ch[NVC], ct;
+                rows_Cx(d, cl, cu, ch, ct);
+                if constexpr (TSET) {
+                    if (tv) {
+                        double res = s_tbv[tid] - ct;
+#pragma unroll
+                        for (int r = 0; r < 9; ++r) res -= s_tA[tid * 9 + r] * Q.eN[inst * 9 + r];
+                        st = fmax(res, 0.1);
+                        rpt = st - res;
+                    }
+                }
+                double gm = val ? fabs(grd) : 0.0, sm = 0.0;
+                if constexpr (!GEN) sm = val ? sl : 0.0;
+#pragma unroll
+                for (int v = 0; v < NVC; ++v)
+                    if (hv[v]) sm = fmax(sm, sh[v]);
+                if (tv) sm = fmax(sm, st);
+                gm = wg_max(gm, red, tid);
+                sm = wg_max(sm, red, tid);
+                const double mu0 = fmax(0.02 * gm * sm, 1e-3);
+                if constexpr (!GEN) {
+                    zl = val ? mu0 / sl : 0.0;
+                    zu = val ? mu0 / su : 0.0;
+                }
+#pragma unroll
+                for (int v = 0; v < NVC; ++v) zh[v] = hv[v] ? mu0 / sh[v] : 0.0;
+                zt = tv ? mu0 / st : 0.0;
+            }
+            int status = 1, nit = 0;
+            const double inv_m = 1.0 / (double)((GEN ? mhull : 2 * n) + MT);
+            const double zero4[NVC] = {0.0, 0.0, 0.0, 0.0};
+            for (int it = 0; it <= C.max_iters; ++it) {
+                double t = 0.0;
+                if constexpr (!GEN) t += val ? sl * zl + su * zu : 0.0;
+#pragma unroll
+                for (int v = 0; v < NVC; ++v)
+                    if (hv[v]) t += sh[v] * zh[v];
+                if (tv) t += st * zt;
+                const double mu = wg_sum(t, red, tid) * inv_m;
+                const double rpn = wg_max(tv ? fabs(rpt) : 0.0, red, tid);
+                if (!(mu == mu) || !(rpn == rpn) || mu > 1e300 || rpn > 1e300) {
+                    status = 2;
+                    break;
+                }
+                if (mu < C.mu_stop && rpn < 1e-9) {
+                    status = 0;
+                    break;
+                }
+                if (it == C.max_iters) break;
+                ++nit;
+                const double wl = (!GEN && val) ? zl / sl : 0.0, wu = (!GEN && val) ? zu / su : 0.0, wt = tv ? zt / st : 0.0;
+                double wh[NVC];
+#pragma unroll
+                for (int v = 0; v < NVC; ++v) wh[v] = hv[v] ? zh[v] / sh[v] : 0.0;
+                form_kkt(wl, wu, wh, wt);
+                factor();
+                __syncthreads();
+                if (s_flag == 0) {   // the factorisation broke down: C' W C with W ~ 1/mu ruins the conditioning near the end
+                    status = (mu < 1e-7 && rpn < 1e-9) ? 0 : 2;
+                    --nit;
+                    break;
+                }
+                // predictor: rc = s z  ->  t = -z + (rc - z rp) / s = -z rp / s  (zero except on the terminal rows)
+                double rhs = -grd;
+                if constexpr (TSET) rhs += cols_Ct(0.0, 0.0, zero4, tv ? -zt * rpt / st : 0.0);
+                __syncthreads();
+                if (tid < npad) xv[xp] = val ? rhs : 0.0;
+                __syncthreads();
+                solve(std::integral_constant<int, SWEEP_ROWS>{});
+                __syncthreads();
+                const double da = (tid < npad && val) ? xv[xp] : 0.0;
+                double cl, cu, ch[NVC], ct;
+                rows_Cx(da, cl, cu, ch, ct);
+                // ds = -rp - C dd,  dz = (-rc - z ds) / s
+                double dsl_a = -cl, dsu_a = -cu, dst_a = -rpt - ct, dsh_a[NVC];
+                double dzl_a = 0.0, dzu_a = 0.0, dzt_a = 0.0, dzh_a[NVC];
+                double ap = 1.0, ad = 1.0;
+                if constexpr (!GEN) {
+                    if (val) {
+                        dzl_a = -zl - zl * dsl_a / sl;
+                        dzu_a = -zu - zu * dsu_a / su;
+                        ap = fmin(ap, fmin(pos_step(sl, dsl_a), pos_step(su, dsu_a)));
+                        ad = fmin(ad, fmin(pos_step(zl, dzl_a), pos_step(zu, dzu_a)));
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < NVC; ++v) {
+                    dsh_a[v] = -ch[v];
+                    dzh_a[v] = 0.0;
+                    if (hv[v]) {
+                        dzh_a[v] = -zh[v] - zh[v] * dsh_a[v] / sh[v];
+                        ap = fmin(ap, pos_step(sh[v], dsh_a[v]));
+                        ad = fmin(ad, pos_step(zh[v], dzh_a[v]));
+                    }
+                }
+                if (tv) {
+                    dzt_a = -zt - zt * dst_a / st;
+                    ap = fmin(ap, pos_step(st, dst_a));
+                    ad = fmin(ad, pos_step(zt, dzt_a));
+                }
+                ap = wg_min(ap, red, tid);
+                ad = wg_min(ad, red, tid);
+                t = 0.0;
+                if constexpr (!GEN) t += val ? (sl + ap * dsl_a) * (zl + ad * dzl_a) + (su + ap * dsu_a) * (zu + ad * dzu_a) : 0.0;
+#pragma unroll
+                for (int v = 0; v < NVC; ++v)
+                    if (hv[v]) t += (sh[v] + ap * dsh_a[v]) * (zh[v] + ad * dzh_a[v]);
+                if (tv) t += (st + ap * dst_a) * (zt + ad * dzt_a);
+                const double mu_aff = wg_sum(t, red, tid) * inv_m;
+                double sigma = mu_aff / mu;
+                sigma = fmin(fmax(sigma * sigma * sigma, 0.0), 1.0);
+                // corrector: rc = s z + ds_a dz_a - sigma mu,  t = -z + (rc - z rp) / s
+                double rcl = 0.0, rcu = 0.0, rct = 0.0, rch[NVC], tl = 0.0, tu = 0.0, tt = 0.0, th[NVC];
+                if constexpr (!GEN) {
+                    if (val) {
+                        rcl = sl * zl + dsl_a * dzl_a - sigma * mu;
+                        rcu = su * zu + dsu_a * dzu_a - sigma * mu;
+                        tl = -zl + rcl / sl;
+                        tu = -zu + rcu / su;
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < NVC; ++v) {
+                    rch[v] = th[v] = 0.0;
+                    if (hv[v]) {
+                        rch[v] = sh[v] * zh[v] + dsh_a[v] * dzh_a[v] - sigma * mu;
+                        th[v] = -zh[v] + rch[v] / sh[v];
+                    }
+                }
+                if (tv) {
+                    rct = st * zt + dst_a * dzt_a - sigma * mu;
+                    tt = -zt + (rct - zt * rpt) / st;
+                }
+                rhs = -grd + cols_Ct(tl, tu, th, tt);
+                __syncthreads();
+                if (tid < npad) xv[xp] = val ? rhs : 0.0;
+                __syncthreads();
+                solve(std::integral_constant<int, SWEEP_ROWS>{});
+                __syncthreads();
+                const double dd = (tid < npad && val) ? xv[xp] : 0.0;
+                rows_Cx(dd, cl, cu, ch, ct);
+                const double dsl = -cl, dsu = -cu, dst = -rpt - ct;
+                double dsh[NVC], dzl = 0.0, dzu = 0.0, dzt = 0.0, dzh[NVC];
+                ap = 1e300;
+                ad = 1e300;
+                if constexpr (!GEN) {
+                    if (val) {
+                        dzl = (-rcl - zl * dsl) / sl;
+                        dzu = (-rcu - zu * dsu) / su;
+                        ap = fmin(ap, fmin(pos_step(sl, dsl), pos_step(su, dsu)));
+                        ad = fmin(ad, fmin(pos_step(zl, dzl), pos_step(zu, dzu)));
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < NVC; ++v) {
+                    dsh[v] = -ch[v];
+                    dzh[v] = 0.0;
+                    if (hv[v]) {
+                        dzh[v] = (-rch[v] - zh[v] * dsh[v]) / sh[v];
+                        ap = fmin(ap, pos_step(sh[v], dsh[v]));
+                        ad = fmin(ad, pos_step(zh[v], dzh[v]));
+                    }
+                }
+                if (tv) {
+                    dzt = (-rct - zt * dst) / st;
+                    ap = fmin(ap, pos_step(st, dst));
+                    ad = fmin(ad, pos_step(zt, dzt));
+                }
+                ap = fmin(1.0, 0.9995 * wg_min(ap, red, tid));
+                ad = fmin(1.0, 0.9995 * wg_min(ad, red, tid));
+                // H dd = rhs - C' (w . (C dd)),  C dd = -ds - rp
+                double whc[NVC];
+#pragma unroll
+                for (int v = 0; v < NVC; ++v) whc[v] = hv[v] ? wh[v] * (-dsh[v]) : 0.0;
+                const double hdd = rhs - cols_Ct(wl * (-dsl), wu * (-dsu), whc, tv ? wt * (-dst - rpt) : 0.0);
+                if (val) {
+                    grd += ap * hdd;
+                    d += ap * dd;
+                    if constexpr (!GEN) {
+                        sl += ap * dsl;
+                        su += ap * dsu;
+                        zl += ad * dzl;
+                        zu += ad * dzu;
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < NVC; ++v)
+                    if (hv[v]) {
+                        sh[v] += ap * dsh[v];
+                        zh[v] += ad * dzh[v];
+                    }
+                if (tv) {
+                    st += ap * dst;
+                    zt += ad * dzt;
+                    rpt *= (1.0 - ap);
+                }
+            }
+            S64(7);
+            // ---------------- outputs ----------------
+            __syncthreads();
+            if constexpr (GEN) {
+                if (val) {
+                    const double tau = (status == 2) ? ubar0 : ubar0 + d;
+                    if (ek == 0) Q.out_tau0[inst * 6 + ea] = tau;
+                    if (Q.out_G) Q.out_G[(inst * N + ek) * 6 + ea] = tau;
+                }
+            } else {
+                double* ubuf = dv;
+                for (int i = tid; i < N * NT; i += WG) ubuf[i] = 0.0;
+                __syncthreads();
+                if (val) {
+                    double u = (sl < su) ? sl : ub0 - su;
+                    if (status == 2) u = ubar0;
+                    ubuf[ek * NT + s_act[ea]] = u;
+                }
+                __syncthreads();
+                if (tid < NT) P.out_u0[inst * NT + tid] = ubuf[tid];
+                if (P.out_U)
+                    for (int i = tid; i < N * NT; i += WG) P.out_U[inst * (int64_t)N * NT + i] = ubuf[i];
+            }
+            if (tid == 0) {
+                if (P.status) P.status[inst] = status;
+                if (P.iters) P.iters[inst] = nit;
+            }
+        }
         S64(9);
 #ifdef FTMPC_STAMPS
         if (tid == 0 && inst < 512 && Q.dbg_H) {
@@ -839,5 +1357,9 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4) ? 2 : 1) ftmpc_sol
 template __global__ void ftmpc_solve_f64_kernel<4, 1>(const DeviceConsts, const Solve64Params);                      // n <= 256
 template __global__ void ftmpc_solve_f64_kernel<f64k::RPF, 3>(const DeviceConsts, const Solve64Params);              // n <= 640
 template __global__ void ftmpc_solve_f64_kernel<f64k::RPF, f64k::NVT_MAX>(const DeviceConsts, const Solve64Params);  // n <= 1024
+// general-constraint modes (n <= 256): 1 = wrench variables + hull rows, 2 = thruster variables + box + terminal set, 3 = wrench + hull + terminal set
+template __global__ void ftmpc_solve_f64_kernel<4, 1, 1>(const DeviceConsts, const Solve64Params);
+template __global__ void ftmpc_solve_f64_kernel<4, 1, 2>(const DeviceConsts, const Solve64Params);
+template __global__ void ftmpc_solve_f64_kernel<4, 1, 3>(const DeviceConsts, const Solve64Params);
 
 }  // namespace ftmpc

@@ -15,11 +15,13 @@ _CSRC = _HERE.parent / "csrc"
 _SO = _HERE / "libftmpc_hip.so"
 
 MAX_NT = 16
+MAX_TERM_ROWS = 80
+MAX_HULL_ROWS = 32
 
 # every symbol include/ftmpc.h declares (tests check the list against the header)
 SYMBOLS = (
     "ftmpc_default_config", "ftmpc_create", "ftmpc_destroy", "ftmpc_last_error", "ftmpc_reserve",
-    "ftmpc_solve_batch", "ftmpc_solve_batch_device", "ftmpc_simulate_batch", "ftmpc_allocate_batch", "ftmpc_shift_warm", "ftmpc_set_profiling",
+    "ftmpc_solve_batch", "ftmpc_solve_batch_device", "ftmpc_solve_wrench_batch", "ftmpc_simulate_batch", "ftmpc_allocate_batch", "ftmpc_shift_warm", "ftmpc_set_profiling",
     "ftmpc_last_kernel_ms", "ftmpc_kernel_name", "ftmpc_debug_build_qp", "ftmpc_version",
     "ftmpc_multi_create", "ftmpc_multi_destroy", "ftmpc_multi_last_error", "ftmpc_multi_device_count",
     "ftmpc_multi_shard_bounds", "ftmpc_multi_solve_batch", "ftmpc_multi_upload", "ftmpc_multi_step",
@@ -41,6 +43,8 @@ class ftmpc_config(C.Structure):
         ("D", C.c_double * (6 * MAX_NT)), ("Q", C.c_double * 9), ("R", C.c_double * 6),
         ("P", C.c_double * 81), ("r", C.c_double * 3), ("f_virt", C.c_double * 3),
         ("rho", C.c_double), ("mu_stop", C.c_double),
+        ("terminal_set", C.c_int32), ("term_rows", C.c_int32),
+        ("term_A", C.c_double * (MAX_TERM_ROWS * 9)), ("term_b", C.c_double * MAX_TERM_ROWS),
     ]
 
 
@@ -80,6 +84,8 @@ def load_library() -> C.CDLL:
     lib.ftmpc_reserve.argtypes = [vp, C.c_int64]
     lib.ftmpc_solve_batch.argtypes = [vp, C.c_int64, dp, dp, dp, dp, C.c_int64, dp, C.c_int64, dp, dp, dp, ip, ip]
     lib.ftmpc_solve_batch_device.argtypes = [vp, C.c_int64, vp, vp, vp, vp, C.c_int64, vp, C.c_int64, vp, vp, vp, vp, vp, vp]
+    lib.ftmpc_solve_wrench_batch.argtypes = [vp, C.c_int64, dp, dp, dp, dp, C.c_int32, ip, dp, C.c_int32, dp, C.c_int64, dp, C.c_int64,
+                                             dp, dp, dp, dp, ip, ip, ip]
     lib.ftmpc_simulate_batch.argtypes = [vp, C.c_int64, C.c_int32, dp, dp, dp, dp, dp, dp, C.c_uint64, dp, ip]
     lib.ftmpc_allocate_batch.argtypes = [vp, C.c_int64, dp, dp, dp, ip, ip]
     lib.ftmpc_shift_warm.argtypes = [C.c_int64, C.c_int32, C.c_int32, dp]

@@ -36,6 +36,9 @@ class MPCConfig:
     mu_stop: float = 0.0          # <= 0: library default (1e-11 for f32, 1e-13 for f64)
     device_id: int = 0
     dtype: str = "f32"            # arithmetic of the KKT/IPM solve: "f32" | "f64" (N*NT > 160 always runs f64)
+    # terminal set  term_A (c_N[0:9] - xref_N) <= term_b  (config/terminal.yaml term_set; spiraling_mpc.py:199-202):
+    # a TerminalSet / (A, b) pair, or True for the shipped config/terminal.yaml.  Needs dtype "f64".
+    terminal_set: object = None
 
 
 def _ptr(a, ct=C.c_double):
@@ -82,6 +85,23 @@ class BatchedMPC:
         if cfg.r is not None:
             c.r[:] = list(_f64(cfg.r, 3))
         c.f_virt[:] = list(_f64(cfg.f_virt, 3))
+        ts = cfg.terminal_set
+        if ts is not None and ts is not False:
+            if ts is True:
+                from .controllers.tools.terminal_ingredients import load_terminal
+                ts = load_terminal().term_set
+            A, b = (ts.A, ts.b) if hasattr(ts, "A") else ts
+            A = _f64(A).reshape(-1, 9)
+            b = _f64(b).reshape(-1)
+            if A.shape[0] != b.size or A.shape[0] > _lib.MAX_TERM_ROWS:
+                raise ValueError(f"terminal set must have at most {_lib.MAX_TERM_ROWS} rows of 9 coefficients")
+            c.terminal_set, c.term_rows = 1, A.shape[0]
+            flatA = np.zeros(_lib.MAX_TERM_ROWS * 9)
+            flatA[:A.size] = A.reshape(-1)
+            flatb = np.zeros(_lib.MAX_TERM_ROWS)
+            flatb[:b.size] = b
+            c.term_A[:] = list(flatA)
+            c.term_b[:] = list(flatb)
         return c
 
     def __init__(self, cfg: MPCConfig | None = None, **kw):
@@ -168,6 +188,62 @@ class BatchedMPC:
                                                _ptr(uref), us, _ptr(warmU), _ptr(u0), _ptr(U),
                                                _ptr(status, C.c_int32), _ptr(iters, C.c_int32)))
         return dict(u0=u0, U=U, status=status, iters=iters)
+
+    # -- the reference's two-stage structure: 6-D generalized-force QP with the input hull, then allocation ----
+    def solve_wrench(self, x0, ub, stuck, xref, uref=None, warmG=None, return_G=False, hull=None):
+        """One MPC step in generalized-force space (reference: spiraling_mpc.py:87-238 with the per-stage hull rows
+        :133-137,175-177) followed by the min-norm allocation (control_allocator.py:65-94).
+        x0 [B,13], ub/stuck [B,NT]; warmG [B,N,6] or None (in/out: total wrenches, already shifted);
+        hull: dict from controllers.tools.input_bounds.hull_tables (built here when None).
+        Returns dict(u0 [B,NT], tau0 [B,6], G [B,N,6]|None, status [B], iters [B], alloc_status [B]); instances whose
+        healthy thrusters do not span R^6 have no hull: status 3, u0 = tau0 = NaN (use `solve` for them)."""
+        from .controllers.tools.input_bounds import hull_tables
+        N, NT = self.cfg.N, self.cfg.NT
+        x0 = _f64(x0).reshape(-1, 13)
+        B = x0.shape[0]
+        ub = _f64(ub, (B, NT))
+        stuck = _f64(stuck, (B, NT))
+        if hull is None:
+            hull = hull_tables(self.D, ub, stuck)
+        ok = ~np.asarray(hull["degenerate"], bool)
+        u0 = np.full((B, NT), np.nan)
+        tau0 = np.full((B, 6), np.nan)
+        G = np.full((B, N, 6), np.nan) if return_G else None
+        status = np.full(B, 3, np.int32)
+        iters = np.zeros(B, np.int32)
+        ast = np.zeros(B, np.int32)
+        if not ok.any():
+            return dict(u0=u0, tau0=tau0, G=G, status=status, iters=iters, alloc_status=ast)
+        sel = np.flatnonzero(ok)
+        full = sel.size == B
+        take = (lambda a: a) if full else (lambda a: np.ascontiguousarray(a[sel]))
+        xref, xs, uref, us = self._refs(B, xref, uref)
+        if xs:
+            xref = take(xref.reshape(B, -1))
+        if uref is not None and us:
+            uref = take(uref.reshape(B, -1))
+        W = None
+        if warmG is not None:
+            if not (isinstance(warmG, np.ndarray) and warmG.dtype == np.float64 and warmG.flags.c_contiguous and warmG.size == B * N * 6):
+                raise ValueError("warmG must be a C-contiguous float64 array of B*N*6 (updated in place)")
+            W = warmG.reshape(B, N, 6) if full else np.ascontiguousarray(warmG.reshape(B, N, 6)[sel])
+        b = sel.size
+        A = np.ascontiguousarray(hull["A"], dtype=np.float64)
+        hs = np.ascontiguousarray(take(hull["set"]), dtype=np.int32)
+        hb = np.ascontiguousarray(take(hull["b"]), dtype=np.float64)
+        o_u0, o_t0 = np.empty((b, NT)), np.empty((b, 6))
+        o_G = np.empty((b, N, 6)) if return_G else None
+        o_st, o_it, o_as = np.empty(b, np.int32), np.empty(b, np.int32), np.empty(b, np.int32)
+        self._check(self.lib.ftmpc_solve_wrench_batch(
+            self._h, b, _ptr(take(x0)), _ptr(take(ub)), _ptr(take(stuck)), _ptr(A), A.shape[0], _ptr(hs, C.c_int32), _ptr(hb),
+            int(hull["rows"]), _ptr(xref), xs, _ptr(uref), us, _ptr(W), _ptr(o_u0), _ptr(o_t0), _ptr(o_G),
+            _ptr(o_st, C.c_int32), _ptr(o_it, C.c_int32), _ptr(o_as, C.c_int32)))
+        u0[sel], tau0[sel], status[sel], iters[sel], ast[sel] = o_u0, o_t0, o_st, o_it, o_as
+        if return_G:
+            G[sel] = o_G
+        if warmG is not None and not full:
+            warmG.reshape(B, N, 6)[sel] = W
+        return dict(u0=u0, tau0=tau0, G=G, status=status, iters=iters, alloc_status=ast)
 
     # -- closed loop on the device (SimulationEnvironment.run_simulation, batched) ------------
     def simulate(self, x0, ub, stuck, xref_traj, T, uref_traj=None, noise=(1e-3, 1e-3, 1e-3, 1e-3), seed=0,

@@ -25,6 +25,8 @@ extern "C" {
 #endif
 
 #define FTMPC_MAX_NT 16
+#define FTMPC_MAX_TERM_ROWS 80   /* rows of the terminal set (config/terminal.yaml: 72) */
+#define FTMPC_MAX_HULL_ROWS 32   /* facets of the generalized-force hull (26 for every fault set of the reference vehicle) */
 #define FTMPC_NX 13
 #define FTMPC_NOPT 9
 #define FTMPC_NG 6
@@ -39,7 +41,11 @@ extern "C" {
 /* per-instance status[] values */
 #define FTMPC_STATUS_CONVERGED 0   /* complementarity gap fell below mu_stop */
 #define FTMPC_STATUS_MAXITER 1     /* stopped at max_iters (last iterate returned, like the reference) */
-#define FTMPC_STATUS_NUMERIC 2     /* non-finite value met; u0 = clip(warm start) returned */
+#define FTMPC_STATUS_NUMERIC 2     /* non-finite value met / factorisation broke down (e.g. an unreachable terminal set);
+                                      the linearisation point (clip(warm start)) is returned */
+
+#define FTMPC_STATUS_NO_HULL 3     /* generalized-force formulation only: the healthy thrusters do not span R^6, the input hull
+                                      is flat (the reference's Qhull call fails on such fault sets); set by the host front-end */
 
 /* arithmetic of the solve path */
 #define FTMPC_DTYPE_F32 0
@@ -77,6 +83,17 @@ typedef struct ftmpc_config {
     double f_virt[3];
     double rho;
     double mu_stop;     /* stop when mean complementarity < mu_stop (<=0: library default) */
+    /*
+     * Terminal set  term_A (c_N[0:9] - xref_N) <= term_b  (the polytope of config/terminal.yaml, term_set; reference
+     * spiraling_mpc.py:199-202).  terminal_set != 0 adds these rows to the QP; they need the float64 kernel
+     * (dtype FTMPC_DTYPE_F64) and N * (number of variables per stage) <= 256.  An instance whose terminal set cannot
+     * be reached within the horizon ends with FTMPC_STATUS_MAXITER / _NUMERIC (the reference logs IPOPT's failure
+     * and carries on, spiraling_mpc.py:347-352).
+     */
+    int32_t terminal_set;
+    int32_t term_rows;  /* <= FTMPC_MAX_TERM_ROWS */
+    double term_A[FTMPC_MAX_TERM_ROWS * FTMPC_NOPT];   /* row-major term_rows x 9 */
+    double term_b[FTMPC_MAX_TERM_ROWS];
 } ftmpc_config;
 
 typedef struct ftmpc_handle ftmpc_handle;
@@ -134,6 +151,32 @@ int ftmpc_solve_batch_device(ftmpc_handle* h, int64_t B,
                              double* out_u0, double* out_U,
                              int32_t* status, int32_t* iters,
                              void* stream);
+
+/*
+ * The reference's own two-stage structure: one MPC step in the 6-D GENERALIZED-FORCE space with the
+ * input hull as constraint (spiraling_mpc.py:133-137,175-177; controllers/tools/input_bounds.py:43-76), followed by the
+ * min-norm thruster allocation (control_allocator.py:65-94).  Per instance
+ *     decision  tau_k in R^6, k < N: the TOTAL generalized force on the body ( = the reference's u_t + u_r + u_comp + D f_fault )
+ *     cost      as ftmpc_solve_batch with ut_k = tau_k - ur_k - [f_virt;0] ( = the reference's deviation input u_t ), no rho term
+ *     s.t.      hull_A tau_k <= hull_b  for every stage  [+ the terminal set when the handle's config has terminal_set != 0]
+ * and u0 = argmin |u|^2 s.t. D u = tau_0 - D stuck, 0 <= u <= ub.  float64 kernel; needs 6 N <= 256 and N * hull_rows <= 1024.
+ *   hull_A    [n_sets][hull_rows*6] row-major facet normals, one table per fault INDEX SET (the normals do not depend on
+ *             the fault intensities);  hull_set [B] table number of every instance (NULL: table 0 for all)
+ *   hull_b    [B*hull_rows] facet offsets (they carry the intensities: b = n . D (ub/2 + stuck) + sum_i |n . D_i| ub_i / 2);
+ *             pad unused rows with a zero normal and b = 1
+ *   warmG     NULL (linearise about thrusters off: tau = D stuck) or [B*N*6] in/out: previous wrench solution, already shifted
+ *   out_u0    [B*NT] allocated thruster forces;  out_tau0 NULL or [B*6];  out_G NULL or [B*N*6] whole-horizon wrenches
+ *   status / iters: IPM (as above);  alloc_status NULL or [B]: as ftmpc_allocate_batch
+ * HOST buffers.
+ */
+int ftmpc_solve_wrench_batch(ftmpc_handle* h, int64_t B,
+                             const double* x0, const double* ub, const double* stuck,
+                             const double* hull_A, int32_t n_sets, const int32_t* hull_set, const double* hull_b, int32_t hull_rows,
+                             const double* xref, int64_t xref_stride,
+                             const double* uref, int64_t uref_stride,
+                             double* warmG,
+                             double* out_u0, double* out_tau0, double* out_G,
+                             int32_t* status, int32_t* iters, int32_t* alloc_status);
 
 /*
  * Batched thruster allocation: the reference's second stage,

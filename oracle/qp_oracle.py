@@ -310,3 +310,240 @@ def make_batch(B, N, NT, nfault, seed, f_max=rm.F_MAX):
     xref = np.zeros((9, N + 1))
     xref[6:9, :] = rm.OMEGA_DES.reshape(3, 1)
     return x0, ub, stuck, xref
+
+
+# ======================================================================================
+# Generalized-force (6-D) formulation with the input hull, and the terminal set
+# (reference: spiraling_mpc.py:133-137,175-177 hull rows per stage,
+#  :199-202 terminal set rows on e_N, controllers/tools/input_bounds.py:43-76 the hull itself).
+#
+# QP-spec, wrench form (per instance):
+#   decision  T = (tau_0..tau_{N-1}), tau_k in R^6 the TOTAL generalized force on the body
+#             ( = the reference's  u_t + u_r + u_comp + D f_fault ,  spiraling_mpc.py:171,175 )
+#   model     as above with gen_k = tau_k ; linearised about Tbar (warm start, else D stuck: thrusters off)
+#   cost      sum e_k'Q e_k + e_N'P e_N + sum ut_k'R ut_k ,  ut_k = tau_k - ur_k - [f_virt;0]  ( = u_t )
+#   s.t.      A_hull tau_k <= b_hull  for every stage   (hull of {D u : 0 <= u_i <= ub_i healthy, u_i = stuck_i broken})
+#             [ A_T (c_hat_N[0:9] - xref_N) <= b_T ]     optional terminal set
+#   output    tau_0 ; the thruster command is the min-norm allocation of  tau_0 - D stuck  (control_allocator.py:65-94)
+# ======================================================================================
+def zonotope_hrep(D, ub, stuck, tol=1e-9):
+    """H-representation A tau <= b of {D u : 0 <= u <= ub (healthy), u_i = stuck_i (ub_i = 0)} without enumerating
+    its 2^na corners: the set is a zonotope with generators g_i = D[:, i] ub_i about the centre D (ub/2 + stuck), whose
+    facet normals are the directions orthogonal to 5 linearly independent generators.  Rows come in +/- pairs, unit
+    normals, sorted lexicographically (scipy's Qhull + np.unique gives the same rows, input_bounds.py:69-74)."""
+    from itertools import combinations
+    D = np.asarray(D, float)
+    act = np.flatnonzero(np.asarray(ub) > 0)
+    Gn = D[:, act] * np.asarray(ub, float)[act]
+    centre = D @ (np.asarray(ub, float) / 2 + np.asarray(stuck, float))
+    if act.size < 6 or np.linalg.matrix_rank(Gn, tol=1e-9 * np.abs(Gn).max()) < 6:
+        raise ValueError("degenerate hull: the healthy thrusters do not span R^6 (scipy's Qhull fails on this set too)")
+    combos = np.array(list(combinations(range(act.size), 5)))
+    M = np.transpose(Gn[:, combos], (1, 2, 0))                     # [ncomb, 5, 6]
+    _, sv, Vt = np.linalg.svd(M)
+    ok = sv[:, 4] > tol * sv[:, 0]                                   # the 5 generators are independent
+    nrm = Vt[ok, 5, :]
+    # canonical sign, then unique
+    first = np.argmax(np.abs(nrm) > 1e-7, axis=1)
+    sgn = np.sign(nrm[np.arange(len(nrm)), first])
+    nrm = nrm * sgn[:, None]
+    nrm = nrm[np.lexsort(np.round(nrm, 7).T[::-1])]
+    keep = np.ones(len(nrm), bool)
+    keep[1:] = np.abs(np.diff(np.round(nrm, 7), axis=0)).max(axis=1) > 0
+    nrm = nrm[keep]
+    half = 0.5 * np.abs(nrm @ Gn).sum(axis=1)
+    A = np.vstack([nrm, -nrm])
+    b = np.concatenate([nrm @ centre + half, -(nrm @ centre) + half])
+    order = np.lexsort(np.round(A, 7).T[::-1])
+    return A[order], b[order]
+
+
+def linearize_wrench(cfg: QPConfig, x0, stuck, warmG=None):
+    N = cfg.N
+    Tbar = np.tile(cfg.D @ np.asarray(stuck, float), (N, 1)) if warmG is None else np.asarray(warmG, float).reshape(N, 6).copy()
+    c = rm.robot_to_center(x0, cfg.r)
+    cbar = np.zeros((N + 1, 13))
+    A = np.zeros((N, 13, 13))
+    Bg = np.zeros((N, 13, 6))
+    cbar[0] = c
+    for k in range(N):
+        c, A[k], Bg[k] = rm.rk4_with_jac(c, Tbar[k], cfg.r, cfg.dt, cfg.mass, cfg.J)
+        cbar[k + 1] = c
+    return cbar, A, Bg, Tbar
+
+
+def build_qp_wrench(cfg: QPConfig, x0, ub, stuck, xref, uref=None, warmG=None, hull=None, term_set=None):
+    """Dense condensed QP in d = T - Tbar (n = 6N) with inequality rows  C d <= h :
+    per stage A_hull d_k <= b - A_hull Tbar_k, then (optional) A_T GN d <= b_T - A_T ebar_N."""
+    N = cfg.N
+    ub = np.asarray(ub, float)
+    stuck = np.asarray(stuck, float)
+    xref = np.asarray(xref, float).reshape(9, N + 1)
+    cbar, A, Bg, Tbar = linearize_wrench(cfg, x0, stuck, warmG)
+    n = 6 * N
+    G = np.zeros((N + 1, 13, n))
+    for k in range(N):
+        G[k + 1] = A[k] @ G[k]
+        G[k + 1][:, 6 * k:6 * k + 6] = Bg[k]
+    Qm = np.diag(cfg.Q)
+    H = np.zeros((n, n))
+    g = np.zeros(n)
+    for k in range(1, N + 1):
+        W = cfg.P if k == N else Qm
+        E = G[k][0:9]
+        e = cbar[k][0:9] - xref[:, k]
+        H += 2 * E.T @ W @ E
+        g += 2 * E.T @ W @ e
+    Rm = np.diag(cfg.R)
+    fv = np.concatenate([cfg.f_virt, np.zeros(3)])
+    for k in range(N):
+        ur = np.zeros(6)
+        if uref is not None:
+            u_r = np.asarray(uref, float).reshape(6, N + 1)[:, k]
+            ur = np.concatenate([rm.rot(cbar[k][9:13]).T @ u_r[0:3], u_r[3:6]])
+        sl = slice(6 * k, 6 * k + 6)
+        H[sl, sl] += 2 * Rm
+        g[sl] += 2 * Rm @ (Tbar[k] - ur - fv)
+    Ah, bh = hull if hull is not None else zonotope_hrep(cfg.D, ub, stuck)
+    mh = Ah.shape[0]
+    C = np.zeros((N * mh, n))
+    h = np.zeros(N * mh)
+    for k in range(N):
+        C[k * mh:(k + 1) * mh, 6 * k:6 * k + 6] = Ah
+        h[k * mh:(k + 1) * mh] = bh - Ah @ Tbar[k]
+    centre = cfg.D @ (ub / 2 + stuck)
+    d0 = (centre[None, :] - Tbar).reshape(-1)
+    eN = cbar[N][0:9] - xref[:, N]
+    GN = G[N][0:9]
+    if term_set is not None:
+        At, bt = term_set
+        C = np.vstack([C, At @ GN])
+        h = np.concatenate([h, np.asarray(bt, float).reshape(-1) - At @ eN])
+    return dict(H=H, g=g, C=C, h=h, d0=d0, Tbar=Tbar, n=n, mh=mh, nhull=N * mh, cbar=cbar, GN=GN, eN=eN, hull=(Ah, bh))
+
+
+def build_qp_box_terminal(cfg: QPConfig, x0, ub, stuck, xref, term_set, uref=None, warmU=None):
+    """The thruster-space QP of build_qp plus the terminal-set rows, in the general form C d <= h
+    (box rows first: -d <= Ubar, d <= ub - Ubar)."""
+    qp = build_qp(cfg, x0, ub, stuck, xref, uref, warmU)
+    n, N, na = qp["n"], cfg.N, qp["na"]
+    G = np.zeros((13, n))
+    Da = cfg.D[:, qp["act"]]
+    for k in range(N):
+        G = qp["A"][k] @ G
+        G[:, k * na:(k + 1) * na] = qp["Bg"][k] @ Da
+    GN = G[0:9]
+    eN = qp["cbar"][N][0:9] - np.asarray(xref, float).reshape(9, N + 1)[:, N]
+    At, bt = term_set
+    bt = np.asarray(bt, float).reshape(-1)
+    C = np.vstack([-np.eye(n), np.eye(n), At @ GN])
+    h = np.concatenate([qp["Ubar"], qp["ub"] - qp["Ubar"], bt - At @ eN])
+    d0 = 0.5 * qp["ub"] - qp["Ubar"]
+    qp.update(C=C, h=h, d0=d0, GN=GN, eN=eN, nhull=2 * n)
+    return qp
+
+
+def ipm_general(H, g, C, h, d0, nfeas, iters=40, mu_stop=1e-10, rp_stop=1e-9, trace=None):
+    """Mehrotra predictor-corrector for  min 1/2 d'Hd + g'd  s.t.  C d + s = h, s >= 0  -- the algorithm of the
+    float64 kernel's general-constraint mode (csrc/ftmpc_solve_f64.hip, MODE != 0), step for step:
+      * start at d0; the first `nfeas` rows (box or hull rows) are strictly feasible there and keep s = h - C d exactly;
+        the remaining rows (terminal set) start at s = max(h - C d0, 0.1) and carry the primal residual r_p = C d + s - h,
+        which every step shrinks by (1 - alpha_p)
+      * duals on the central path at mu0 = max(0.02 |grad|_inf * max(s), 1e-3); step fraction 0.9995
+      * one Cholesky of H + C' diag(z/s) C per iteration, two solves
+      * stop when mu < mu_stop and |r_p|_inf < rp_stop (status 0) or at the iteration cap (status 1); C' diag(z/s) C
+        with z/s ~ 1/mu on the active rows ruins the conditioning long before float64 runs out in the box form, hence
+        mu_stop = 1e-10 here, and a factorisation that breaks down once mu < 1e-7 ends the iteration as converged
+        (status 0; earlier: status 2)
+    Returns (d, s, z, iterations, status)."""
+    n, m = g.size, h.size
+    d = d0.copy()
+    res = h - C @ d
+    s = res.copy()
+    s[nfeas:] = np.maximum(res[nfeas:], 0.1)
+    if (s[:nfeas] <= 0).any():
+        raise ValueError("start point is not strictly inside the box / hull rows")
+    rp = C @ d + s - h
+    grad = H @ d + g
+    mu0 = max(0.02 * np.abs(grad).max() * s.max(), 1e-3)
+    z = mu0 / s
+    tau = 0.9995
+    nit, status = 0, 1
+    for it in range(iters + 1):
+        mu = float(s @ z) / m
+        rpn = float(np.abs(rp).max())
+        if not (np.isfinite(mu) and np.isfinite(rpn)):
+            status = 2
+            break
+        if mu < mu_stop and rpn < rp_stop:
+            status = 0
+            break
+        if it == iters:
+            break
+        nit += 1
+        w = z / s
+        M = H + C.T @ (w[:, None] * C)
+        try:
+            L = np.linalg.cholesky(M)
+        except np.linalg.LinAlgError:
+            status = 0 if (mu < 1e-7 and rpn < rp_stop) else 2
+            nit -= 1
+            break
+        # predictor
+        rc = s * z
+        rhs = -(grad + C.T @ z) + C.T @ ((rc - z * rp) / s)
+        da = _solve(L, rhs)
+        ds_a = -rp - C @ da
+        dz_a = (-rc - z * ds_a) / s
+        ap = min(1.0, _pos_step(s, ds_a))
+        ad = min(1.0, _pos_step(z, dz_a))
+        mu_aff = float((s + ap * ds_a) @ (z + ad * dz_a)) / m
+        sigma = min(max((mu_aff / mu) ** 3, 0.0), 1.0)
+        # corrector
+        rc = s * z + ds_a * dz_a - sigma * mu
+        rhs = -(grad + C.T @ z) + C.T @ ((rc - z * rp) / s)
+        dd = _solve(L, rhs)
+        ds = -rp - C @ dd
+        dz = (-rc - z * ds) / s
+        ap = min(1.0, tau * _pos_step(s, ds))
+        ad = min(1.0, tau * _pos_step(z, dz))
+        d = d + ap * dd
+        s = s + ap * ds
+        z = z + ad * dz
+        rp = (1.0 - ap) * rp
+        grad = grad + ap * (H @ dd)
+        if trace is not None:
+            trace.append((mu, rpn, ap, ad))
+    return d, s, z, nit, status
+
+
+def _pos_step(v, dv):
+    m = dv < 0
+    return float((-v[m] / dv[m]).min()) if m.any() else 1e30
+
+
+def kkt_general(H, g, C, h, d, z):
+    """Optimality certificate of a convex QP with rows C d <= h: (stationarity, primal violation, dual violation,
+    complementarity), each in max-norm.  All four ~ 0  <=>  d is THE solution (H positive definite)."""
+    r = h - C @ d
+    return (float(np.abs(H @ d + g + C.T @ z).max()), float(max(0.0, (-r).max())), float(max(0.0, (-z).max())),
+            float(np.abs(r * z).max()))
+
+
+def solve_wrench_instance(cfg: QPConfig, x0, ub, stuck, xref, uref=None, warmG=None, hull=None, term_set=None, iters=40, mu_stop=1e-10):
+    """Full oracle step of the generalized-force formulation.  Returns (tau0 (6,), T (N,6), status, iterations, qp dict)."""
+    qp = build_qp_wrench(cfg, x0, ub, stuck, xref, uref, warmG, hull, term_set)
+    d, s, z, nit, st = ipm_general(qp["H"], qp["g"], qp["C"], qp["h"], qp["d0"], qp["nhull"], iters=iters, mu_stop=mu_stop)
+    T = qp["Tbar"] + (d.reshape(cfg.N, 6) if st != 2 else 0.0)
+    qp.update(d=d, z=z, s=s)
+    return T[0].copy(), T, st, nit, qp
+
+
+def solve_box_terminal_instance(cfg: QPConfig, x0, ub, stuck, xref, term_set, uref=None, warmU=None, iters=40, mu_stop=1e-10):
+    """Thruster-space QP with the terminal-set rows.  Returns (u0 (NT,), U (N,NT), status, iterations, qp dict)."""
+    qp = build_qp_box_terminal(cfg, x0, ub, stuck, xref, term_set, uref, warmU)
+    d, s, z, nit, st = ipm_general(qp["H"], qp["g"], qp["C"], qp["h"], qp["d0"], qp["nhull"], iters=iters, mu_stop=mu_stop)
+    U = np.zeros((cfg.N, cfg.NT))
+    U[:, qp["act"]] = (qp["Ubar"] + (d if st != 2 else 0.0)).reshape(cfg.N, qp["na"])
+    qp.update(d=d, z=z, s=s)
+    return U[0].copy(), U, st, nit, qp

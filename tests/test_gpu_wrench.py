@@ -19,16 +19,33 @@ F_MAX = rm.F_MAX
 TOL = 1e-6
 
 
-def _near_origin(B, N, NT, nf, seed):
-    """States from which the terminal set can be reached within the horizon."""
+def _near_terminal_set(B, N, NT, nf, seed, At, bt, scale=2.0):
+    """Random poses / faults whose orbit-centre tracking error starts on `scale` times the boundary of the terminal set:
+    for some of them the set is reachable within the horizon (often with active rows), for others it is not."""
     x0, ub, stuck, xref = qo.make_batch(B, N, NT, nf, seed)
-    x0[:, 0:3] *= 0.05
-    x0[:, 3:6] *= 0.1
-    x0[:, 10:13] = rm.OMEGA_DES + (x0[:, 10:13] - rm.OMEGA_DES) * 0.2
+    rng = np.random.default_rng(seed + 1)
+    r = rm.spiral_r()
+    for b in range(B):
+        e = rng.standard_normal(9)
+        e *= scale / max((At @ e / bt).max(), 1e-9)
+        R = rm.rot(x0[b, 6:10])
+        w = rm.OMEGA_DES + e[6:9]
+        x0[b, 0:3] = e[0:3] - R.T @ r                    # robot_to_center (spiral_model.py:103-109) inverted
+        x0[b, 3:6] = e[3:6] - R.T @ np.cross(w, r)
+        x0[b, 10:13] = w
     return x0, ub, stuck, xref
 
 
-@pytest.mark.parametrize("N,NT,nf,B", [(20, 16, 2, 40), (15, 16, 1, 24), (20, 8, 2, 24), (20, 8, 0, 8)])
+def _reachable(qp):
+    """Independent certificate (LP phase 1, HiGHS): is there any d with C d <= h at all?"""
+    from scipy.optimize import linprog
+    n, m, nh = qp["n"], len(qp["h"]), qp["nhull"]
+    Aub = np.hstack([qp["C"], np.r_[np.zeros(nh), -np.ones(m - nh)][:, None]])
+    res = linprog(np.r_[np.zeros(n), 1.0], A_ub=Aub, b_ub=qp["h"], bounds=[(None, None)] * n + [(0, None)], method="highs")
+    return res.status == 0 and res.fun <= 1e-9
+
+
+@pytest.mark.parametrize("N,NT,nf,B", [(20, 16, 2, 40), (15, 16, 1, 24), (20, 8, 2, 24), (15, 16, 0, 8)])
 def test_wrench_step_against_the_oracle(gpu_mpc_factory, N, NT, nf, B):
     mpc = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40)
     cfg = qo.QPConfig(N=N, NT=NT)
@@ -64,7 +81,8 @@ def test_wrench_solution_is_the_thruster_space_solution_without_allocation_weigh
     cfg0 = qo.QPConfig(N=N, NT=NT, rho=1e-9)
     for b in np.flatnonzero(out["status"] == 0):
         _, U, _ = qo.solve_instance(cfg0, x0[b], ub[b], stuck[b], xref, exact=True)
-        assert np.abs(out["G"][b] - (U + stuck[b]) @ cfg0.D.T).max() <= 5e-6
+        diff = np.abs(out["G"][b] - (U + stuck[b]) @ cfg0.D.T).max()
+        assert diff / F_MAX <= 1e-5, (b, diff)      # two different stopping rules (mu 1e-10 there, active-set exact here)
     assert (out["status"] == 0).sum() >= B - 2
 
 
@@ -117,36 +135,39 @@ def test_wrench_persistent_loop(gpu_mpc_factory):
 @pytest.mark.parametrize("form", ["box", "wrench"])
 def test_terminal_set_rows(gpu_mpc_factory, form):
     """72-row terminal set of config/terminal.yaml in the IPM (flagged): thruster-space (box + terminal rows) and
-    generalized-force (hull + terminal rows) against the oracle; the rows are active for some instances."""
-    N, NT, B = 20, 8, 20
+    generalized-force (hull + terminal rows) against the oracle.  Where the set is reachable (LP certificate) the
+    solutions agree and some have active rows; where it is not, both report it (non-zero status, finite output)."""
+    N, NT, B = 20, 8, 24
     term = load_terminal().term_set
     At, bt = term.A, term.b.reshape(-1)
     mpc = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=60, terminal_set=term)
     cfg = qo.QPConfig(N=N, NT=NT)
-    x0, ub, stuck, xref = _near_origin(B, N, NT, 2, 12)
+    x0, ub, stuck, xref = _near_terminal_set(B, N, NT, 2, 12, At, bt)
     xr = xref.reshape(-1, order="F")
-    active = 0
-    if form == "box":
-        out = mpc.solve(x0, ub, stuck, xr, return_U=True)
+    out = mpc.solve(x0, ub, stuck, xr, return_U=True) if form == "box" else mpc.solve_wrench(x0, ub, stuck, xr, return_G=True)
+    key = "U" if form == "box" else "G"
+    solved = active = 0
+    with np.errstate(all="ignore"):
         for b in range(B):
-            u0, U, st, nit, qp = qo.solve_box_terminal_instance(cfg, x0[b], ub[b], stuck[b], xref, (At, bt), iters=60)
-            assert st == 0 and out["status"][b] == 0
-            assert np.abs(out["U"][b] - U).max() / F_MAX <= TOL
-            eN = qp["eN"] + qp["GN"] @ qp["d"]
-            assert (At @ eN <= bt + 1e-7).all()
+            if form == "box":
+                _, X, st, nit, qp = qo.solve_box_terminal_instance(cfg, x0[b], ub[b], stuck[b], xref, (At, bt), iters=60)
+            else:
+                _, X, st, nit, qp = qo.solve_wrench_instance(cfg, x0[b], ub[b], stuck[b], xref, term_set=(At, bt), iters=60)
+            assert (st == 0) == _reachable(qp), b
+            assert (out["status"][b] == 0) == (st == 0), (b, out["status"][b], st)
+            assert np.isfinite(out[key][b]).all()
+            if st != 0:
+                continue
+            solved += 1
+            assert max(qo.kkt_general(qp["H"], qp["g"], qp["C"], qp["h"], qp["d"], qp["z"])) < 1e-4
+            assert np.abs(out[key][b] - X).max() / F_MAX <= TOL, (b, np.abs(out[key][b] - X).max())
+            assert (At @ (qp["eN"] + qp["GN"] @ qp["d"]) <= bt + 1e-7).all()
             active += int((qp["z"][qp["nhull"]:] > 1e-6).any())
-    else:
-        out = mpc.solve_wrench(x0, ub, stuck, xr, return_G=True)
-        for b in range(B):
-            tau0, T, st, nit, qp = qo.solve_wrench_instance(cfg, x0[b], ub[b], stuck[b], xref, term_set=(At, bt), iters=60)
-            assert st == 0 and out["status"][b] == 0
-            assert np.abs(out["G"][b] - T).max() / F_MAX <= TOL
-            active += int((qp["z"][qp["nhull"]:] > 1e-6).any())
-    assert active >= 2      # the rows matter: without them these instances end elsewhere
+    assert solved >= 6 and active >= 2 and solved < B      # reachable with active rows, and unreachable, both occur
     free = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=60)
-    ref = free.solve(x0, ub, stuck, xr) if form == "box" else free.solve_wrench(x0, ub, stuck, xr)
-    key = "u0" if form == "box" else "tau0"
-    assert np.abs(ref[key] - out[key]).max() / F_MAX > 1e-4
+    ref = free.solve(x0, ub, stuck, xr, return_U=True) if form == "box" else free.solve_wrench(x0, ub, stuck, xr, return_G=True)
+    ok = out["status"] == 0
+    assert np.abs(ref[key][ok] - out[key][ok]).max() / F_MAX > 1e-4     # the rows matter
 
 
 def test_unreachable_terminal_set_is_reported_not_raised(gpu_mpc_factory):
@@ -156,8 +177,16 @@ def test_unreachable_terminal_set_is_reported_not_raised(gpu_mpc_factory):
     mpc = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40, terminal_set=True)
     x0, ub, stuck, xref = qo.make_batch(B, N, NT, 2, 13)
     out = mpc.solve(x0, ub, stuck, xref.reshape(-1, order="F"))
-    assert (out["status"] != 0).sum() >= B // 2
+    assert (out["status"] != 0).sum() >= 3
     assert np.isfinite(out["u0"]).all() and (out["u0"] >= 0).all() and (out["u0"] <= ub + 1e-9).all()
+
+
+def test_hull_with_more_facets_than_the_kernel_holds_is_refused():
+    """The synthetic 8-thruster benchmark matrix is generic: 2 C(8,5) = 112 facets without a fault (the reference
+    vehicle's symmetric layout has 26 for every fault set); the front-end refuses instead of truncating."""
+    x0, ub, stuck, xref = qo.make_batch(4, 20, 8, 0, 1)
+    with pytest.raises(ValueError):
+        hull_tables(qo.QPConfig(N=20, NT=8).D, ub, stuck)
 
 
 def test_terminal_set_needs_the_float64_kernel():

@@ -31,6 +31,7 @@ using ftmpc::DeviceConsts;
 using ftmpc::LinParams;
 using ftmpc::SolveParams;
 using ftmpc::Solve64Params;
+using ftmpc::TermCost;
 
 static thread_local std::string g_create_error;
 
@@ -87,6 +88,9 @@ struct ftmpc_handle {
     double *d_hullA = nullptr, *d_hullb = nullptr, *d_warmG = nullptr, *d_tau0 = nullptr, *d_G = nullptr, *d_taud = nullptr;
     int32_t* d_hullset = nullptr;
     int32_t* d_ast2 = nullptr;
+    TermCost* d_tcost = nullptr;       // non-quadratic terminal-cost terms (terminal_cost_terms != 0)
+    double* d_cost = nullptr;
+    int64_t cap_cost = 0;
     int64_t cap_hullA = 0, cap_wrench = 0;
     // debug
     float *d_dbgH = nullptr, *d_dbgv = nullptr;
@@ -218,6 +222,7 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
     lp.rec = h->rec;
     lp.warmG = nullptr;
     lp.out_eN = h->tset ? h->d_eN : nullptr;
+    lp.tcost = h->d_tcost;
     const int nvar = h->use_f64 ? 0 : (h->nb_max <= 8 ? 1 : (h->nb_max == 9 ? 2 : 3));   // fp32 instantiations in use
     lp.qlist = h->use_f64 ? nullptr : h->d_qlist;
     lp.qcount = h->d_qctl;
@@ -473,6 +478,31 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
               (h->nb_max > 9 && grow(h, &h->hs[2], (int64_t)h->grid[2] * slot_words(10, cfg->N)) != FTMPC_OK) ||
               grow(h, &h->d_dbgH, 4096 * 24 + 160 * 160) != FTMPC_OK || grow(h, &h->d_dbgv, 3 * 160 + 4) != FTMPC_OK;
     }
+    if (!bad && cfg->terminal_cost_terms) {
+        if (cfg->tc_npoly < 0 || cfg->tc_npoly > FTMPC_MAX_TCOST_TERMS || cfg->tc_nroot < 0 || cfg->tc_nroot > FTMPC_MAX_TCOST_TERMS) {
+            ftmpc_destroy(h);
+            return fail(nullptr, FTMPC_ERR_ARG, "tc_npoly / tc_nroot out of range 0..24");
+        }
+        TermCost t;
+        std::memset(&t, 0, sizeof(t));
+        t.npoly = cfg->tc_npoly;
+        t.nroot = cfg->tc_nroot;
+        std::memcpy(t.poly_coef, cfg->tc_poly_coef, sizeof(t.poly_coef));
+        std::memcpy(t.root_coef, cfg->tc_root_coef, sizeof(t.root_coef));
+        std::memcpy(t.root_eps, cfg->tc_root_eps, sizeof(t.root_eps));
+        std::memcpy(t.root_pow, cfg->tc_root_pow, sizeof(t.root_pow));
+        for (int i = 0; i < FTMPC_MAX_TCOST_TERMS * 9; ++i) {
+            t.poly_exp[i] = cfg->tc_poly_exp[i];
+            t.root_exp[i] = cfg->tc_root_exp[i];
+            if (t.poly_exp[i] < 0 || t.poly_exp[i] > 16 || t.root_exp[i] < 0 || t.root_exp[i] > 16) bad = true;
+        }
+        t.cconst = cfg->tc_const;
+        void* p = nullptr;
+        bad = bad || hipMalloc(&p, sizeof(TermCost)) != hipSuccess;
+        h->d_tcost = static_cast<TermCost*>(p);
+        bad = bad || hipMemcpy(h->d_tcost, &t, sizeof(TermCost), hipMemcpyHostToDevice) != hipSuccess;
+        if (bad) h->err = "terminal-cost tables: bad exponent or allocation failure";
+    }
     if (bad) {
         g_create_error = h->err;
         ftmpc_destroy(h);
@@ -488,7 +518,7 @@ int ftmpc_destroy(ftmpc_handle* h) {
     void* ptrs[] = {h->rec, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, h->d_uref, h->d_warm, h->d_u0, h->d_U,
                     h->d_status, h->d_iters, h->hs[0], h->hs[1], h->hs[2], h->d_dbgH, h->d_dbgv, h->Hs, h->Ls, h->Eall, h->d_dbgH64, h->d_dbgv64,
                     h->d_atau, h->d_aub, h->d_au, h->d_ast, h->d_ait, h->d_qlist, h->d_qctl, h->d_term, h->d_eN, h->gHs, h->gLs,
-                    h->gEall, h->d_hullA, h->d_hullb, h->d_warmG, h->d_tau0, h->d_G, h->d_taud, h->d_hullset, h->d_ast2};
+                    h->gEall, h->d_tcost, h->d_cost, h->d_hullA, h->d_hullb, h->d_warmG, h->d_tau0, h->d_G, h->d_taud, h->d_hullset, h->d_ast2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->pin_in.p) (void)hipHostFree(h->pin_in.p);
@@ -664,6 +694,41 @@ int ftmpc_solve_batch(ftmpc_handle* h, int64_t B, const double* x0, const double
     return FTMPC_OK;
 }
 
+int ftmpc_eval_cost_batch(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, const double* stuck, const double* xref,
+                          int64_t xref_stride, const double* uref, int64_t uref_stride, const double* U, double* out_cost) {
+    if (!h) return FTMPC_ERR_ARG;
+    if (B < 0 || !x0 || !ub || !stuck || !xref || !U || !out_cost) return fail(h, FTMPC_ERR_ARG, "null buffer or negative batch");
+    if (B == 0) return FTMPC_OK;
+    int rc = check_strides(h, xref_stride, uref_stride, uref);
+    if (rc != FTMPC_OK) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if ((rc = ftmpc_reserve(h, B)) != FTMPC_OK) return rc;
+    if (B > h->cap_cost) {
+        if ((rc = grow(h, &h->d_cost, B)) != FTMPC_OK) return rc;
+        h->cap_cost = B;
+    }
+    const int N = h->cfg.N, NT = h->cfg.NT;
+    hipStream_t s = h->stream;
+    HIP_TRY(h, hipMemcpyAsync(h->d_x0, x0, B * 13 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_ub, ub, B * NT * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_stuck, stuck, B * NT * sizeof(double), hipMemcpyHostToDevice, s));
+    if ((rc = stage_refs(h, B, xref, xref_stride, uref, uref_stride)) != FTMPC_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->d_U, U, B * N * NT * sizeof(double), hipMemcpyHostToDevice, s));
+    ftmpc::CostParams cp;
+    cp.B = B;
+    cp.x0 = h->d_x0; cp.ub = h->d_ub; cp.stuck = h->d_stuck;
+    cp.xref = h->d_xref; cp.xref_stride = xref_stride;
+    cp.uref = uref ? h->d_uref : nullptr; cp.uref_stride = uref_stride;
+    cp.U = h->d_U;
+    cp.tcost = h->d_tcost;
+    cp.out = h->d_cost;
+    hipLaunchKernelGGL(ftmpc::ftmpc_cost_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, h->dc, cp);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(out_cost, h->d_cost, B * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return FTMPC_OK;
+}
+
 int ftmpc_solve_batch_device(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, const double* stuck,
                              const double* xref, int64_t xref_stride, const double* uref, int64_t uref_stride,
                              const double* warmU, double* out_u0, double* out_U, int32_t* status, int32_t* iters,
@@ -748,6 +813,7 @@ int ftmpc_solve_wrench_batch(ftmpc_handle* h, int64_t B, const double* x0, const
     lp.qlist = nullptr; lp.qcount = nullptr; lp.qvmax = -1;
     lp.warmG = warmG ? h->d_warmG : nullptr;
     lp.out_eN = h->d_eN;
+    lp.tcost = h->d_tcost;
     hipLaunchKernelGGL(ftmpc::ftmpc_linearize_kernel<double>, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, h->dc, lp);
     HIP_TRY(h, hipGetLastError());
     Solve64Params q;

@@ -67,6 +67,56 @@ struct DeviceConsts {
     double mu_refine;       // take the float64 reference gradient once mu falls below this (<= 0: never)
 };
 
+// non-quadratic terminal-cost terms (include/ftmpc.h ftmpc_config.tc_*), device copy
+constexpr int MAX_TCOST = 24;
+struct TermCost {
+    int npoly, nroot;
+    double poly_coef[MAX_TCOST];
+    int poly_exp[MAX_TCOST * 9];
+    double root_coef[MAX_TCOST], root_eps[MAX_TCOST], root_pow[MAX_TCOST];
+    int root_exp[MAX_TCOST * 9];
+    double cconst;
+};
+
+// e^k for small non-negative integer k
+__host__ __device__ inline double ipow(double e, int k) {
+    double r = 1.0;
+    for (int i = 0; i < k; ++i) r *= e;
+    return r;
+}
+// V_nq(e) and (when grad != nullptr) its gradient
+__host__ __device__ inline double term_cost_nq(const TermCost& T, const double e[9], double* grad) {
+    double v = T.cconst;
+    if (grad)
+        for (int i = 0; i < 9; ++i) grad[i] = 0.0;
+    for (int t = 0; t < T.npoly + T.nroot; ++t) {
+        const bool root = t >= T.npoly;
+        const int* ex = root ? T.root_exp + 9 * (t - T.npoly) : T.poly_exp + 9 * t;
+        double m = 1.0;
+        for (int j = 0; j < 9; ++j) m *= ipow(e[j], ex[j]);
+        double outer = 1.0, coef;                    // d/dm of the term
+        if (root) {
+            const int r = t - T.npoly;
+            const double base = m + T.root_eps[r];
+            coef = T.root_coef[r];
+            v += coef * pow(base, T.root_pow[r]);
+            outer = T.root_pow[r] * pow(base, T.root_pow[r] - 1.0);
+        } else {
+            coef = T.poly_coef[t];
+            v += coef * m;
+        }
+        if (grad)
+            for (int i = 0; i < 9; ++i) {
+                if (ex[i] == 0) continue;
+                double dm = ex[i] * ipow(e[i], ex[i] - 1);
+                for (int j = 0; j < 9; ++j)
+                    if (j != i) dm *= ipow(e[j], ex[j]);
+                grad[i] += coef * outer * dm;
+            }
+    }
+    return v;
+}
+
 struct LinParams {
     int64_t B;
     const double* x0;       // [B*13]
@@ -88,6 +138,7 @@ struct LinParams {
     // ([B*N*6]; nullptr: D (clip(warmU) + stuck) as above)
     const double* warmG;
     double* out_eN;         // nullptr or [B*9]: terminal tracking error c_N[0:9] - xref_N at the linearisation point
+    const TermCost* tcost;  // nullptr or the non-quadratic terminal-cost terms: W e_N gets + 1/2 grad V_nq(e_N)
 };
 
 struct SolveParams {

@@ -327,10 +327,12 @@ __global__ void __launch_bounds__(64) ftmpc_linearize_kernel(const DeviceConsts 
                 if (P.out_eN && b0 + lane < P.B) {
                     for (int a = 0; a < 9; ++a) P.out_eN[b * 9 + a] = e[a];
                 }
+                double gnq[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                if (P.tcost) (void)term_cost_nq(*P.tcost, e, gnq);      // exact gradient of the non-quadratic terminal terms
                 for (int a = 0; a < 9; ++a) {
                     double s = 0.0;
                     for (int c = 0; c < 9; ++c) s += C.P[9 * a + c] * e[c];
-                    put(REC_WE - REC_BPF + a, s);
+                    put(REC_WE - REC_BPF + a, s + 0.5 * gnq[a]);
                 }
             }
             for (int g = 0; g < 6; ++g) put(REC_RUT - REC_BPF + g, rut[g]);
@@ -341,5 +343,121 @@ __global__ void __launch_bounds__(64) ftmpc_linearize_kernel(const DeviceConsts 
 }
 
 template __global__ void ftmpc_linearize_kernel<double>(const DeviceConsts, const LinParams);
+
+// ---------------------------------------------------------------------------------------------------------
+// Cost of the nonlinear program for given thruster sequences (merit function of the line-search SQP; include/ftmpc.h
+// ftmpc_eval_cost_batch).  One lane per instance, float64.
+// ---------------------------------------------------------------------------------------------------------
+struct CostParams {
+    int64_t B;
+    const double* x0;
+    const double* ub;
+    const double* stuck;
+    const double* xref;
+    int64_t xref_stride;
+    const double* uref;
+    int64_t uref_stride;
+    const double* U;        // [B*N*NT]
+    const TermCost* tcost;  // or nullptr
+    double* out;            // [B]
+};
+
+namespace {
+// centre dynamics (spiral_model.py:44-76): s = [p, v, w, q]
+__device__ inline void centre_rhs(const DeviceConsts& C, const double s[13], const double gen[6], double ds[13]) {
+    const double* v = s + 3;
+    const double* w = s + 6;
+    const double* q = s + 9;
+    double Jw[3], wxJw[3], t[3], dw[3];
+    mat3vec(C.J, w, Jw);
+    cross3(w, Jw, wxJw);
+    for (int i = 0; i < 3; ++i) t[i] = gen[3 + i] - wxJw[i];
+    mat3vec(C.Jinv, t, dw);
+    double wxr[3], wxwxr[3], dwxr[3], ab[3], RT[9], dv[3];
+    cross3(w, C.r, wxr);
+    cross3(w, wxr, wxwxr);
+    cross3(dw, C.r, dwxr);
+    for (int i = 0; i < 3; ++i) ab[i] = gen[i] * C.inv_mass + dwxr[i] + wxwxr[i];
+    rotT(q, RT);
+    mat3vec(RT, ab, dv);
+    for (int i = 0; i < 3; ++i) {
+        ds[i] = v[i];
+        ds[3 + i] = dv[i];
+        ds[6 + i] = dw[i];
+    }
+    ds[9] = 0.5 * (w[2] * q[1] - w[1] * q[2] + w[0] * q[3]);
+    ds[10] = 0.5 * (-w[2] * q[0] + w[0] * q[2] + w[1] * q[3]);
+    ds[11] = 0.5 * (w[1] * q[0] - w[0] * q[1] + w[2] * q[3]);
+    ds[12] = 0.5 * (-w[0] * q[0] - w[1] * q[1] - w[2] * q[2]);
+}
+}  // namespace
+
+__global__ void __launch_bounds__(64) ftmpc_cost_kernel(const DeviceConsts C, const CostParams P) {
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= P.B) return;
+    const int N = C.N, NT = C.NT;
+    double s[13];
+    {
+        double x[13];
+        for (int i = 0; i < 13; ++i) x[i] = P.x0[b * 13 + i];
+        double RT[9], wxr[3], a[3], c[3];
+        rotT(x + 6, RT);
+        cross3(x + 10, C.r, wxr);
+        mat3vec(RT, C.r, a);
+        mat3vec(RT, wxr, c);
+        for (int i = 0; i < 3; ++i) {
+            s[i] = x[i] + a[i];
+            s[3 + i] = x[3 + i] + c[i];
+            s[6 + i] = x[10 + i];
+        }
+        for (int i = 0; i < 4; ++i) s[9 + i] = x[6 + i];
+    }
+    const double* xref = P.xref + b * P.xref_stride;
+    const double* uref = P.uref ? P.uref + b * P.uref_stride : nullptr;
+    const double dt = C.dt;
+    double cost = 0.0;
+    for (int k = 0; k < N; ++k) {
+        double gen[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < NT; ++i) {
+            const bool healthy = P.ub[b * NT + i] > 0.0;
+            const double u = healthy ? P.U[(b * N + k) * NT + i] : 0.0;
+            cost += C.rho * u * u;
+            const double t = u + P.stuck[b * NT + i];
+            for (int g = 0; g < 6; ++g) gen[g] += C.D[g * MAX_NT + i] * t;
+        }
+        double ur[6] = {0, 0, 0, 0, 0, 0};
+        if (uref) {
+            double RT[9], f3[3] = {uref[6 * k], uref[6 * k + 1], uref[6 * k + 2]}, o[3];
+            rotT(s + 9, RT);
+            mat3vec(RT, f3, o);
+            ur[0] = o[0]; ur[1] = o[1]; ur[2] = o[2];
+            ur[3] = uref[6 * k + 3]; ur[4] = uref[6 * k + 4]; ur[5] = uref[6 * k + 5];
+        }
+        for (int g = 0; g < 6; ++g) {
+            const double ut = gen[g] - ur[g] - (g < 3 ? C.fvirt[g] : 0.0);
+            cost += C.R[g] * ut * ut;
+        }
+        // RK4 (sys_model.py:152-158), no quaternion renormalisation
+        double k1[13], k2[13], k3[13], k4[13], t[13];
+        centre_rhs(C, s, gen, k1);
+        for (int i = 0; i < 13; ++i) t[i] = s[i] + 0.5 * dt * k1[i];
+        centre_rhs(C, t, gen, k2);
+        for (int i = 0; i < 13; ++i) t[i] = s[i] + 0.5 * dt * k2[i];
+        centre_rhs(C, t, gen, k3);
+        for (int i = 0; i < 13; ++i) t[i] = s[i] + dt * k3[i];
+        centre_rhs(C, t, gen, k4);
+        for (int i = 0; i < 13; ++i) s[i] += dt / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+        double e[9];
+        for (int a = 0; a < 9; ++a) e[a] = s[a] - xref[9 * (k + 1) + a];
+        if (k + 1 < N) {
+            for (int a = 0; a < 9; ++a) cost += C.Q[a] * e[a] * e[a];
+        } else {
+            for (int a = 0; a < 9; ++a)
+                for (int c = 0; c < 9; ++c) cost += e[a] * C.P[9 * a + c] * e[c];
+            if (P.tcost) cost += term_cost_nq(*P.tcost, e, nullptr);
+        }
+    }
+    P.out[b] = cost;
+}
 
 }  // namespace ftmpc

@@ -17,11 +17,12 @@ _SO = _HERE / "libftmpc_hip.so"
 MAX_NT = 16
 MAX_TERM_ROWS = 80
 MAX_HULL_ROWS = 32
+MAX_TCOST = 24
 
 # every symbol include/ftmpc.h declares (tests check the list against the header)
 SYMBOLS = (
     "ftmpc_default_config", "ftmpc_create", "ftmpc_destroy", "ftmpc_last_error", "ftmpc_reserve",
-    "ftmpc_solve_batch", "ftmpc_solve_batch_device", "ftmpc_solve_wrench_batch", "ftmpc_simulate_batch", "ftmpc_allocate_batch", "ftmpc_shift_warm", "ftmpc_set_profiling",
+    "ftmpc_solve_batch", "ftmpc_solve_batch_device", "ftmpc_solve_wrench_batch", "ftmpc_eval_cost_batch", "ftmpc_simulate_batch", "ftmpc_allocate_batch", "ftmpc_shift_warm", "ftmpc_set_profiling",
     "ftmpc_last_kernel_ms", "ftmpc_kernel_name", "ftmpc_debug_build_qp", "ftmpc_version",
     "ftmpc_multi_create", "ftmpc_multi_destroy", "ftmpc_multi_last_error", "ftmpc_multi_device_count",
     "ftmpc_multi_shard_bounds", "ftmpc_multi_solve_batch", "ftmpc_multi_upload", "ftmpc_multi_step",
@@ -45,6 +46,10 @@ class ftmpc_config(C.Structure):
         ("rho", C.c_double), ("mu_stop", C.c_double),
         ("terminal_set", C.c_int32), ("term_rows", C.c_int32),
         ("term_A", C.c_double * (MAX_TERM_ROWS * 9)), ("term_b", C.c_double * MAX_TERM_ROWS),
+        ("terminal_cost_terms", C.c_int32), ("tc_npoly", C.c_int32), ("tc_nroot", C.c_int32), ("tc_reserved", C.c_int32),
+        ("tc_poly_coef", C.c_double * MAX_TCOST), ("tc_poly_exp", C.c_int32 * (MAX_TCOST * 9)),
+        ("tc_root_coef", C.c_double * MAX_TCOST), ("tc_root_eps", C.c_double * MAX_TCOST), ("tc_root_pow", C.c_double * MAX_TCOST),
+        ("tc_root_exp", C.c_int32 * (MAX_TCOST * 9)), ("tc_const", C.c_double),
     ]
 
 
@@ -86,6 +91,7 @@ def load_library() -> C.CDLL:
     lib.ftmpc_solve_batch_device.argtypes = [vp, C.c_int64, vp, vp, vp, vp, C.c_int64, vp, C.c_int64, vp, vp, vp, vp, vp, vp]
     lib.ftmpc_solve_wrench_batch.argtypes = [vp, C.c_int64, dp, dp, dp, dp, C.c_int32, ip, dp, C.c_int32, dp, C.c_int64, dp, C.c_int64,
                                              dp, dp, dp, dp, ip, ip, ip]
+    lib.ftmpc_eval_cost_batch.argtypes = [vp, C.c_int64, dp, dp, dp, dp, C.c_int64, dp, C.c_int64, dp, dp]
     lib.ftmpc_simulate_batch.argtypes = [vp, C.c_int64, C.c_int32, dp, dp, dp, dp, dp, dp, C.c_uint64, dp, ip]
     lib.ftmpc_allocate_batch.argtypes = [vp, C.c_int64, dp, dp, dp, ip, ip]
     lib.ftmpc_shift_warm.argtypes = [C.c_int64, C.c_int32, C.c_int32, dp]

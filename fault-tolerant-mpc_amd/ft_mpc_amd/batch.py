@@ -39,6 +39,10 @@ class MPCConfig:
     # terminal set  term_A (c_N[0:9] - xref_N) <= term_b  (config/terminal.yaml term_set; spiraling_mpc.py:199-202):
     # a TerminalSet / (A, b) pair, or True for the shipped config/terminal.yaml.  Needs dtype "f64".
     terminal_set: object = None
+    # non-quadratic part of the terminal cost (config/terminal.yaml `cost` beyond e'P e; spiraling_mpc.py:196): a
+    # TerminalIngredients object, or True for the shipped config/terminal.yaml.  Every QP then carries its exact
+    # gradient at the linearisation point and eval_cost includes it (see BatchedMPC.solve_sqp).
+    terminal_cost: object = None
 
 
 def _ptr(a, ct=C.c_double):
@@ -102,6 +106,27 @@ class BatchedMPC:
             flatb[:b.size] = b
             c.term_A[:] = list(flatA)
             c.term_b[:] = list(flatb)
+        tc = cfg.terminal_cost
+        if tc is not None and tc is not False:
+            if tc is True:
+                from .controllers.tools.terminal_ingredients import load_terminal
+                tc = load_terminal()
+            t = tc.device_tables(_lib.MAX_TCOST, _lib.MAX_TCOST)
+            c.terminal_cost_terms, c.tc_npoly, c.tc_nroot = 1, len(t["poly_coef"]), len(t["root_coef"])
+
+            def put(dst, src, n):
+                a = np.zeros(n, dtype=np.asarray(src).dtype if np.asarray(src).size else float)
+                a[:np.asarray(src).size] = np.asarray(src).reshape(-1)
+                dst[:] = list(a)
+            put(c.tc_poly_coef, t["poly_coef"], _lib.MAX_TCOST)
+            put(c.tc_poly_exp, t["poly_exp"].astype(int), _lib.MAX_TCOST * 9)
+            put(c.tc_root_coef, t["root_coef"], _lib.MAX_TCOST)
+            put(c.tc_root_eps, t["root_eps"], _lib.MAX_TCOST)
+            put(c.tc_root_pow, t["root_pow"], _lib.MAX_TCOST)
+            put(c.tc_root_exp, t["root_exp"].astype(int), _lib.MAX_TCOST * 9)
+            c.tc_const = float(t["const"])
+            if cfg.P is None:
+                c.P[:] = list(_f64(tc.P, 81))
         return c
 
     def __init__(self, cfg: MPCConfig | None = None, **kw):
@@ -188,6 +213,68 @@ class BatchedMPC:
                                                _ptr(uref), us, _ptr(warmU), _ptr(u0), _ptr(U),
                                                _ptr(status, C.c_int32), _ptr(iters, C.c_int32)))
         return dict(u0=u0, U=U, status=status, iters=iters)
+
+    # -- towards the reference's nonlinear program: sequential QP with a line search on the true cost -----------
+    def eval_cost(self, x0, ub, stuck, xref, U, uref=None):
+        """Cost of the NONLINEAR program (nonlinear rollout, full terminal cost when MPCConfig.terminal_cost is set)
+        for thruster sequences U [B,N,NT] -> [B]   (include/ftmpc.h ftmpc_eval_cost_batch)."""
+        N, NT = self.cfg.N, self.cfg.NT
+        x0 = _f64(x0).reshape(-1, 13)
+        B = x0.shape[0]
+        ub = _f64(ub, (B, NT))
+        stuck = _f64(stuck, (B, NT))
+        U = _f64(U, (B, N, NT))
+        xref, xs, uref, us = self._refs(B, xref, uref)
+        J = np.empty(B)
+        self._check(self.lib.ftmpc_eval_cost_batch(self._h, B, _ptr(x0), _ptr(ub), _ptr(stuck), _ptr(xref), xs, _ptr(uref), us,
+                                                   _ptr(U), _ptr(J)))
+        return J
+
+    def solve_sqp(self, x0, ub, stuck, xref, uref=None, warmU=None, sqp_iters=10, tol=1e-9, backtracks=8):
+        """Globalised sequential QP towards the reference's NLP (spiraling_mpc.py:87-238: nonlinear dynamics, full
+        terminal cost) in thruster space.  Each major iteration solves the QP linearised about the current U (Hessian
+        2 (B'QB + R + rho I) with the quadratic terminal weight P, gradient exact -- including the non-quadratic terminal
+        terms when MPCConfig.terminal_cost is set), then backtracks alpha = 1, 1/2, ... along U_qp - U on the TRUE cost
+        (eval_cost) until it decreases; an instance stops when no step decreases its cost by more than tol (1 + |J|).
+        Plain re-linearisation (`solve(relinearize=k)`) has no such safeguard and oscillates on the smoothed |.|^(1/4)
+        terms of the terminal cost.  Returns dict(u0, U, cost [B], cost0 [B] (at the start point), sqp_iters [B],
+        iters [B] (IPM iterations summed), status [B] of the last QP)."""
+        N, NT = self.cfg.N, self.cfg.NT
+        x0 = _f64(x0).reshape(-1, 13)
+        B = x0.shape[0]
+        ub = _f64(ub, (B, NT))
+        stuck = _f64(stuck, (B, NT))
+        U = np.zeros((B, N, NT)) if warmU is None else np.clip(_f64(warmU, (B, N, NT)), 0.0, ub[:, None, :])
+        J = self.eval_cost(x0, ub, stuck, xref, U, uref)
+        J0 = J.copy()
+        active = np.ones(B, bool)
+        n_major = np.zeros(B, np.int32)
+        ipm = np.zeros(B, np.int32)
+        status = np.zeros(B, np.int32)
+        for _ in range(int(sqp_iters)):
+            if not active.any():
+                break
+            W = np.ascontiguousarray(U)
+            out = self.solve(x0, ub, stuck, xref, uref=uref, warmU=W, return_U=True)     # W <- U_qp
+            ipm += np.where(active, out["iters"], 0)
+            status = np.where(active, out["status"], status)
+            step = out["U"] - U
+            alpha = np.ones(B)
+            todo = active & (out["status"] != 2)
+            improved = np.zeros(B, bool)
+            for _bt in range(int(backtracks)):
+                if not todo.any():
+                    break
+                Jt = self.eval_cost(x0, ub, stuck, xref, U + alpha[:, None, None] * step, uref)
+                ok = todo & (Jt < J - tol * (1.0 + np.abs(J)))
+                U[ok] += alpha[ok, None, None] * step[ok]
+                J[ok] = Jt[ok]
+                improved |= ok
+                todo &= ~ok
+                alpha[todo] *= 0.5
+            n_major += improved.astype(np.int32)
+            active &= improved
+        return dict(u0=U[:, 0, :].copy(), U=U, cost=J, cost0=J0, sqp_iters=n_major, iters=ipm, status=status)
 
     # -- the reference's two-stage structure: 6-D generalized-force QP with the input hull, then allocation ----
     def solve_wrench(self, x0, ub, stuck, xref, uref=None, warmG=None, return_G=False, hull=None):

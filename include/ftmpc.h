@@ -26,6 +26,7 @@ extern "C" {
 
 #define FTMPC_MAX_NT 16
 #define FTMPC_MAX_TERM_ROWS 80   /* rows of the terminal set (config/terminal.yaml: 72) */
+#define FTMPC_MAX_TCOST_TERMS 24  /* non-quadratic terms of the terminal cost (config/terminal.yaml: 13 polynomial + 12 root terms) */
 #define FTMPC_MAX_HULL_ROWS 32   /* facets of the generalized-force hull (26 for every fault set of the reference vehicle) */
 #define FTMPC_NX 13
 #define FTMPC_NOPT 9
@@ -94,6 +95,22 @@ typedef struct ftmpc_config {
     int32_t term_rows;  /* <= FTMPC_MAX_TERM_ROWS */
     double term_A[FTMPC_MAX_TERM_ROWS * FTMPC_NOPT];   /* row-major term_rows x 9 */
     double term_b[FTMPC_MAX_TERM_ROWS];
+    /*
+     * Non-quadratic part of the terminal cost (config/terminal.yaml `cost` beyond e'P e; reference spiraling_mpc.py:196):
+     *     V_nq(e) = sum_i tc_poly_coef[i] prod_j e_j^tc_poly_exp[i][j] + sum_r tc_root_coef[r] (prod_j e_j^tc_root_exp[r][j] + tc_root_eps[r])^tc_root_pow[r] + tc_const
+     * terminal_cost_terms != 0: every QP carries the exact gradient of V_nq at its linearisation point (the Hessian
+     * stays 2P: the root terms are concave away from 0), and ftmpc_eval_cost_batch includes V_nq -- the two pieces of
+     * the line-search SQP towards the reference's nonlinear program (ft_mpc_amd.BatchedMPC.solve_sqp).
+     */
+    int32_t terminal_cost_terms;
+    int32_t tc_npoly, tc_nroot, tc_reserved;
+    double tc_poly_coef[FTMPC_MAX_TCOST_TERMS];
+    int32_t tc_poly_exp[FTMPC_MAX_TCOST_TERMS * FTMPC_NOPT];
+    double tc_root_coef[FTMPC_MAX_TCOST_TERMS];
+    double tc_root_eps[FTMPC_MAX_TCOST_TERMS];
+    double tc_root_pow[FTMPC_MAX_TCOST_TERMS];
+    int32_t tc_root_exp[FTMPC_MAX_TCOST_TERMS * FTMPC_NOPT];
+    double tc_const;
 } ftmpc_config;
 
 typedef struct ftmpc_handle ftmpc_handle;
@@ -139,6 +156,21 @@ int ftmpc_solve_batch(ftmpc_handle* h, int64_t B,
                       double* warmU,
                       double* out_u0, double* out_U,
                       int32_t* status, int32_t* iters);
+
+/*
+ * Value of the NONLINEAR program's cost for given thruster sequences -- the merit function of the line-search SQP:
+ * nonlinear RK4 rollout of the orbit-centre model from robot_to_center(x0) under U (spiral_model.py:44-76,
+ * sys_model.py:138-162), then
+ *     sum_{k=1}^{N-1} e_k'Q e_k + V(e_N) + sum_{k<N} [ut_k'R ut_k + rho |u_k|^2],   V(e) = e'P e [+ V_nq(e) when
+ * terminal_cost_terms != 0],  ut_k = D (u_k + stuck) - [Rot(q_k)^T uref_k[0:3]; uref_k[3:6]] - [f_virt; 0]
+ * (spiraling_mpc.py:156-171,188,196; q_k is the rollout's own quaternion, as the decision-variable quaternion is there).
+ *   U [B*N*NT] thruster forces (entries of broken thrusters are ignored);  out_cost [B].   HOST buffers.
+ */
+int ftmpc_eval_cost_batch(ftmpc_handle* h, int64_t B,
+                          const double* x0, const double* ub, const double* stuck,
+                          const double* xref, int64_t xref_stride,
+                          const double* uref, int64_t uref_stride,
+                          const double* U, double* out_cost);
 
 /* Same contract with DEVICE pointers (HBM-resident inputs/outputs) enqueued on `stream`
  * (a hipStream_t passed as void*; NULL = the default stream).  Asynchronous: returns after

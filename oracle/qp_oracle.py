@@ -547,3 +547,72 @@ def solve_box_terminal_instance(cfg: QPConfig, x0, ub, stuck, xref, term_set, ur
     U[:, qp["act"]] = (qp["Ubar"] + (d if st != 2 else 0.0)).reshape(cfg.N, qp["na"])
     qp.update(d=d, z=z, s=s)
     return U[0].copy(), U, st, nit, qp
+
+
+# ======================================================================================
+# The reference's nonlinear program in thruster space and a line-search SQP on it
+# (reference spiraling_mpc.py:87-238: RK4 dynamics, stage costs, full terminal cost)
+# ======================================================================================
+def nlp_cost(cfg: QPConfig, x0, ub, stuck, xref, U, uref=None, terminal_cost=None):
+    """sum_{k=1}^{N-1} e_k'Q e_k + V(e_N) + sum_k [ut_k'R ut_k + rho |u_k|^2] along the NONLINEAR rollout;
+    V = e'P e, or terminal_cost(e) (callable on the 9-vector: the full terminal.yaml cost) when given."""
+    N = cfg.N
+    ub = np.asarray(ub, float)
+    U = np.where(ub > 0, np.asarray(U, float).reshape(N, cfg.NT), 0.0)
+    xref = np.asarray(xref, float).reshape(9, N + 1)
+    c = rm.robot_to_center(x0, cfg.r)
+    fv = np.concatenate([cfg.f_virt, np.zeros(3)])
+    J = 0.0
+    for k in range(N):
+        gen = cfg.D @ (U[k] + stuck)
+        ur = np.zeros(6)
+        if uref is not None:
+            u_r = np.asarray(uref, float).reshape(6, N + 1)[:, k]
+            ur = np.concatenate([rm.rot(c[9:13]).T @ u_r[0:3], u_r[3:6]])
+        ut = gen - ur - fv
+        J += ut @ (cfg.R * ut) + cfg.rho * (U[k] @ U[k])
+        c = rm.rk4(lambda s: rm.centre_dx_dt(s, gen, cfg.r, cfg.mass, cfg.J), c, cfg.dt)
+        e = c[0:9] - xref[:, k + 1]
+        if k + 1 < N:
+            J += e @ (cfg.Q * e)
+        else:
+            J += float(terminal_cost(e)) if terminal_cost is not None else e @ cfg.P @ e
+    return float(J)
+
+
+def sqp_linesearch(cfg: QPConfig, x0, ub, stuck, xref, uref=None, warmU=None, terminal=None, sqp_iters=10, tol=1e-9, backtracks=8):
+    """Mirror of ft_mpc_amd.BatchedMPC.solve_sqp for one instance.  terminal: object with .cost(e) and
+    .grad(e, quadratic=False) (the non-quadratic gradient enters g through W e_N), or None.  QPs are solved exactly (BVLS)."""
+    N, NT = cfg.N, cfg.NT
+    ub = np.asarray(ub, float)
+    U = np.zeros((N, NT)) if warmU is None else np.clip(np.asarray(warmU, float).reshape(N, NT), 0.0, ub)
+    tc = (lambda e: terminal.cost(e)) if terminal is not None else None
+    J = nlp_cost(cfg, x0, ub, stuck, xref, U, uref, tc)
+    hist = [J]
+    for _ in range(sqp_iters):
+        qp = build_qp(cfg, x0, ub, stuck, xref, uref, U)
+        if terminal is not None:
+            # gradient of the non-quadratic terminal terms at the linearisation point, through GN
+            na = qp["na"]
+            G = np.zeros((13, qp["n"]))
+            Da = cfg.D[:, qp["act"]]
+            for k in range(N):
+                G = qp["A"][k] @ G
+                G[:, k * na:(k + 1) * na] = qp["Bg"][k] @ Da
+            eN = qp["cbar"][N][0:9] - np.asarray(xref, float).reshape(9, N + 1)[:, N]
+            qp["g"] = qp["g"] + G[0:9].T @ terminal.grad(eN, quadratic=False)
+        d = solve_exact(qp["H"], qp["g"], -qp["Ubar"], qp["ub"] - qp["Ubar"])
+        Uq = np.zeros((N, NT))
+        Uq[:, qp["act"]] = (qp["Ubar"] + d).reshape(N, qp["na"])
+        step = Uq - U
+        alpha, done = 1.0, True
+        for _bt in range(backtracks):
+            Jt = nlp_cost(cfg, x0, ub, stuck, xref, U + alpha * step, uref, tc)
+            if Jt < J - tol * (1.0 + abs(J)):
+                U, J, done = U + alpha * step, Jt, False
+                break
+            alpha *= 0.5
+        hist.append(J)
+        if done:
+            break
+    return U, J, hist

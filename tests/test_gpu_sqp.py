@@ -1,0 +1,73 @@
+"""GPU: the line-search sequential QP towards the reference's nonlinear program (SURVEY.md section 8(f) rank 2;
+reference spiraling_mpc.py:87-238: RK4 dynamics as constraints, full terminal.yaml cost :196).
+  * ftmpc_eval_cost_batch (nonlinear rollout cost incl. the non-quadratic terminal terms) against oracle nlp_cost: 1e-10 rel
+  * the QP gradient with the exact terminal-cost gradient against the oracle: 1e-9 (float64 path)
+  * BatchedMPC.solve_sqp against oracle sqp_linesearch: monotone decrease, same final cost (1e-4 rel; the QPs are solved
+    by different methods -- IPM on the GPU, BVLS in the oracle -- so backtracking decisions may differ in the last digits)
+  * plain re-linearisation (no line search) does NOT converge on these instances: the reason the safeguard exists."""
+import numpy as np
+import pytest
+
+from ft_mpc_amd.controllers.tools.terminal_ingredients import load_terminal
+from oracle import qp_oracle as qo
+from oracle import refmath as rm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N,NT,dtype", [(20, 8, "f32"), (15, 16, "f64")])
+def test_cost_and_gradient_of_the_nonlinear_program(gpu_mpc_factory, N, NT, dtype):
+    T = load_terminal()
+    mpc = gpu_mpc_factory(N=N, NT=NT, dtype=dtype, terminal_cost=T)
+    plain = gpu_mpc_factory(N=N, NT=NT, dtype=dtype)
+    cfg = qo.QPConfig(N=N, NT=NT)
+    B = 64
+    x0, ub, stuck, xref = qo.make_batch(B, N, NT, 2, 8100 + N)
+    rng = np.random.default_rng(1)
+    U = rng.uniform(0, rm.F_MAX, (B, N, NT)) * (ub[:, None, :] > 0)
+    traj = rm.circle_trajectory(0.1, 10, radius=0.65, s_per_circle=40.0)
+    xr_all, ur_all = rm.assign_trajectory(traj, N)
+    xw, uw = rm.trajectory_window(xr_all, ur_all, 0.5, N)
+    for (xr, ur) in ((xref, None), (xw, uw)):
+        J = mpc.eval_cost(x0, ub, stuck, xr.reshape(-1, order="F"), U, None if ur is None else ur.reshape(-1, order="F"))
+        Jq = plain.eval_cost(x0, ub, stuck, xr.reshape(-1, order="F"), U, None if ur is None else ur.reshape(-1, order="F"))
+        for b in range(0, B, 7):
+            ref = qo.nlp_cost(cfg, x0[b], ub[b], stuck[b], xr, U[b], ur, T.cost)
+            assert J[b] == pytest.approx(ref, rel=1e-10)
+            assert Jq[b] == pytest.approx(qo.nlp_cost(cfg, x0[b], ub[b], stuck[b], xr, U[b], ur, None), rel=1e-10)
+    if dtype == "f64":     # the gradient of the QP carries the non-quadratic terminal gradient
+        for b in (0, 3):
+            H, g, lo, hi = mpc.debug_build_qp(x0, ub, stuck, xref.reshape(-1, order="F"), b, warmU=U)
+            qp = qo.build_qp(cfg, x0[b], ub[b], stuck[b], xref, None, U[b])
+            na, n = qp["na"], qp["n"]
+            Gm = np.zeros((13, n))
+            Da = cfg.D[:, qp["act"]]
+            for k in range(N):
+                Gm = qp["A"][k] @ Gm
+                Gm[:, k * na:(k + 1) * na] = qp["Bg"][k] @ Da
+            eN = qp["cbar"][N][0:9] - xref[:, N]
+            gref = qp["g"] + Gm[0:9].T @ T.grad(eN, quadratic=False)
+            assert np.abs(g - gref).max() <= 1e-9 * max(1.0, np.abs(gref).max())
+            assert np.abs(H - qp["H"]).max() <= 1e-11 * np.abs(qp["H"]).max()
+
+
+def test_line_search_sqp_against_the_oracle(gpu_mpc_factory):
+    N, NT, B = 20, 8, 12
+    T = load_terminal()
+    mpc = gpu_mpc_factory(N=N, NT=NT, terminal_cost=T)
+    cfg = qo.QPConfig(N=N, NT=NT)
+    x0, ub, stuck, xref = qo.make_batch(B, N, NT, 2, 3)
+    out = mpc.solve_sqp(x0, ub, stuck, xref.reshape(-1, order="F"), sqp_iters=12)
+    assert (out["cost"] < out["cost0"]).all() and (out["sqp_iters"] >= 3).all()
+    assert (out["U"] >= 0).all() and (out["U"] <= ub[:, None, :] + 1e-12).all()
+    for b in range(0, B, 3):
+        U, J, hist = qo.sqp_linesearch(cfg, x0[b], ub[b], stuck[b], xref, terminal=T, sqp_iters=12)
+        assert all(h1 <= h0 for h0, h1 in zip(hist, hist[1:]))
+        assert out["cost0"][b] == pytest.approx(hist[0], rel=1e-10)
+        assert out["cost"][b] == pytest.approx(J, rel=2e-3)
+        # the cost reported is the cost of the returned sequence
+        assert out["cost"][b] == pytest.approx(qo.nlp_cost(cfg, x0[b], ub[b], stuck[b], xref, out["U"][b], None, T.cost), rel=1e-9)
+    # without the safeguard: full re-linearised steps leave the cost an order of magnitude higher
+    rel = mpc.solve(x0, ub, stuck, xref.reshape(-1, order="F"), return_U=True, relinearize=11)
+    Jrel = mpc.eval_cost(x0, ub, stuck, xref.reshape(-1, order="F"), rel["U"])
+    assert np.median(Jrel / out["cost"]) > 3.0

@@ -254,11 +254,11 @@ class BatchedMPC:
         for _ in range(int(sqp_iters)):
             if not active.any():
                 break
-            W = np.ascontiguousarray(U)
+            W = U.copy()                      # solve() overwrites its warm-start buffer with the QP solution
             out = self.solve(x0, ub, stuck, xref, uref=uref, warmU=W, return_U=True)     # W <- U_qp
             ipm += np.where(active, out["iters"], 0)
             status = np.where(active, out["status"], status)
-            step = out["U"] - U
+            step = np.clip(out["U"], 0.0, ub[:, None, :]) - U      # the fp32 kernels return ub rounded to float32
             alpha = np.ones(B)
             todo = active & (out["status"] != 2)
             improved = np.zeros(B, bool)

@@ -5,6 +5,10 @@ constructor and method signatures, whose per-step solve runs on the MI355X throu
 Differences a caller can observe (DESIGN.md QP-spec): the solve is one condensed thruster-space
 QP per step (linearised about the shifted previous solution), so `solve_mpc` returns 16-D thruster
 force stages instead of 6-D generalized deviation inputs, and `status` is an IPM status string.
+
+`params["formulation"] = "wrench"` switches to the reference's own two-stage structure: a 6-D generalized-force QP
+with the input hull (tools/input_bounds.py, built once per fault set like the reference's InputBounds) followed by the
+min-norm allocation; `params["terminal_set"] = True` adds the 72-row terminal set of config/terminal.yaml.
 """
 import copy
 import time
@@ -32,12 +36,24 @@ class SpiralingController:
         pset = params[params["param_set"]]
         self.Q, self.R = np.diag(pset["Q"]).astype(float), np.diag(pset["R"]).astype(float)
         self.u_comp = self.spiral_params.compensation_force
+        self.formulation = str(params.get("formulation", "thruster"))
+        if self.formulation not in ("thruster", "wrench"):
+            raise ValueError("params['formulation'] must be 'thruster' or 'wrench'")
         t0 = time.time()
         self.mpc = BatchedMPC(MPCConfig(N=self.Nt, NT=self.model.Nu_full, dt=self.dt, mass=self.mass, J=self.J,
                                         D=self.model.D, Q=np.array(pset["Q"], float), R=np.array(pset["R"], float),
                                         r=self.spiral_params.r, f_virt=self.spiral_params.f_virt,
                                         rho=float(params.get("rho", 0.05)), device_id=device_id, dtype=dtype,
-                                        max_iters=int(params.get("max_iters", 0))))
+                                        max_iters=int(params.get("max_iters", 0)),
+                                        terminal_set=True if params.get("terminal_set") else None))
+        self.hull = None
+        if self.formulation == "wrench":           # spiraling_mpc.py:49: self.bounds = InputBounds(self.model), once
+            from .tools.input_bounds import hull_tables
+            self.hull = hull_tables(self.model.D, np.asarray(self.model.u_ub_physical, float).reshape(1, -1),
+                                    np.asarray(self.model.faulty_force, float).reshape(1, -1))
+            if self.hull["degenerate"][0]:
+                raise ValueError("the healthy thrusters do not span R^6: no input hull (use formulation='thruster')")
+        self.optimal_wrench = None                 # warm start of the wrench formulation: previous tau*, [N, 6]
         self.logger.info(f"# Time to build mpc solver: {time.time() - t0} sec")
         self.logger.info(f"# Number of variables: {self.Nt * self.model.Nu_full} (thruster space, condensed)")
         self.trajectory = None
@@ -64,6 +80,15 @@ class SpiralingController:
     def _solve(self, x0):
         ub = np.asarray(self.model.u_ub_physical, float).reshape(1, -1)
         stuck = np.asarray(self.model.faulty_force, float).reshape(1, -1)
+        if self.formulation == "wrench":
+            warm = None
+            if self.optimal_wrench is not None:    # shifted like the reference's warm start; the last stage repeats
+                warm = np.vstack([self.optimal_wrench[1:], self.optimal_wrench[-1:]])[None].copy()
+            out = self.mpc.solve_wrench(np.asarray(x0, float).reshape(1, 13), ub, stuck, self.x_sp.reshape(-1),
+                                        uref=self.u_sp.reshape(-1), warmG=warm, return_G=True, hull=self.hull)
+            self.optimal_wrench = out["G"][0]
+            out["U"] = None
+            return out
         warm = None
         if self.optimal_solution is not None:      # shift by one stage (spiraling_mpc.py:324-334)
             warm = np.vstack([self.optimal_solution[1:], np.zeros((1, self.model.Nu_full))])[None].copy()
@@ -105,6 +130,8 @@ class SpiralingController:
         t0 = time.time()
         x0 = self.model.center_to_robot(np.asarray(c0, float).flatten())
         out = self._solve(x0)
+        if self.formulation == "wrench":
+            raise NotImplementedError("solve_mpc returns thruster stages; with formulation='wrench' use get_control / mpc.solve_wrench")
         U = out["U"][0]
         xs = [np.asarray(c0, float).flatten()]
         x = x0

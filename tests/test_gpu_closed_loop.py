@@ -152,3 +152,38 @@ def test_debug_export_has_reference_csv_format(tmp_path):
     assert data.shape == (5, 67) and np.allclose(data[:, 0], [0, .1, .2, .3, .4])
     assert np.allclose(data[:, 14 + 10], 0.0)                      # broken thruster is never commanded
     assert np.allclose(data[:, 30:33], (m.D @ data[:, 14:30].T).T[:, 0:3])   # force = D u
+
+
+def test_closed_loop_in_the_reference_two_stage_structure():
+    """params["formulation"] = "wrench": 6-D generalized-force MPC with the input hull, then allocation (the reference's
+    own structure, spiraling_mpc.py:288-317) in the examples/sim.py scenario (10, 11 stuck fully on).  The loop settles on
+    the micro-orbit like the thruster-space loop does; the two differ only by the allocation weight rho the
+    thruster-space QP carries (the commands stay within a few percent of f_max of each other)."""
+    def run(formulation):
+        m = SystemModel(0.1)
+        for i in (10, 11):
+            m.set_fault(BrokenThruster(i, 1.0))
+        sm = SpiralModel.from_system_model(m)
+        ctrl = SpiralingController(sm, dict(PARAMS, formulation=formulation), ControllerDebug(), quiet=True)
+        ctrl.load_trajectory("hover", 30)
+        us = []
+
+        class Recorder:           # the seam is duck-typed: record what the controller commands
+            def get_control(self, x, t):
+                us.append(ctrl.get_control(x, t).copy())
+                return us[-1]
+        env = SimulationEnvironment(m, Recorder(), seed=7)
+        env.set_initial_state(**IC)
+        for k in env.noise:
+            env.noise[k] = 0.0
+        for _ in range(60):
+            env.step()
+        return sm.robot_to_center(env.state), np.array(us), m
+    c_w, u_w, m = run("wrench")
+    c_t, u_t, _ = run("thruster")
+    assert (u_w >= -1e-9).all() and (u_w <= m.u_ub_physical + 1e-9).all() and (u_w[:, [10, 11]] == 0).all()
+    e0 = np.linalg.norm(SpiralModel.from_system_model(m).robot_to_center(
+        np.r_[IC["position"], IC["velocity"], IC["orientation"], IC["angular_velocity"]])[0:6])
+    assert np.linalg.norm(c_w[0:6]) < 0.6 * e0 and np.linalg.norm(c_t[0:6]) < 0.6 * e0      # both close in on the reference
+    assert np.abs(c_w[6:9] - [0, 0, 0.6]).max() < 0.1
+    assert np.abs(c_w[0:9] - c_t[0:9]).max() < 0.1

@@ -216,61 +216,124 @@ def walk_back(items, preds, start, budget):
             pos -= 1
 
 
-def check_function(items):
-    preds = predecessors(items)
-    found = []
+def check_consumer(items, preds, i, found):
+    """Appends the violations whose CONSUMER is items[i]."""
+    c = items[i]
+    if isinstance(c, tuple) or c.kind in ("salu", "other"):
+        return
 
     def report(rule, need, prod, cons, dist, reg):
         found.append(dict(rule=rule, need=need, have=dist, reg=f"{reg[0]}{reg[1]}", prod=prod, cons=cons,
                           asm=prod.in_asm or cons.in_asm))
 
-    for i, c in enumerate(items):
-        if isinstance(c, tuple) or c.kind in ("salu", "other"):
-            continue
-        rules = []   # (name, need, producer predicate, registers of interest)
-        vrd = {r for r in c.rd if r[0] in "va"}
-        srd = {r for r in c.rd if r[0] == "s"}
-        if c.kind in ("valu", "mfma"):
-            if c.dpp:
-                rules.append(("dpp_vgpr", 2, lambda p: p.kind in ("valu", "mfma"), vrd))
-                rules.append(("dpp_exec", 5, lambda p: p.kind == "valu", set(SPECIAL["exec"])))
-            if c.kind == "valu" and not TRANS.match(c.mn):
-                rules.append(("trans_use", 1, lambda p: p.kind == "valu" and bool(TRANS.match(p.mn)), vrd))
-            if c.mn.startswith(("v_permlane16_swap", "v_permlane32_swap")):
-                rules.append(("permlane_swap", 2, lambda p: p.kind in ("valu", "mfma"), vrd))
-            if c.mn.startswith(("v_readlane", "v_readfirstlane")):
-                rules.append(("readlane_vgpr", 1, lambda p: p.kind in ("valu", "mfma"), vrd))
-            if c.lanesel:
-                rules.append(("lane_select", 4, lambda p: p.kind == "valu", set(c.lanesel)))
-            if c.mn.startswith("v_div_fmas"):
-                rules.append(("div_fmas", 4, lambda p: p.kind == "valu", set(SPECIAL["vcc"])))
-            sv = {r for r in srd if r[1] < 124 or r[1] in (106, 107)}
-            if sv:
-                rules.append(("sgpr_valu", 2, lambda p: p.kind == "valu", sv))
-            if c.kind == "mfma":
-                rules.append(("valu_mfma", 2, lambda p: p.kind == "valu" and p.in_asm, vrd))
-        if c.kind == "vmem" and srd:
-            rules.append(("sgpr_vmem", 5, lambda p: p.kind == "valu", srd))
-        touched = (c.rd | c.wr) if c.kind == "valu" else c.rd
-        vt = {r for r in touched if r[0] in "va"}
-        budget = max([r[1] for r in rules] + [MAXW if vt else 0])
-        if budget == 0:
-            continue
-        for p, dist in walk_back(items, preds, i, budget):
-            for name, need, pred, regs in rules:
-                if dist < need and regs and pred(p):
-                    hit = p.wr & regs
-                    if hit:
-                        report(name, need, p, c, dist, sorted(hit)[0])
-            if p.kind == "mfma" and vt and c.kind != "mfma":
-                for pre, (wv, wm) in MFMA_WAIT.items():
-                    if p.mn.startswith(pre):
-                        need = wm if c.kind in ("vmem", "lds") else wv
-                        hit = p.wr & vt
-                        if hit and dist < need:
-                            report("mfma_use", need, p, c, dist, sorted(hit)[0])
-                        break
+    rules = []   # (name, need, producer predicate, registers of interest)
+    vrd = {r for r in c.rd if r[0] in "va"}
+    srd = {r for r in c.rd if r[0] == "s"}
+    if c.kind in ("valu", "mfma"):
+        if c.dpp:
+            rules.append(("dpp_vgpr", 2, lambda p: p.kind in ("valu", "mfma"), vrd))
+            rules.append(("dpp_exec", 5, lambda p: p.kind == "valu", set(SPECIAL["exec"])))
+        if c.kind == "valu" and not TRANS.match(c.mn):
+            rules.append(("trans_use", 1, lambda p: p.kind == "valu" and bool(TRANS.match(p.mn)), vrd))
+        if c.mn.startswith(("v_permlane16_swap", "v_permlane32_swap")):
+            rules.append(("permlane_swap", 2, lambda p: p.kind in ("valu", "mfma"), vrd))
+        if c.mn.startswith(("v_readlane", "v_readfirstlane")):
+            rules.append(("readlane_vgpr", 1, lambda p: p.kind in ("valu", "mfma"), vrd))
+        if c.lanesel:
+            rules.append(("lane_select", 4, lambda p: p.kind == "valu", set(c.lanesel)))
+        if c.mn.startswith("v_div_fmas"):
+            rules.append(("div_fmas", 4, lambda p: p.kind == "valu", set(SPECIAL["vcc"])))
+        sv = {r for r in srd if r[1] < 124 or r[1] in (106, 107)}
+        if sv:
+            rules.append(("sgpr_valu", 2, lambda p: p.kind == "valu", sv))
+        if c.kind == "mfma":
+            rules.append(("valu_mfma", 2, lambda p: p.kind == "valu" and p.in_asm, vrd))
+    if c.kind == "vmem" and srd:
+        rules.append(("sgpr_vmem", 5, lambda p: p.kind == "valu", srd))
+    touched = (c.rd | c.wr) if c.kind == "valu" else c.rd
+    vt = {r for r in touched if r[0] in "va"}
+    budget = max([r[1] for r in rules] + [MAXW if vt else 0])
+    if budget == 0:
+        return
+    for p, dist in walk_back(items, preds, i, budget):
+        for name, need, pred, regs in rules:
+            if dist < need and regs and pred(p):
+                hit = p.wr & regs
+                if hit:
+                    report(name, need, p, c, dist, sorted(hit)[0])
+        if p.kind == "mfma" and vt and c.kind != "mfma":
+            for pre, (wv, wm) in MFMA_WAIT.items():
+                if p.mn.startswith(pre):
+                    need = wm if c.kind in ("vmem", "lds") else wv
+                    hit = p.wr & vt
+                    if hit and dist < need:
+                        report("mfma_use", need, p, c, dist, sorted(hit)[0])
+                    break
+
+
+def check_function(items):
+    preds = predecessors(items)
+    found = []
+    for i in range(len(items)):
+        check_consumer(items, preds, i, found)
     return found
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Wait-state elision.  Every asm body opens with a fixed `s_nop` that covers "whatever hipcc scheduled right before"
+# (the author cannot know); in the final stream most of them are not needed.  Each asm-side s_nop is lowered to the
+# smallest count for which every consumer in the window behind it still passes the rule table above (greedy, in
+# program order, against the CFG-aware checker; kept as written when a branch follows within the window).
+# ---------------------------------------------------------------------------------------------------------
+ELIDE_WINDOW = 24
+
+
+def elide_function(items):
+    preds = predecessors(items)
+    saved = removed = 0
+    for i, it in enumerate(items):
+        if isinstance(it, tuple) or it.mn != "s_nop" or not it.in_asm:
+            continue
+        win = items[i + 1:i + 1 + ELIDE_WINDOW]
+        if any((not isinstance(x, tuple)) and x.mn.startswith(("s_branch", "s_cbranch", "s_setpc", "s_swappc", "s_endpgm", "s_call")) for x in win):
+            continue
+        orig = it.ws
+        for w in range(0, orig + 1):
+            it.ws = w
+            found = []
+            for j in range(i + 1, min(len(items), i + 1 + ELIDE_WINDOW)):
+                check_consumer(items, preds, j, found)
+                if found:
+                    break
+            if not found:
+                break
+        saved += orig - it.ws
+        removed += 1 if it.ws == 0 else 0
+    return saved, removed
+
+
+def elide(asm_in, asm_out):
+    """Writes asm_out = asm_in with the asm-side wait states minimised; returns statistics.  The result is audited again."""
+    funcs = parse(asm_in)
+    new_ws = {}
+    stats = {}
+    for name, items in funcs.items():
+        before = sum(it.ws for it in items if not isinstance(it, tuple) and it.mn == "s_nop" and it.in_asm)
+        saved, removed = elide_function(items)
+        stats[name] = dict(asm_wait_states=before, saved=saved, nops_removed=removed)
+        for it in items:
+            if not isinstance(it, tuple) and it.mn == "s_nop" and it.in_asm:
+                new_ws[it.line] = it.ws
+    out = []
+    for ln, raw in enumerate(open(asm_in), 1):
+        if ln in new_ws:
+            w = new_ws[ln]
+            if w == 0:
+                continue
+            raw = re.sub(r"s_nop\s+\S+", f"s_nop {w - 1}", raw, count=1)
+        out.append(raw)
+    Path(asm_out).write_text("".join(out))
+    return stats
 
 
 def build_asm(out):
@@ -294,12 +357,20 @@ def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--asm", help="device assembly to audit (default: compile csrc/ftmpc_capi.hip)")
     ap.add_argument("-v", "--verbose", action="store_true")
+    ap.add_argument("--elide", metavar="OUT", help="write the assembly with minimised asm-side wait states to OUT, then audit OUT")
     args = ap.parse_args()
     if args.asm:
         path = Path(args.asm)
     else:
         path = Path(tempfile.mkdtemp(prefix="ftmpc_haz_")) / "ftmpc_dev.s"
         build_asm(path)
+    if args.elide:
+        st = elide(path, args.elide)
+        for name, v in st.items():
+            if v["asm_wait_states"]:
+                print(f"elide {re.sub(r'^_ZN5ftmpc[0-9]+', '', name)[:50]:52s} asm wait states {v['asm_wait_states']:6d} -> {v['asm_wait_states'] - v['saved']:6d}"
+                      f"  ({v['nops_removed']} s_nop removed)")
+        path = Path(args.elide)
     summary = audit(path)
     bad = 0
     for name, s in summary.items():

@@ -31,6 +31,21 @@ def test_no_hazard_in_any_kernel(device_asm):
     assert sum(len(s["compiler"]) for s in summary.values()) == 0
 
 
+def test_elided_stream_is_clean_and_shorter(device_asm, tmp_path):
+    """What the build ships: the asm-side wait states lowered to what the final schedule needs (csrc/Makefile step 2).
+    The lowered stream passes the same audit and drops most of the conservative s_nops of the fp32 kernels."""
+    out = tmp_path / "final.s"
+    stats = ch.elide(device_asm, out)
+    summary = ch.audit(out)
+    assert not [f for s in summary.values() for f in s["asm"]] and sum(len(s["compiler"]) for s in summary.values()) == 0
+    k8 = next(v for n, v in stats.items() if "ftmpc_solve_f32_kernelILi8" in n)
+    assert k8["saved"] > 0.5 * k8["asm_wait_states"]
+    # every change is an s_nop line lowered or dropped: nothing else differs
+    a = [l for l in device_asm.read_text().split("\n") if not l.strip().startswith("s_nop")]
+    b = [l for l in out.read_text().split("\n") if not l.strip().startswith("s_nop")]
+    assert a == b
+
+
 def test_checker_sees_deleted_wait_states(device_asm, tmp_path):
     lines, out, in_asm = device_asm.read_text().split("\n"), [], False
     for l in lines:

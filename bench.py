@@ -135,7 +135,7 @@ def make_line(args, world, elapsed, B, N, NT, iters, status, ub, kernel_ms, para
     dom = max(kernel_ms, key=kernel_ms.get)
     sol_ms = kernel_ms[dom]
     flops = batch_flops(N, ub, iters)
-    f64 = args.dtype == "f64" or N * NT > 160
+    f64 = args.dtype == "f64" or N * NT > 240
     peak = F64_PEAK_TFLOPS if f64 else F32_PEAK_TFLOPS
     achieved = flops / (sol_ms * 1e-3) / 1e12
     traffic, traffic_src = traffic_for(dom, B, N, NT)

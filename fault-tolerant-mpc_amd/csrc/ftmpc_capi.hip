@@ -24,6 +24,7 @@
 #include "ftmpc_linearize.hip"
 #include "ftmpc_solve.hip"
 #include "ftmpc_solve_f64.hip"
+#include "ftmpc_solve_wg.hip"
 #include "ftmpc_sim.hip"
 #include "ftmpc_alloc.hip"
 
@@ -32,6 +33,7 @@ using ftmpc::LinParams;
 using ftmpc::SolveParams;
 using ftmpc::Solve64Params;
 using ftmpc::TermCost;
+using ftmpc::SolveWgParams;
 
 static thread_local std::string g_create_error;
 
@@ -71,6 +73,11 @@ struct ftmpc_handle {
     static constexpr int MAX_CHUNKS = 8;
     hipEvent_t ev_in[MAX_CHUNKS] = {}, ev_k[MAX_CHUNKS] = {}, ev_out[MAX_CHUNKS] = {};
     int stage_chunks = 4;
+    // fp32 workgroup-per-instance kernel with the factor in LDS (160 < N*NT <= 240)
+    bool use_wg = false;
+    float* wg_slot = nullptr;
+    int grid_wg = 0;
+    int64_t wg_slot_words = 0;
     // float64 general-size path
     bool use_f64 = false;
     int npad_max = 0;
@@ -96,9 +103,9 @@ struct ftmpc_handle {
     float *d_dbgH = nullptr, *d_dbgv = nullptr;
     // profiling
     bool profiling = false;
-    hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // start/stop per kernel slot
+    hipEvent_t ev[12] = {};  // start/stop per kernel slot
     bool ev_valid = false;
-    bool ev_used[5] = {false, false, false, false, false};
+    bool ev_used[6] = {false, false, false, false, false, false};
 };
 
 namespace {
@@ -154,7 +161,7 @@ int build_consts(const ftmpc_config& c, DeviceConsts& d, std::string& why) {
     d.N = c.N;
     d.NT = c.NT;
     d.max_iters = c.max_iters > 0 ? c.max_iters : 30;
-    if ((c.dtype == FTMPC_DTYPE_F64 || c.N * c.NT > 160) && c.max_iters <= 0) d.max_iters = 30;
+    if ((c.dtype == FTMPC_DTYPE_F64 || c.N * c.NT > 240) && c.max_iters <= 0) d.max_iters = 30;
     d.dt = c.dt;
     d.inv_mass = 1.0 / c.mass;
     std::memcpy(d.J, c.J, sizeof(d.J));
@@ -188,7 +195,7 @@ int build_consts(const ftmpc_config& c, DeviceConsts& d, std::string& why) {
     for (int i = 0; i < 9; ++i)
         for (int j = 0; j < 9; ++j) d.LPt[9 * i + j] = s2 * L[9 * j + i];  // sqrt(2) L'
     d.rho = c.rho;
-    d.mu_stop = c.mu_stop > 0 ? c.mu_stop : ((c.dtype == FTMPC_DTYPE_F64 || c.N * c.NT > 160) ? 1e-13 : 1e-11);
+    d.mu_stop = c.mu_stop > 0 ? c.mu_stop : ((c.dtype == FTMPC_DTYPE_F64 || c.N * c.NT > 240) ? 1e-13 : 1e-11);
     if (c.terminal_set && !(c.mu_stop > 0)) d.mu_stop = 1e-10;   // general rows: C' W C ruins the conditioning below that
     d.mu_refine = 1e-3;
     return FTMPC_OK;
@@ -223,10 +230,10 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
     lp.warmG = nullptr;
     lp.out_eN = h->tset ? h->d_eN : nullptr;
     lp.tcost = h->d_tcost;
-    const int nvar = h->use_f64 ? 0 : (h->nb_max <= 8 ? 1 : (h->nb_max == 9 ? 2 : 3));   // fp32 instantiations in use
+    const int nvar = h->use_f64 ? 0 : (h->nb_max <= 8 ? 1 : (h->nb_max == 9 ? 2 : 3));   // one-wave fp32 instantiations in use
     lp.qlist = h->use_f64 ? nullptr : h->d_qlist;
     lp.qcount = h->d_qctl;
-    lp.qvmax = nvar - 1;
+    lp.qvmax = h->use_wg ? 3 : nvar - 1;   // list 3: ceil(n/16) >= 11, the workgroup kernel
     if (!h->use_f64) HIP_TRY(h, hipMemsetAsync(h->d_qctl, 0, 8 * sizeof(int32_t), s));
     const int lin_blocks = (int)((B + 63) / 64);
     for (bool& u : h->ev_used) u = false;
@@ -305,6 +312,25 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
             h->ev_used[1 + v] = true;
         }
     }
+    if (h->use_wg) {
+        SolveWgParams w;
+        w.base = sp;
+        w.base.hscratch = nullptr;
+        w.base.tile_words = 0;
+        w.base.qlist = h->d_qlist + (int64_t)3 * B;
+        w.base.qcount = h->d_qctl + 3;
+        w.base.qhead = h->d_qctl + 7;
+        w.slot = h->wg_slot;
+        w.slot_words = h->wg_slot_words;
+        const int grid = (int)std::min<int64_t>(B, h->grid_wg);
+        if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[10], s));
+        hipLaunchKernelGGL(ftmpc::ftmpc_solve_wg32_kernel<15>, dim3(grid), dim3(ftmpc::wgk::WG), 0, s, h->dc, w);
+        HIP_TRY(h, hipGetLastError());
+        if (h->profiling) {
+            HIP_TRY(h, hipEventRecord(h->ev[11], s));
+            h->ev_used[5] = true;
+        }
+    }
     if (h->profiling) h->ev_valid = true;
     return FTMPC_OK;
 }
@@ -313,7 +339,7 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
 
 extern "C" {
 
-int32_t ftmpc_version(void) { return 200; }
+int32_t ftmpc_version(void) { return 300; }
 
 int ftmpc_default_config(ftmpc_config* cfg, int32_t N, int32_t NT) {
     if (!cfg || N < 1 || N > 64 || NT < 1 || NT > FTMPC_MAX_NT) return FTMPC_ERR_ARG;
@@ -398,7 +424,10 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
     }
     // fp32 LDS-resident kernels cover n <= 160; larger problems and dtype F64 use the float64
     // workgroup-per-instance kernel
-    h->use_f64 = (cfg->dtype == FTMPC_DTYPE_F64) || h->nb_max > 10;
+    // fp32: one-wave register-resident kernels up to n = 160, the workgroup kernel with the factor in LDS up to n = 240;
+    // beyond that, and for dtype F64, the float64 workgroup kernel with its tiles in a global slot
+    h->use_f64 = (cfg->dtype == FTMPC_DTYPE_F64) || h->nb_max > 15;
+    h->use_wg = !h->use_f64 && h->nb_max > 10;
     h->tset = cfg->terminal_set != 0;
     if (h->tset) {
         const char* why = nullptr;
@@ -422,7 +451,7 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
         delete h;
         return fail(nullptr, FTMPC_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
-    for (int i = 0; i < 10; ++i) (void)hipEventCreate(&h->ev[i]);
+    for (int i = 0; i < 12; ++i) (void)hipEventCreate(&h->ev[i]);
     bool sbad = hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking) != hipSuccess ||
                 hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking) != hipSuccess;
     for (int i = 0; i < ftmpc_handle::MAX_CHUNKS; ++i)
@@ -476,7 +505,12 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
         bad = grow(h, &h->hs[0], (int64_t)h->grid[0] * slot_words(8, cfg->N)) != FTMPC_OK ||
               (h->nb_max > 8 && grow(h, &h->hs[1], (int64_t)h->grid[1] * slot_words(9, cfg->N)) != FTMPC_OK) ||
               (h->nb_max > 9 && grow(h, &h->hs[2], (int64_t)h->grid[2] * slot_words(10, cfg->N)) != FTMPC_OK) ||
-              grow(h, &h->d_dbgH, 4096 * 24 + 160 * 160) != FTMPC_OK || grow(h, &h->d_dbgv, 3 * 160 + 4) != FTMPC_OK;
+              grow(h, &h->d_dbgH, 4096 * 24 + 256 * 256) != FTMPC_OK || grow(h, &h->d_dbgv, 3 * 256 + 4) != FTMPC_OK;
+        if (!bad && h->use_wg) {
+            h->grid_wg = h->num_cu;      // ~150 KiB of LDS: one workgroup per CU
+            h->wg_slot_words = ftmpc::wgk::slot_words(15, cfg->N);
+            bad = grow(h, &h->wg_slot, (int64_t)h->grid_wg * h->wg_slot_words) != FTMPC_OK;
+        }
     }
     if (!bad && cfg->terminal_cost_terms) {
         if (cfg->tc_npoly < 0 || cfg->tc_npoly > FTMPC_MAX_TCOST_TERMS || cfg->tc_nroot < 0 || cfg->tc_nroot > FTMPC_MAX_TCOST_TERMS) {
@@ -518,12 +552,12 @@ int ftmpc_destroy(ftmpc_handle* h) {
     void* ptrs[] = {h->rec, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, h->d_uref, h->d_warm, h->d_u0, h->d_U,
                     h->d_status, h->d_iters, h->hs[0], h->hs[1], h->hs[2], h->d_dbgH, h->d_dbgv, h->Hs, h->Ls, h->Eall, h->d_dbgH64, h->d_dbgv64,
                     h->d_atau, h->d_aub, h->d_au, h->d_ast, h->d_ait, h->d_qlist, h->d_qctl, h->d_term, h->d_eN, h->gHs, h->gLs,
-                    h->gEall, h->d_tcost, h->d_cost, h->d_hullA, h->d_hullb, h->d_warmG, h->d_tau0, h->d_G, h->d_taud, h->d_hullset, h->d_ast2};
+                    h->gEall, h->wg_slot, h->d_tcost, h->d_cost, h->d_hullA, h->d_hullb, h->d_warmG, h->d_tau0, h->d_G, h->d_taud, h->d_hullset, h->d_ast2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->pin_in.p) (void)hipHostFree(h->pin_in.p);
     if (h->pin_out.p) (void)hipHostFree(h->pin_out.p);
-    for (int i = 0; i < 10; ++i)
+    for (int i = 0; i < 12; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (int i = 0; i < ftmpc_handle::MAX_CHUNKS; ++i) {
         if (h->ev_in[i]) (void)hipEventDestroy(h->ev_in[i]);
@@ -559,7 +593,7 @@ int ftmpc_reserve(ftmpc_handle* h, int64_t max_batch) {
     if ((rc = grow(h, &h->d_U, B * N * NT)) != FTMPC_OK) return rc;
     if ((rc = grow(h, &h->d_status, B)) != FTMPC_OK) return rc;
     if ((rc = grow(h, &h->d_iters, B)) != FTMPC_OK) return rc;
-    if (!h->use_f64 && (rc = grow(h, &h->d_qlist, 3 * B)) != FTMPC_OK) return rc;
+    if (!h->use_f64 && (rc = grow(h, &h->d_qlist, 4 * B)) != FTMPC_OK) return rc;
     if ((rc = grow(h, &h->d_eN, B * 9)) != FTMPC_OK) return rc;
     h->cap_batch = B;
     return FTMPC_OK;
@@ -926,10 +960,10 @@ int ftmpc_set_profiling(ftmpc_handle* h, int32_t enabled) {
     return FTMPC_OK;
 }
 
-int ftmpc_last_kernel_ms(ftmpc_handle* h, float ms[5]) {
+int ftmpc_last_kernel_ms(ftmpc_handle* h, float ms[6]) {
     if (!h || !ms) return FTMPC_ERR_ARG;
     if (!h->ev_valid) return fail(h, FTMPC_ERR_ARG, "no profiled solve recorded");
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < 6; ++k) {
         ms[k] = 0.f;
         if (!h->ev_used[k]) continue;
         HIP_TRY(h, hipEventSynchronize(h->ev[2 * k + 1]));
@@ -938,10 +972,10 @@ int ftmpc_last_kernel_ms(ftmpc_handle* h, float ms[5]) {
     return FTMPC_OK;
 }
 
-static const char* const k_kernel_names[5] = {"ftmpc_linearize_kernel", "ftmpc_solve_f32_kernel<8>", "ftmpc_solve_f32_kernel<9>",
-                                              "ftmpc_solve_f32_kernel<10>", "ftmpc_solve_f64_kernel"};
+static const char* const k_kernel_names[6] = {"ftmpc_linearize_kernel", "ftmpc_solve_f32_kernel<8>", "ftmpc_solve_f32_kernel<9>",
+                                              "ftmpc_solve_f32_kernel<10>", "ftmpc_solve_f64_kernel", "ftmpc_solve_wg32_kernel<15>"};
 
-const char* ftmpc_kernel_name(int32_t slot) { return (slot >= 0 && slot < 5) ? k_kernel_names[slot] : ""; }
+const char* ftmpc_kernel_name(int32_t slot) { return (slot >= 0 && slot < 6) ? k_kernel_names[slot] : ""; }
 
 int ftmpc_debug_build_qp(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, const double* stuck,
                          const double* xref, int64_t xref_stride, const double* uref, int64_t uref_stride,
@@ -959,7 +993,7 @@ int ftmpc_debug_build_qp(ftmpc_handle* h, int64_t B, const double* x0, const dou
     HIP_TRY(h, hipMemcpyAsync(h->d_stuck, stuck, B * NT * sizeof(double), hipMemcpyHostToDevice, s));
     if ((rc = stage_refs(h, B, xref, xref_stride, uref, uref_stride)) != FTMPC_OK) return rc;
     if (warmU) HIP_TRY(h, hipMemcpyAsync(h->d_warm, warmU, B * N * NT * sizeof(double), hipMemcpyHostToDevice, s));
-    if (!h->use_f64) HIP_TRY(h, hipMemsetAsync(h->d_dbgv, 0, (3 * 160 + 4) * sizeof(float), s));
+    if (!h->use_f64) HIP_TRY(h, hipMemsetAsync(h->d_dbgv, 0, (3 * 256 + 4) * sizeof(float), s));
     rc = enqueue(h, B, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, xref_stride, uref ? h->d_uref : nullptr, uref_stride,
                  warmU ? h->d_warm : nullptr, h->d_u0, nullptr, h->d_status, h->d_iters, s, inst);
     if (rc != FTMPC_OK) return rc;
@@ -981,11 +1015,13 @@ int ftmpc_debug_build_qp(ftmpc_handle* h, int64_t B, const double* x0, const dou
         *n_out = n;
         return FTMPC_OK;
     }
-    std::vector<float> Hf(160 * 160), vf(3 * 160 + 4);
+    std::vector<float> Hf(256 * 256), vf(3 * 256 + 4);
     HIP_TRY(h, hipMemcpyAsync(Hf.data(), h->d_dbgH, Hf.size() * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipMemcpyAsync(vf.data(), h->d_dbgv, vf.size() * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
-    const int n = (int)vf[480], npad = (int)vf[481];
+    // the one-wave kernels leave (n, npad) at words 480 / 481, the workgroup kernel at 720 / 721
+    const int mk = (vf[720] > 0.f) ? 720 : 480;
+    const int n = (int)vf[mk], npad = (int)vf[mk + 1];
     if (n == 0) return fail(h, FTMPC_ERR_ARG, "instance has no active thruster or was not dumped");
     if ((int64_t)n * n > H_cap) return fail(h, FTMPC_ERR_ARG, "H buffer too small");
     for (int i = 0; i < n; ++i) {

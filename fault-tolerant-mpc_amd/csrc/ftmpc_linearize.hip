@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(64) ftmpc_linearize_kernel(const DeviceConsts 
         int na = 0;
         for (int i = 0; i < NT; ++i) na += (ubv[i] > 0.0) ? 1 : 0;
         const int nbk = (N * na + 15) >> 4;
-        int v = (na == 0 || nbk <= 8) ? 0 : nbk - 8;
+        int v = (na == 0 || nbk <= 8) ? 0 : nbk - 8;      // 0..2: one-wave kernels NB = 8 / 9 / 10; 3: workgroup kernel
         v = v > P.qvmax ? P.qvmax : v;
         const bool real = b0 + lane < P.B;
         for (int vv = 0; vv <= P.qvmax; ++vv) {

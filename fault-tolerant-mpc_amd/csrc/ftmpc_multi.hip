@@ -317,7 +317,7 @@ int ftmpc_multi_set_profiling(ftmpc_multi* m, int32_t enabled) {
     return FTMPC_OK;
 }
 
-int ftmpc_multi_last_kernel_ms(ftmpc_multi* m, int32_t slot, float ms[5]) {
+int ftmpc_multi_last_kernel_ms(ftmpc_multi* m, int32_t slot, float ms[6]) {
     if (!m || !ms || slot < 0 || slot >= (int32_t)m->dev.size()) return FTMPC_ERR_ARG;
     return multi_run(m, [=](ftmpc_multi::Dev& d) -> int {
         if ((int)(&d - m->dev.data()) != slot) return FTMPC_OK;

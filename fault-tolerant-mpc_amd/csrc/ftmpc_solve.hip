@@ -566,7 +566,8 @@ typedef __attribute__((address_space(3))) double lds_f64;
 typedef __attribute__((address_space(3))) const float lds_cf32;
 typedef __attribute__((address_space(1))) double glb_f64;
 typedef __attribute__((address_space(1))) const double glb_cf64;
-template <class SPtr>   // stage storage: lds_f64* when it fits behind the vectors, else glb_f64* (long horizons)
+// GOFF: offset (doubles) of the wrench scratch behind the gradient in the global slot (>= n)
+template <class SPtr, int GOFF = 160>   // stage storage: lds_f64* when it fits behind the vectors, else glb_f64* (long horizons)
 __device__ __noinline__ void struct_grad(const DeviceConsts& C, glb_cf64* recg, lds_f64* recd, lds_cf32* s_Da,
                                             lds_cf32* dnat, SPtr sS, glb_f64* gout, int na, int lane) {
     constexpr int ZERO = REC_STRIDE;
@@ -604,7 +605,7 @@ __device__ __noinline__ void struct_grad(const DeviceConsts& C, glb_cf64* recg, 
     const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
     // wrench perturbations gen_k = Da d_k of ALL stages up front, one (stage, component) pair per lane,
     // parked behind the gradient in the global scratch (N x 8 doubles) and prefetched with the records
-    glb_f64* genS = gout + slot_gens_off();
+    glb_f64* genS = gout + GOFF;
     for (int t = lane; t < N * 8; t += 64) {
         const int k = t >> 3, g = t & 7;
         double acc = 0.0;

@@ -35,7 +35,7 @@ class MPCConfig:
     max_iters: int = 0            # <= 0: library default (30)
     mu_stop: float = 0.0          # <= 0: library default (1e-11 for f32, 1e-13 for f64)
     device_id: int = 0
-    dtype: str = "f32"            # arithmetic of the KKT/IPM solve: "f32" | "f64" (N*NT > 160 always runs f64)
+    dtype: str = "f32"            # arithmetic of the KKT/IPM solve: "f32" | "f64" (N*NT > 240 always runs f64)
     # terminal set  term_A (c_N[0:9] - xref_N) <= term_b  (config/terminal.yaml term_set; spiraling_mpc.py:199-202):
     # a TerminalSet / (A, b) pair, or True for the shipped config/terminal.yaml.  Needs dtype "f64".
     terminal_set: object = None
@@ -390,9 +390,9 @@ class BatchedMPC:
 
     def last_kernel_ms(self):
         """{kernel name: device ms} of the last profiled solve (kernels that were launched)."""
-        ms = (C.c_float * 5)()
+        ms = (C.c_float * 6)()
         self._check(self.lib.ftmpc_last_kernel_ms(self._h, ms))
-        return {self.kernel_name(k): float(ms[k]) for k in range(5) if ms[k] > 0}
+        return {self.kernel_name(k): float(ms[k]) for k in range(6) if ms[k] > 0}
 
     # -- test hook ----------------------------------------------------------------------
     def debug_build_qp(self, x0, ub, stuck, xref, inst, uref=None, warmU=None):

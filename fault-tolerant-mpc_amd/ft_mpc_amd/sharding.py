@@ -148,9 +148,9 @@ class MultiGPUMPC:
 
     def last_kernel_ms(self, slot=0):
         C = self._C
-        ms = (C.c_float * 5)()
+        ms = (C.c_float * 6)()
         self._check(self.lib.ftmpc_multi_last_kernel_ms(self._h, int(slot), ms))
-        return {self.lib.ftmpc_kernel_name(k).decode(): float(ms[k]) for k in range(5) if ms[k] > 0}
+        return {self.lib.ftmpc_kernel_name(k).decode(): float(ms[k]) for k in range(6) if ms[k] > 0}
 
 
 def solve_multi_gpu(cfg, x0, ub, stuck, xref, devices=None, **kw):

@@ -255,10 +255,11 @@ int ftmpc_simulate_batch(ftmpc_handle* h, int64_t B, int32_t T, double* x, const
 /* Per-kernel device timing of the LAST solve call, measured with hipEvents on the launch
  * stream when enabled.  ms[slot] is the duration of kernel slot `slot` (0 when that kernel was
  * not launched); ftmpc_kernel_name(slot) is the kernel's name as it appears in rocprofv3
- * traces:  0 linearise, 1..3 condense+IPM fp32 for n <= 128 / 144 / 160, 4 condense+IPM fp64
- * (general n). */
+ * traces:  0 linearise, 1..3 condense+IPM fp32 (one wave per instance) for n <= 128 / 144 / 160,
+ * 4 condense+IPM fp64 (workgroup per instance, general n), 5 condense+IPM fp32 with the factor in LDS (workgroup per
+ * instance, 160 < n <= 240). */
 int ftmpc_set_profiling(ftmpc_handle* h, int32_t enabled);
-int ftmpc_last_kernel_ms(ftmpc_handle* h, float ms[5]);
+int ftmpc_last_kernel_ms(ftmpc_handle* h, float ms[6]);
 const char* ftmpc_kernel_name(int32_t slot);
 
 /*
@@ -311,7 +312,7 @@ int ftmpc_multi_step(ftmpc_multi* m, int32_t steps, int32_t keep_U);
 int ftmpc_multi_download(ftmpc_multi* m, double* out_u0, double* out_U, int32_t* status, int32_t* iters);
 /* per-kernel device timing of device slot `slot` (see ftmpc_set_profiling / ftmpc_last_kernel_ms) */
 int ftmpc_multi_set_profiling(ftmpc_multi* m, int32_t enabled);
-int ftmpc_multi_last_kernel_ms(ftmpc_multi* m, int32_t slot, float ms[5]);
+int ftmpc_multi_last_kernel_ms(ftmpc_multi* m, int32_t slot, float ms[6]);
 
 /* Library/ABI version: major*10000 + minor*100 + patch. */
 int32_t ftmpc_version(void);

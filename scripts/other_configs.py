@@ -21,5 +21,7 @@ run("cfg2-shape at 65536",65536,20,8,1,"f32",1002)
 run("nominal 8 thrusters",65536,20,8,0,"f32",1001)
 run("cfg3 double fault (headline)",65536,20,8,2,"f32",1003)
 run("cfg4 shard (32768/GPU)",32768,20,8,2,"f32",1004)
+run("reference vehicle N=15 NT=16 2f (fp32 workgroup kernel)",4096,15,16,2,"f32",1011)
+run("reference vehicle, nominal (n=240)",4096,15,16,0,"f32",1012)
 run("reference vehicle N=15 NT=16 2f",4096,15,16,2,"f64",1011)
 run("cfg5 shard (2048/GPU) N=40 NT=16",2048,40,16,2,"f64",1005)

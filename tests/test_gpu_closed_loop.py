@@ -86,7 +86,7 @@ def test_on_device_closed_loop_matches_oracle_loop_f64(gpu_mpc_factory):
     oracle/closed_loop.py: 16-thruster vehicle, shipped double fault, float64 kernel."""
     from oracle import closed_loop as cl
     N, NT, B, T = 15, 16, 5, 12
-    mpc = gpu_mpc_factory(N=N, NT=NT, max_iters=40)
+    mpc = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40)
     x0, _, _, _ = qo.make_batch(B, N, NT, 0, 99)
     ub = np.full((B, NT), 3.4); stuck = np.zeros((B, NT))
     ub[:, [10, 11]] = 0.0; stuck[:, [10, 11]] = 3.4
@@ -118,7 +118,7 @@ def test_relinearisation_converges_and_matches_oracle(gpu_mpc_factory):
     """Sequential QP (re-linearise about the previous solution): the GPU loop equals the oracle loop and
     the iterates contract (first step: nonlinear dynamics, quadratic terminal cost)."""
     N, NT, B = 15, 16, 4
-    mpc = gpu_mpc_factory(N=N, NT=NT, max_iters=40)
+    mpc = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40)
     x0, _, _, xref = qo.make_batch(B, N, NT, 0, 321)
     ub = np.full((B, NT), 3.4); stuck = np.zeros((B, NT))
     ub[:, 3] = 0.0; stuck[:, 3] = 1.0

@@ -103,6 +103,71 @@ def test_sixteen_thrusters_short_horizon_on_the_fp32_kernels(gpu_mpc_factory, nf
 
 
 # ---------------------------------------------------------------------------------------------
+# fp32 workgroup kernel with the factor in LDS (160 < n <= 240: the reference vehicle at its shipped horizon)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nfault", [0, 1, 2])
+def test_wg_kernel_build_matches_oracle(gpu_mpc_factory, nfault):
+    N, NT = 15, 16
+    mpc = gpu_mpc_factory(N=N, NT=NT)
+    x0, ub, stuck, xref = qo.make_batch(6, N, NT, nfault, 2100 + nfault)
+    cfg = _cfg(N, NT)
+    for inst in (0, 5):
+        H, g, lo, hi = mpc.debug_build_qp(x0, ub, stuck, xref.reshape(-1, order="F"), inst)
+        qp = qo.build_qp(cfg, x0[inst], ub[inst], stuck[inst], xref)
+        assert H.shape == qp["H"].shape and H.shape[0] == N * (NT - nfault)
+        assert np.abs(H - qp["H"]).max() <= 2e-5 * np.abs(qp["H"]).max()
+        assert np.abs(g - qp["g"]).max() <= 2e-5 * max(1.0, np.abs(qp["g"]).max())
+        assert np.allclose(lo, -qp["Ubar"], atol=1e-6) and np.allclose(hi, qp["ub"] - qp["Ubar"], atol=1e-6)
+
+
+@pytest.mark.parametrize("N,nfault,B", [(15, 2, 64), (15, 0, 32), (15, 1, 32), (12, 0, 32), (13, 2, 32)])
+def test_wg_kernel_u0_against_the_c_oracle(gpu_mpc_factory, N, nfault, B):
+    """n = 210 (reactive.yaml's horizon, two faults), 240 (nominal), 225, 192 and 182: block counts 12..15."""
+    NT = 16
+    mpc = gpu_mpc_factory(N=N, NT=NT)
+    x0, ub, stuck, xref = qo.make_batch(B, N, NT, nfault, 3400 + N + nfault)
+    out = mpc.solve(x0, ub, stuck, xref.reshape(-1, order="F"), return_U=True)
+    assert (out["status"] == 0).all(), out["status"]
+    ref = co.solve_batch(_cfg(N, NT), x0, ub, stuck, xref, nthreads=8, max_iters=60, mu_stop=1e-13)
+    assert (ref["status"] == 0).all()
+    assert np.abs(out["u0"] - ref["u0"]).max() / F_MAX <= 1e-4
+    assert np.abs(out["U"] - ref["U"]).max() / F_MAX <= 2e-3
+    assert (out["u0"][ub == 0] == 0).all() and out["iters"].max() <= 30
+
+
+def test_wg_kernel_whole_batch_mixed_fault_counts_warm_start_and_uref(gpu_mpc_factory):
+    """4096 instances (16 per workgroup), fault counts 0..10 mixed in one batch (routed between the one-wave kernels
+    NB = 8 / 9 / 10 and the workgroup kernel), then a warm-started step with a circle reference window."""
+    import os
+    N, NT, B = 15, 16, 4096
+    mpc = gpu_mpc_factory(N=N, NT=NT)
+    x0, ub, stuck, xref = qo.make_batch(B, N, NT, 2, 3500)
+    rng = np.random.default_rng(9)
+    for b in range(0, B, 5):                      # every fifth instance: a random number of extra broken thrusters
+        k = int(rng.integers(0, 9))
+        idx = rng.choice(np.flatnonzero(ub[b] > 0), k, replace=False)
+        ub[b, idx] = 0.0
+        stuck[b, idx] = rng.uniform(0, 1, k) * F_MAX
+    out = mpc.solve(x0, ub, stuck, xref.reshape(-1, order="F"), return_U=True)
+    nt = min(32, len(os.sched_getaffinity(0)))
+    ref = co.solve_batch(_cfg(N, NT), x0, ub, stuck, xref, nthreads=nt, max_iters=60, mu_stop=1e-13)
+    ok = ref["status"] == 0
+    assert ok.mean() > 0.99 and (out["status"][ok] == 0).all()
+    assert np.abs(out["u0"][ok] - ref["u0"][ok]).max() / F_MAX <= 1e-4
+    traj = rm.circle_trajectory(0.1, 10, radius=0.65, s_per_circle=40.0)
+    xr_all, ur_all = rm.assign_trajectory(traj, N)
+    xw, uw = rm.trajectory_window(xr_all, ur_all, 1.0, N)
+    W = np.ascontiguousarray(np.concatenate([out["U"][:, 1:], np.zeros((B, 1, NT))], axis=1))
+    W0 = W.copy()
+    out2 = mpc.solve(x0, ub, stuck, xw.reshape(-1, order="F"), uref=uw.reshape(-1, order="F"), warmU=W)
+    ref2 = co.solve_batch(_cfg(N, NT), x0, ub, stuck, xw, uref=uw, warmU=W0, nthreads=nt, max_iters=60, mu_stop=1e-13)
+    ok2 = ref2["status"] == 0
+    assert (out2["status"][ok2] == 0).all()
+    assert np.abs(out2["u0"][ok2] - ref2["u0"][ok2]).max() / F_MAX <= 1e-4
+    assert np.abs(W[ok2] - ref2["U"][ok2]).max() / F_MAX <= 2e-3
+
+
+# ---------------------------------------------------------------------------------------------
 # float64 general-size kernel (reference 16-thruster vehicle, long horizons)
 # ---------------------------------------------------------------------------------------------
 def _faults16(B, pattern):
@@ -119,7 +184,7 @@ def test_f64_kernel_reference_vehicle(gpu_mpc_factory, N, pattern):
     """NT=16 (the reference's D, sys_model.py:73-123); N=15 with thrusters 10,11 stuck fully on is the
     shipped reactive.yaml scenario.  float64 path: u0 and U within 1e-7 f_max of the exact solution."""
     B = 6
-    mpc = gpu_mpc_factory(N=N, NT=16, max_iters=40)
+    mpc = gpu_mpc_factory(N=N, NT=16, dtype="f64", max_iters=40)
     x0, _, _, xref = qo.make_batch(B, N, 16, 0, 3000 + N)
     ub, stuck = _faults16(B, pattern)
     cfg = _cfg(N, 16)

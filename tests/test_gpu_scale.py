@@ -44,7 +44,7 @@ def _check_f64(mpc, cfg, x0, ub, stuck, xref):
 def test_f64_persistent_loop_reference_vehicle(gpu_mpc_factory):
     """<4,1> (n <= 256): N=15, 16 thrusters, two random faults (n = 210), B = 4096 = 8..16 instances per workgroup."""
     N, NT, B = 15, 16, 4096
-    mpc = gpu_mpc_factory(N=N, NT=NT, max_iters=40)
+    mpc = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40)
     x0, ub, stuck, xref = qo.make_batch(B, N, NT, 2, 5101)
     out = _check_f64(mpc, qo.QPConfig(N=N, NT=NT), x0, ub, stuck, xref)
     assert out["iters"].max() <= 40
@@ -82,10 +82,11 @@ def _windows(B, N, seed):
     return xr, ur
 
 
-@pytest.mark.parametrize("N,NT,dtype,tol", [(20, 8, "f32", 1e-4), (15, 16, "f32", 1e-7)])
+@pytest.mark.parametrize("N,NT,dtype,tol", [(20, 8, "f32", 1e-4), (15, 16, "f64", 1e-7), (15, 16, "f32", 1e-4)])
 def test_per_instance_reference_strides_host_and_device_entry(gpu_mpc_factory, N, NT, dtype, tol):
     """xref_stride = 9(N+1) (+ padding), uref_stride = 6(N+1) (+ padding) on ftmpc_solve_batch and on
-    ftmpc_solve_batch_device, fp32 kernels (N=20, NT=8) and the float64 kernel (N=15, NT=16: n > 160)."""
+    ftmpc_solve_batch_device: one-wave fp32 kernels (N=20, NT=8), the float64 kernel and the fp32 workgroup kernel
+    (N=15, NT=16)."""
     import torch
     B = 192
     mpc = gpu_mpc_factory(N=N, NT=NT, dtype=dtype, max_iters=40)

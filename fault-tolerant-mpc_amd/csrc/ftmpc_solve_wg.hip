@@ -18,6 +18,8 @@
 // controllers/tools/control_allocator.py:65-94 (see DESIGN.md QP-spec); oracle/qp_oracle.py:ipm_box is the mirror.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "ftmpc_common.h"
 
 namespace ftmpc {
@@ -34,6 +36,137 @@ __host__ __device__ constexpr int64_t slot_e_off(int npad, int N) { return ((slo
 __host__ __device__ constexpr int64_t slot_h_off(int npad, int N) { return slot_e_off(npad, N) + (int64_t)N * 9 * npad; }
 __host__ __device__ constexpr int64_t slot_words(int nbmax, int N) { return slot_h_off(16 * nbmax, N) + (int64_t)ntiles(nbmax) * 256; }
 }  // namespace wgk
+
+namespace {
+// X'Y into two accumulators (two independent MFMA chains: a dependent fp32 16x16x4 MFMA costs 40 cycles, an independent one 32)
+__device__ __forceinline__ void mm_tn2(const f32x4& X, const f32x4& Y, f32x4& a, f32x4& b) {
+    a = mfma4(X.x, Y.x, a);
+    b = mfma4(X.y, Y.y, b);
+    a = mfma4(X.z, Y.z, a);
+    b = mfma4(X.w, Y.w, b);
+}
+// Schur sums of the tiles (wave + 4 t, J1), t in [T0, T1), over the block columns K < Kend:
+//     acc[t] += sum_K T(J1, K)' T(wave + 4 t, K)
+// All operands are LDS tiles in register order (one b128 per lane); the tiles of the next K are requested before the
+// MFMAs of the current one are issued, and the T1 - T0 tiles are independent chains.
+template <int T0, int T1>
+__device__ __forceinline__ void schur_cols(const float* Tl, int lane, int wave, int J1, int Kend, f32x4 (&acc)[4]) {
+    if (Kend <= 0) return;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const float* pj = Tl + tidx(J1, 0) * 256 + 4 * lane;
+    const float* pi[4];
+    f32x4 a2[4], ti[4], tin[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        pi[t] = Tl + tidx(wave + 4 * t, 0) * 256 + 4 * lane;
+        a2[t] = z;
+        ti[t] = z;
+        tin[t] = z;
+    }
+    (void)tin;
+    for (int K = 0; K < Kend; ++K) {   // (a hand-pipelined version with pinned order measured slower: scripts/ubench_lds_mfma.hip)
+        const f32x4 tj = lds4(pj + K * 256);
+#pragma unroll
+        for (int t = T0; t < T1; ++t) ti[t] = lds4(pi[t] + K * 256);
+#pragma unroll
+        for (int t = T0; t < T1; ++t) mm_tn2(tj, ti[t], acc[t], a2[t]);
+    }
+#pragma unroll
+    for (int t = T0; t < T1; ++t) acc[t] += a2[t];
+}
+// The tiles (wave + 4 t, J), t in [T0, T1), of block column J: last Schur term (K = J - 1), panel solve
+// L_IJ' = W_J (H_IJ' - sum), store.  Straight-line code over the tiles: their MFMA chains interleave.
+// Returns the first tile (the one the owner of the next diagonal block needs at once).
+template <int T0, int T1>
+__device__ __forceinline__ f32x4 panel_tiles(float* Tl, int lane, int wave, int J, const f32x4& wtn, const f32x4& tjl, f32x4 (&bacc)[4]) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ti[4], tij[4];
+    if (J > 0) {
+#pragma unroll
+        for (int t = T0; t < T1; ++t) ti[t] = lds4(Tl + tidx(wave + 4 * t, J - 1) * 256 + 4 * lane);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int t = T0; t < T1; ++t) bacc[t] = mfma4(tjl[s4], ti[t][s4], bacc[t]);
+    }
+#pragma unroll
+    for (int t = T0; t < T1; ++t) tij[t] = z;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int t = T0; t < T1; ++t) tij[t] = mfma4(wtn[s4], bacc[t][s4], tij[t]);
+#pragma unroll
+    for (int t = T0; t < T1; ++t) *reinterpret_cast<f32x4*>(Tl + tidx(wave + 4 * t, J) * 256 + 4 * lane) = tij[t];
+    return tij[T0];
+}
+// sum_K T(D, K)' T(D, K) for K < Kend (the diagonal tile D)
+__device__ __forceinline__ f32x4 schur_diag(const float* Tl, int lane, int D, int Kend) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    if (Kend <= 0) return a;
+    const float* pd = Tl + tidx(D, 0) * 256 + 4 * lane;
+    for (int K = 0; K < Kend; ++K) {
+        const f32x4 tk = lds4(pd + K * 256);
+        mm_tn2(tk, tk, a, b);
+    }
+    return a + b;
+}
+// KKT solve on ONE wave, vectors in registers, tiles streamed from LDS (the serial chain per block is
+// reduce -> W mat-vec -> reduce, as in solve_reg of ftmpc_solve.hip; the tiles of a block column / row do not depend on
+// the chain and are requested at the top of the step).  xv: right-hand side in, solution out (natural order).
+template <int NB>
+__device__ __forceinline__ void solve_lds(const float* Tl, const float* Wdl, float* xv, int nb, int lane) {
+    const int li = lane & 15, lq = lane >> 4;
+    f32x4 Y[NB];
+    f32x2 p[NB];
+#pragma unroll
+    for (int J = 0; J < NB; ++J) p[J] = f32x2{0.f, 0.f};
+    // forward (right-looking): y_J = W_J (b_J - p_J),  p_I += L_IJ y_J for I > J
+#pragma unroll
+    for (int J = 0; J < NB; ++J) {
+        if (J < nb) {
+            f32x4 tc[NB];
+#pragma unroll
+            for (int I = J + 1; I < NB; ++I)
+                if (I < nb) tc[I] = lds4(Tl + tidx(I, J) * 256 + 4 * lane);
+            const f32x4 w = lds4(Wdl + J * 256 + 4 * lane);
+            float r = xv[16 * J + li];
+            if (J > 0) r -= quad_sum(p[J].x + p[J].y);
+            float y0 = w.x * r, y1 = w.y * r, y2 = w.z * r, y3 = w.w * r;
+            row_sum16x4(y0, y1, y2, y3);
+            Y[J] = f32x4{y0, y1, y2, y3};
+#pragma unroll
+            for (int I = J + 1; I < NB; ++I)
+                if (I < nb) {
+                    p[I] += f32x2{tc[I].x, tc[I].y} * f32x2{y0, y1};
+                    p[I] += f32x2{tc[I].z, tc[I].w} * f32x2{y2, y3};
+                }
+        }
+    }
+    // backward: x_J = W_J' (y_J - a_J),  a_K += L_JK' x_J for K < J
+    f32x4 a[NB];
+#pragma unroll
+    for (int J = 0; J < NB; ++J) a[J] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int J = NB - 1; J >= 0; --J) {
+        if (J < nb) {
+            f32x4 tr[NB];
+#pragma unroll
+            for (int K = 0; K < J; ++K) tr[K] = lds4(Tl + tidx(J, K) * 256 + 4 * lane);
+            const f32x4 w = lds4(Wdl + J * 256 + 4 * lane);
+            f32x4 r = Y[J];
+            if (J + 1 < nb) {
+                float s0 = a[J].x, s1 = a[J].y, s2 = a[J].z, s3 = a[J].w;
+                row_sum16x4(s0, s1, s2, s3);
+                r -= f32x4{s0, s1, s2, s3};
+            }
+            const float xr = quad_sum(w.x * r.x + w.y * r.y + w.z * r.z + w.w * r.w);
+            if (lq == 0) xv[16 * J + li] = xr;
+#pragma unroll
+            for (int K = 0; K < J; ++K) a[K] += tr[K] * xr;
+        }
+    }
+}
+}  // namespace
 
 struct SolveWgParams {
     SolveParams base;    // hscratch / tile_words unused
@@ -61,9 +194,11 @@ __global__ void __launch_bounds__(wgk::WG, 1) ftmpc_solve_wg32_kernel(const Devi
     __shared__ int s_act[MAX_NT];
     __shared__ int s_flag, s_q;
     float* const Wdl = Tl + NT_ALL * 256;
+    __shared__ float s_D[6 * MAX_NT];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    // wave-uniform values are forced into SGPRs: branches on them become scalar branches instead of EXEC masking
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lq = lane >> 4;
     const int N = C.N, NT = C.NT;
     const float rho = (float)C.rho;
@@ -86,14 +221,22 @@ __global__ void __launch_bounds__(wgk::WG, 1) ftmpc_solve_wg32_kernel(const Devi
         return decltype(op)::f(decltype(op)::f(red[0], red[1]), decltype(op)::f(red[2], red[3]));
     };
 
+    // the allocation matrix goes to LDS through CONSTANT indices: one dynamically indexed access to the by-value
+    // argument block would move the whole block (2.5 KiB per lane) to scratch and turn every later C.x into a scratch load
+#pragma unroll
+    for (int i = 0; i < 6 * MAX_NT; ++i)
+        if (tid == i) s_D[i] = (float)C.D[i];
+    const float dtf = (float)C.dt;
     const int qn = *P.qcount;
     for (;;) {
         __syncthreads();
         if (tid == 0) s_q = atomicAdd(P.qhead, 1);
         __syncthreads();
-        const int qi = s_q;
+        const int qi = __builtin_amdgcn_readfirstlane(s_q);
         if (qi >= qn) break;
-        const int64_t inst = P.qlist[qi];
+        const int64_t inst = __builtin_amdgcn_readfirstlane(P.qlist[qi]);
+        STAMP_DECL;
+        STAMP_START();
         // ---------------- prologue ----------------
         if (tid == 0) {
             int na0 = 0;
@@ -102,7 +245,7 @@ __global__ void __launch_bounds__(wgk::WG, 1) ftmpc_solve_wg32_kernel(const Devi
             s_flag = na0;
         }
         __syncthreads();
-        const int na = s_flag;
+        const int na = __builtin_amdgcn_readfirstlane(s_flag);
         const int n = N * na;
         const int nb = (n + 15) >> 4;
         const int npad = nb * 16;
@@ -118,7 +261,7 @@ __global__ void __launch_bounds__(wgk::WG, 1) ftmpc_solve_wg32_kernel(const Devi
         }
         if (tid < 6 * MAX_NT) {
             const int g = tid / MAX_NT, a = tid % MAX_NT;
-            s_Da[tid] = (a < na) ? (float)C.D[g * MAX_NT + s_act[a]] : 0.f;
+            s_Da[tid] = (a < na) ? s_D[g * MAX_NT + s_act[a]] : 0.f;
         }
         if (tid < npad) {
             const int s = tid / na;
@@ -148,7 +291,13 @@ __global__ void __launch_bounds__(wgk::WG, 1) ftmpc_solve_wg32_kernel(const Devi
                 Td[a] = s_Da[(3 + a) * MAX_NT + acol];
             }
         }
-        // ---------------- build, phase 1: condense (one column per thread), E panels of every stage -> slot ----------------
+        STAMP(0);
+        // ---------------- build: the E panels of every stage go to LDS when they fit (the factor area is idle during the
+        // build: N x 9 x npad floats), else to the global slot; two instantiations so that each keeps its address space ----------------
+        const int ntl = ntiles(nb);
+        auto build = [&](auto IN_LDS) {
+        float* const Eb = decltype(IN_LDS)::value ? Tl : Eall;
+        // ---------------- phase 1: condense (one column per thread) ----------------
         float G[13];
 #pragma unroll
         for (int r = 0; r < 13; ++r) G[r] = 0.f;
@@ -163,7 +312,7 @@ __global__ void __launch_bounds__(wgk::WG, 1) ftmpc_solve_wg32_kernel(const Devi
                     float p[3], vv[3], w[3], q[4];
 #pragma unroll
                     for (int a = 0; a < 3; ++a) {
-                        p[a] = G[a] + (float)C.dt * G[3 + a];
+                        p[a] = G[a] + dtf * G[3 + a];
                         vv[a] = G[3 + a];
                         w[a] = 0.f;
 #pragma unroll
@@ -224,7 +373,7 @@ __global__ void __launch_bounds__(wgk::WG, 1) ftmpc_solve_wg32_kernel(const Devi
 #pragma unroll
                 for (int r = 0; r < 9; ++r) gs += G[r] * rb[REC_WE + r];
                 gacc += gs;
-                float* Ek = Eall + (int64_t)k * 9 * npad;
+                float* Ek = Eb + (int64_t)k * 9 * npad;
                 if (!terminal) {
 #pragma unroll
                     for (int r = 0; r < 9; ++r) Ek[r * npad + tid] = (float)C.sq2Q[r] * G[r];
@@ -240,8 +389,8 @@ __global__ void __launch_bounds__(wgk::WG, 1) ftmpc_solve_wg32_kernel(const Devi
             }
         }
         __syncthreads();   // E panels visible to the whole workgroup
+        STAMP(1);
         // ---------------- build, phase 2: Hessian tiles on the matrix cores, -H' in register order -> slot ----------------
-        const int ntl = ntiles(nb);
         for (int t = wave; t < ntl; t += NWAVE) {
             int I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
             while (tidx(I + 1, 0) <= t) ++I;
@@ -250,7 +399,7 @@ __global__ void __launch_bounds__(wgk::WG, 1) ftmpc_solve_wg32_kernel(const Devi
             f32x4 acc = zero4;
             const int kstart = (16 * I) / na < N ? (16 * I) / na : N;
             for (int k = kstart; k < N; ++k) {
-                const float* Ek = Eall + (int64_t)k * 9 * npad;
+                const float* Ek = Eb + (int64_t)k * 9 * npad;
 #pragma unroll
                 for (int s3 = 0; s3 < 3; ++s3) {
                     const int r = 4 * s3 + lq;
@@ -271,6 +420,10 @@ __global__ void __launch_bounds__(wgk::WG, 1) ftmpc_solve_wg32_kernel(const Devi
             *reinterpret_cast<f32x4*>(Hs + (int64_t)t * 256 + 4 * lane) = -acc;
         }
         __syncthreads();
+        STAMP(2);
+        };
+        if ((int64_t)N * 9 * npad <= (int64_t)(NT_ALL + NBMAX) * 256) build(std::true_type{});
+        else build(std::false_type{});
         float gv = valid ? 2.f * (gacc + rho * ubar) : 0.f;
         const float lo = -ubar, hi = ubv - ubar;
         float sl = 0.5f * ubv, su = 0.5f * ubv, zl = 0.f, zu = 0.f, grad = 0.f;
@@ -303,140 +456,110 @@ __global__ void __launch_bounds__(wgk::WG, 1) ftmpc_solve_wg32_kernel(const Devi
         }
 
         // ---------------- KKT factorisation (see the header) ----------------
-        // rows of wave w in block column Jc (below the diagonal): I = first(Jc) + 4 t
-        auto first_row = [&](int Jc) { return Jc + 1 + ((wave - (Jc + 1)) & 3); };
+        // rows of wave w: I = w + 4 t (t = 0..3); its tiles in block column Jc are those with Jc < I < nb
         auto factor = [&]() {
             if (tid == 0) s_flag = 1;
             f32x4 bacc[4], dacc = zero4;
-            // prologue: diagonal tile 0 (wave 0), H of diagonal tile 1 (wave 1), column 0 of every wave
-            if (wave == 0) {
-                const f32x4 h = ldh(tidx(0, 0));
-                const float sg = sigv[li];
+            auto potrf_publish = [&](int D, const f32x4& dsum) {
+                // diagonal tile D: H + Sigma - sum, Cholesky + inverse in registers, W and W' to LDS
+                const float sg = sigv[16 * D + li];
                 f32x4 cd;
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) cd[rr] = ((4 * lq + rr == li) ? sg : 0.f) - h[rr];
+                for (int rr = 0; rr < 4; ++rr) cd[rr] = ((4 * lq + rr == li) ? sg : 0.f) - dsum[rr];
                 const f32x4 w = potrf_inv16_call(cd, lane, NoWork{});
                 if (!(fabsf(w.w) <= 3.0e38f) && lane == 63) s_flag = 0;
-                *reinterpret_cast<f32x4*>(Wdl + 4 * lane) = w;
+                *reinterpret_cast<f32x4*>(Wdl + D * 256 + 4 * lane) = w;
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) S17[(4 * lq + rr) * 17 + li] = w[rr];
                 wave_lds_fence();
                 f32x4 wt;
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) wt[rr] = S17[li * 17 + 4 * lq + rr];
-                stt(tidx(0, 0), wt);
-            }
+                stt(tidx(D, D), wt);
+            };
+            // prologue: diagonal tile 0 (wave 0), H of diagonal tile 1 (wave 1), column 0 of every wave
+            if (wave == 0) potrf_publish(0, ldh(tidx(0, 0)));
             if (wave == 1 && nb > 1) dacc = ldh(tidx(1, 1));
-            {
-                const int I0 = first_row(0);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) bacc[t] = (I0 + 4 * t < nb) ? ldh(tidx(I0 + 4 * t, 0)) : zero4;
+            for (int t = 0; t < 4; ++t) {
+                const int I = wave + 4 * t;
+                bacc[t] = (I > 0 && I < nb) ? ldh(tidx(I, 0)) : zero4;
             }
             __syncthreads();   // W_0 published
+            const int t1 = (nb - wave + 3) >> 2;           // slots t < t1 have I < nb
             for (int J = 0; J < nb; ++J) {
                 // ---- phase J: W_J and every tile of the columns < J are visible ----
-                const int I0 = first_row(J);
-                const int In0 = first_row(J + 1);
                 // Hessian tiles of the next column (and of the diagonal two ahead): requested now, used at the end
                 f32x4 hn[4], hd = zero4;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) hn[t] = (J + 1 < nb && In0 + 4 * t < nb) ? ldh(tidx(In0 + 4 * t, J + 1)) : zero4;
+                for (int t = 0; t < 4; ++t) {
+                    const int I = wave + 4 * t;
+                    hn[t] = (I > J + 1 && I < nb) ? ldh(tidx(I, J + 1)) : zero4;
+                }
                 const bool two_ahead = (wave == ((J + 2) & 3)) && (J + 2 < nb);
                 if (two_ahead) hd = ldh(tidx(J + 2, J + 2));
                 f32x4 wtn = ldt(tidx(J, J));
                 wtn = -wtn;
                 const f32x4 tjl = (J > 0) ? ldt(tidx(J, J - 1)) : zero4;       // T(J, J-1): the last Schur term of column J
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int I = I0 + 4 * t;
-                    if (I < nb) {
-                        if (J > 0) bacc[t] = mm_tn(tjl, ldt(tidx(I, J - 1)), bacc[t]);
-                        const f32x4 tij = mm_tn(wtn, bacc[t], zero4);            // L_IJ' = W_J (H_IJ' - sum)
-                        stt(tidx(I, J), tij);
-                        if (t == 0 && I == J + 1) {
-                            // this wave owns the next diagonal tile: finish it and factorise it right away
-                            if (J > 0) {
-                                const f32x4 tl = ldt(tidx(J + 1, J - 1));
-                                dacc = mm_tn(tl, tl, dacc);
-                            }
-                            dacc = mm_tn(tij, tij, dacc);
-                            const float sg = sigv[16 * (J + 1) + li];
-                            f32x4 cd;
-#pragma unroll
-                            for (int rr = 0; rr < 4; ++rr) cd[rr] = ((4 * lq + rr == li) ? sg : 0.f) - dacc[rr];
-                            const f32x4 w = potrf_inv16_call(cd, lane, NoWork{});
-                            if (!(fabsf(w.w) <= 3.0e38f) && lane == 63) s_flag = 0;
-                            *reinterpret_cast<f32x4*>(Wdl + (J + 1) * 256 + 4 * lane) = w;
-#pragma unroll
-                            for (int rr = 0; rr < 4; ++rr) S17[(4 * lq + rr) * 17 + li] = w[rr];
-                            wave_lds_fence();
-                            f32x4 wt;
-#pragma unroll
-                            for (int rr = 0; rr < 4; ++rr) wt[rr] = S17[li * 17 + 4 * lq + rr];
-                            stt(tidx(J + 1, J + 1), wt);
+                {
+                    int p0 = (J + 1 - wave + 3) >> 2;      // first slot with I > J
+                    p0 = p0 < 0 ? 0 : p0;
+                    f32x4 tfirst = zero4;
+                    switch (p0 * 8 + t1) {
+                        case 0 * 8 + 1: tfirst = panel_tiles<0, 1>(Tl, lane, wave, J, wtn, tjl, bacc); break;
+                        case 0 * 8 + 2: tfirst = panel_tiles<0, 2>(Tl, lane, wave, J, wtn, tjl, bacc); break;
+                        case 0 * 8 + 3: tfirst = panel_tiles<0, 3>(Tl, lane, wave, J, wtn, tjl, bacc); break;
+                        case 0 * 8 + 4: tfirst = panel_tiles<0, 4>(Tl, lane, wave, J, wtn, tjl, bacc); break;
+                        case 1 * 8 + 2: tfirst = panel_tiles<1, 2>(Tl, lane, wave, J, wtn, tjl, bacc); break;
+                        case 1 * 8 + 3: tfirst = panel_tiles<1, 3>(Tl, lane, wave, J, wtn, tjl, bacc); break;
+                        case 1 * 8 + 4: tfirst = panel_tiles<1, 4>(Tl, lane, wave, J, wtn, tjl, bacc); break;
+                        case 2 * 8 + 3: tfirst = panel_tiles<2, 3>(Tl, lane, wave, J, wtn, tjl, bacc); break;
+                        case 2 * 8 + 4: tfirst = panel_tiles<2, 4>(Tl, lane, wave, J, wtn, tjl, bacc); break;
+                        case 3 * 8 + 4: tfirst = panel_tiles<3, 4>(Tl, lane, wave, J, wtn, tjl, bacc); break;
+                        default: break;
+                    }
+                    if (wave == ((J + 1) & 3) && J + 1 < nb) {
+                        // this wave owns the next diagonal tile (its first tile of this column is (J+1, J)): finish and factorise it
+                        if (J > 0) {
+                            const f32x4 tl = ldt(tidx(J + 1, J - 1));
+                            dacc = mm_tn(tl, tl, dacc);
                         }
+                        dacc = mm_tn(tfirst, tfirst, dacc);
+                        potrf_publish(J + 1, dacc);
                     }
                 }
+                STAMP(9);
                 // Schur sums of the NEXT column over the columns < J (column J itself joins after the barrier)
                 f32x4 nacc[4] = {zero4, zero4, zero4, zero4};
-                if (J + 1 < nb) {
-                    for (int K = 0; K < J; ++K) {
-                        const f32x4 tj = ldt(tidx(J + 1, K));
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-                            if (In0 + 4 * t < nb) nacc[t] = mm_tn(tj, ldt(tidx(In0 + 4 * t, K)), nacc[t]);
+                if (J + 1 < nb && J > 0) {
+                    int t0 = (J + 2 - wave + 3) >> 2;      // first slot with I > J + 1
+                    t0 = t0 < 0 ? 0 : t0;
+                    switch (t0 * 8 + t1) {
+                        case 0 * 8 + 1: schur_cols<0, 1>(Tl, lane, wave, J + 1, J, nacc); break;
+                        case 0 * 8 + 2: schur_cols<0, 2>(Tl, lane, wave, J + 1, J, nacc); break;
+                        case 0 * 8 + 3: schur_cols<0, 3>(Tl, lane, wave, J + 1, J, nacc); break;
+                        case 0 * 8 + 4: schur_cols<0, 4>(Tl, lane, wave, J + 1, J, nacc); break;
+                        case 1 * 8 + 2: schur_cols<1, 2>(Tl, lane, wave, J + 1, J, nacc); break;
+                        case 1 * 8 + 3: schur_cols<1, 3>(Tl, lane, wave, J + 1, J, nacc); break;
+                        case 1 * 8 + 4: schur_cols<1, 4>(Tl, lane, wave, J + 1, J, nacc); break;
+                        case 2 * 8 + 3: schur_cols<2, 3>(Tl, lane, wave, J + 1, J, nacc); break;
+                        case 2 * 8 + 4: schur_cols<2, 4>(Tl, lane, wave, J + 1, J, nacc); break;
+                        case 3 * 8 + 4: schur_cols<3, 4>(Tl, lane, wave, J + 1, J, nacc); break;
+                        default: break;
                     }
                 }
                 // diagonal tile two columns ahead over the columns < J
-                if (two_ahead) {
-                    f32x4 d2 = zero4;
-                    for (int K = 0; K < J; ++K) {
-                        const f32x4 tk = ldt(tidx(J + 2, K));
-                        d2 = mm_tn(tk, tk, d2);
-                    }
-                    dacc = d2 + hd;
-                }
+                if (two_ahead) dacc = schur_diag(Tl, lane, J + 2, J) + hd;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) bacc[t] = nacc[t] + hn[t];
+                STAMP(10);
                 __syncthreads();   // column J and W_{J+1} published
+                STAMP(11);
             }
         };
-        // ---- KKT solve on wave 0: right-hand side in xv, solution back in xv (natural order); yv is the intermediate ----
+        // ---- KKT solve on wave 0: right-hand side in xv, solution back in xv (natural order) ----
         auto solve = [&]() {
-            if (wave == 0) {
-                // forward  L y = b :  r_J = b_J - sum_{K<J} L_JK y_K (row vector),  y_J = W_J r_J (column tile)
-                for (int J = 0; J < nb; ++J) {
-                    f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
-                    for (int K = 0; K < J; ++K) {
-                        const f32x4 t = ldt(tidx(J, K));
-                        const f32x4 y4 = lds4(yv + 16 * K + 4 * lq);
-                        a0 += f32x2{t.x, t.y} * f32x2{y4.x, y4.y};
-                        a1 += f32x2{t.z, t.w} * f32x2{y4.z, y4.w};
-                    }
-                    float r = xv[16 * J + li];
-                    if (J > 0) r -= quad_sum(a0.x + a0.y + a1.x + a1.y);
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(Wdl + J * 256 + 4 * lane);
-                    float y0 = w.x * r, y1 = w.y * r, y2 = w.z * r, y3 = w.w * r;
-                    row_sum16x4(y0, y1, y2, y3);
-                    if (li == 0) *reinterpret_cast<f32x4*>(yv + 16 * J + 4 * lq) = f32x4{y0, y1, y2, y3};
-                    wave_lds_fence();
-                }
-                // backward  L' x = y :  r_J = y_J - sum_{I>J} L_IJ' x_I (column tile),  x_J = W_J' r_J (row vector)
-                for (int J = nb - 1; J >= 0; --J) {
-                    f32x4 acc = zero4;
-                    for (int I = J + 1; I < nb; ++I) acc += ldt(tidx(I, J)) * xv[16 * I + li];
-                    f32x4 r = lds4(yv + 16 * J + 4 * lq);
-                    if (J < nb - 1) {
-                        float s0 = acc.x, s1 = acc.y, s2 = acc.z, s3 = acc.w;
-                        row_sum16x4(s0, s1, s2, s3);
-                        r -= f32x4{s0, s1, s2, s3};
-                    }
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(Wdl + J * 256 + 4 * lane);
-                    const float xr = quad_sum(w.x * r.x + w.y * r.y + w.z * r.z + w.w * r.w);
-                    if (lq == 0) xv[16 * J + li] = xr;
-                    wave_lds_fence();
-                }
-            }
+            if (wave == 0) solve_lds<NBMAX>(Tl, Wdl, xv, nb, lane);
             __syncthreads();
         };
 
@@ -448,7 +571,7 @@ __global__ void __launch_bounds__(wgk::WG, 1) ftmpc_solve_wg32_kernel(const Devi
         const float inv2n = 1.0f / (float)(2 * n);
         for (int it = 0; it <= C.max_iters; ++it) {
             __syncthreads();
-            const bool do_ref = !refined && mu_last < (float)C.mu_refine;
+            const bool do_ref = __builtin_amdgcn_readfirstlane(!refined && mu_last < (float)C.mu_refine);
             const float dcur = valid ? ((sl < su) ? lo + sl : hi - su) : 0.f;
             if (do_ref) {
                 // one accurate (float64, structured) gradient at the current iterate: wave 0, the others wait
@@ -465,6 +588,7 @@ __global__ void __launch_bounds__(wgk::WG, 1) ftmpc_solve_wg32_kernel(const Devi
                 __syncthreads();
                 grad = (valid && tid < n) ? (float)(sbuf[tid] + 2.0 * C.rho * ((double)ubar + (double)dcur)) : 0.f;
                 refined = true;
+                STAMP(7);
             } else if (it == 0) {
                 // gradient at the start point: g + H d (every tile once: -H' in register order serves both triangles)
                 if (tid < npad) {
@@ -495,6 +619,7 @@ __global__ void __launch_bounds__(wgk::WG, 1) ftmpc_solve_wg32_kernel(const Devi
                 }
                 __syncthreads();
                 grad = valid ? yv[tid] + gv : 0.f;
+                STAMP(3);
             }
             if (first) {
                 const float gm = wg_reduce(valid ? fabsf(grad) : 0.f, OpMax{});
@@ -506,7 +631,7 @@ __global__ void __launch_bounds__(wgk::WG, 1) ftmpc_solve_wg32_kernel(const Devi
             }
             const float mu = wg_reduce(valid ? sl * zl + su * zu : 0.f, OpAdd{}) * inv2n;
             mu_last = mu;
-            if (!(mu >= mu_stop)) {
+            if (__builtin_amdgcn_readfirstlane(!(mu >= mu_stop))) {
                 status = (mu == mu) ? 0 : 2;
                 break;
             }
@@ -517,15 +642,19 @@ __global__ void __launch_bounds__(wgk::WG, 1) ftmpc_solve_wg32_kernel(const Devi
             __syncthreads();
             if (tid < npad) sigv[tid] = Sig;
             __syncthreads();
+            STAMP(6);
             factor();
-            if (s_flag == 0) {
+            STAMP(4);
+            if (__builtin_amdgcn_readfirstlane(s_flag) == 0) {
                 status = 2;
                 break;
             }
             // predictor: (H + Sig) da = -grad
             if (tid < npad) xv[tid] = -grad;
             __syncthreads();
+            STAMP(6);
             solve();
+            STAMP(5);
             const float da = (tid < npad && valid) ? xv[tid] : 0.f;
             float dzl_a = 0.f, dzu_a = 0.f, ap = 1.f, ad = 1.f;
             if (valid) {
@@ -552,7 +681,9 @@ __global__ void __launch_bounds__(wgk::WG, 1) ftmpc_solve_wg32_kernel(const Devi
             __syncthreads();
             if (tid < npad) xv[tid] = rhs;
             __syncthreads();
+            STAMP(6);
             solve();
+            STAMP(5);
             const float dd = (tid < npad && valid) ? xv[tid] : 0.f;
             float dzl = 0.f, dzu = 0.f;
             ap = 1e30f;
@@ -576,6 +707,7 @@ __global__ void __launch_bounds__(wgk::WG, 1) ftmpc_solve_wg32_kernel(const Devi
                 zu += ad * dzu;
             }
         }
+        STAMP(6);
         // ---------------- outputs ----------------
         __syncthreads();
         float* ubuf = Tl;   // N*NT <= 1024 words, zero = broken thruster
@@ -594,6 +726,13 @@ __global__ void __launch_bounds__(wgk::WG, 1) ftmpc_solve_wg32_kernel(const Devi
             if (P.status) P.status[inst] = status;
             if (P.iters) P.iters[inst] = nit;
         }
+        STAMP(8);
+#ifdef FTMPC_STAMPS
+        if (tid == 0 && inst < 4096) {
+            unsigned long long* sb = reinterpret_cast<unsigned long long*>(P.dbg_H) + inst * 12;
+            for (int i = 0; i < 12; ++i) sb[i] = st_acc[i];
+        }
+#endif
     }
 }
 

@@ -9,7 +9,8 @@ _lib._SO = Path(os.environ["FTMPC_LIB"]) if os.environ.get("FTMPC_LIB") else _li
 import ft_mpc_amd
 B=int(sys.argv[1]) if len(sys.argv)>1 else 4096
 nf=int(sys.argv[2]) if len(sys.argv)>2 else 2
-N,NT=20,8
+N=int(sys.argv[3]) if len(sys.argv)>3 else 20
+NT=int(sys.argv[4]) if len(sys.argv)>4 else 8
 mpc=ft_mpc_amd.BatchedMPC(N=N,NT=NT)
 x0,ub,stuck,xref=ft_mpc_amd.make_synthetic_batch(B,N,NT,nf,1003)
 out=mpc.solve(x0,ub,stuck,xref.reshape(-1,order='F'))
@@ -18,6 +19,7 @@ buf=np.zeros((cnt,12),np.uint64)
 f=mpc.lib.ftmpc_debug_read_stamps; f.argtypes=[C.c_void_p,C.c_int64,C.c_void_p]
 assert f(mpc._h,cnt,buf.ctypes.data_as(C.c_void_p))==0
 names=["prologue","build:propagate","build:mfma","finalize+store","matvec","chol","solves(2)","elementwise","refine (f64 grad)","output","x10","x11"]
+if N*NT>160: names=["prologue","build 1: condense","build 2: H tiles","start gradient","factor","solves(2)","elementwise","refine (f64 grad)","output","factor: finish+panel+potrf (wave 0)","factor: schur sums (wave 0)","factor: barrier wait (wave 0)"]
 m=buf.astype(np.float64).mean(axis=0); tot=m.sum()
 print("iters mean %.2f   total cycles/QP %.0f"%(out['iters'].mean(),tot))
 for n_,v in zip(names,m):

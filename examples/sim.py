@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--nominal", action="store_true", help="no actuator failure (BASELINE config 1)")
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--formulation", default="thruster", choices=["thruster", "wrench"],
+                    help="wrench: the reference's own two-stage structure (6-D MPC with the input hull, then allocation)")
+    ap.add_argument("--terminal-set", action="store_true", help="add the 72-row terminal set of config/terminal.yaml")
     args = ap.parse_args()
     params = yaml.safe_load(open(ROOT / "fault-tolerant-mpc_amd" / "ft_mpc_amd" / "config" / "reactive.yaml"))
     dt, duration = params["time_step"], params["traj_duration"]
@@ -40,7 +43,8 @@ def main():
                 continue
             model.set_fault(BrokenThruster(f["act_id"], f["intensity"]))
     spiral_model = SpiralModel.from_system_model(model)
-    controller = SpiralingController(spiral_model, params["tuning"]["spiraling"], history, quiet=True)
+    tuning = dict(params["tuning"]["spiraling"], formulation=args.formulation, terminal_set=args.terminal_set)
+    controller = SpiralingController(spiral_model, tuning, history, quiet=True)
     controller.load_trajectory(params["traj_shape"], duration)
     env = SimulationEnvironment(model, controller, seed=args.seed)
     env.set_initial_state(position=[1, 0, 1], velocity=[1, 0.5, 0],

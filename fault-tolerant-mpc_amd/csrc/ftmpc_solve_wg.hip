@@ -45,60 +45,6 @@ __device__ __forceinline__ void mm_tn2(const f32x4& X, const f32x4& Y, f32x4& a,
     a = mfma4(X.z, Y.z, a);
     b = mfma4(X.w, Y.w, b);
 }
-// Schur sums of the tiles (wave + 4 t, J1), t in [T0, T1), over the block columns K < Kend:
-//     acc[t] += sum_K T(J1, K)' T(wave + 4 t, K)
-// All operands are LDS tiles in register order (one b128 per lane); the tiles of the next K are requested before the
-// MFMAs of the current one are issued, and the T1 - T0 tiles are independent chains.
-template <int T0, int T1>
-__device__ __forceinline__ void schur_cols(const float* Tl, int lane, int wave, int J1, int Kend, f32x4 (&acc)[4]) {
-    if (Kend <= 0) return;
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    const float* pj = Tl + tidx(J1, 0) * 256 + 4 * lane;
-    const float* pi[4];
-    f32x4 a2[4], ti[4], tin[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        pi[t] = Tl + tidx(wave + 4 * t, 0) * 256 + 4 * lane;
-        a2[t] = z;
-        ti[t] = z;
-        tin[t] = z;
-    }
-    (void)tin;
-    for (int K = 0; K < Kend; ++K) {   // (a hand-pipelined version with pinned order measured slower: scripts/ubench_lds_mfma.hip)
-        const f32x4 tj = lds4(pj + K * 256);
-#pragma unroll
-        for (int t = T0; t < T1; ++t) ti[t] = lds4(pi[t] + K * 256);
-#pragma unroll
-        for (int t = T0; t < T1; ++t) mm_tn2(tj, ti[t], acc[t], a2[t]);
-    }
-#pragma unroll
-    for (int t = T0; t < T1; ++t) acc[t] += a2[t];
-}
-// The tiles (wave + 4 t, J), t in [T0, T1), of block column J: last Schur term (K = J - 1), panel solve
-// L_IJ' = W_J (H_IJ' - sum), store.  Straight-line code over the tiles: their MFMA chains interleave.
-// Returns the first tile (the one the owner of the next diagonal block needs at once).
-template <int T0, int T1>
-__device__ __forceinline__ f32x4 panel_tiles(float* Tl, int lane, int wave, int J, const f32x4& wtn, const f32x4& tjl, f32x4 (&bacc)[4]) {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    f32x4 ti[4], tij[4];
-    if (J > 0) {
-#pragma unroll
-        for (int t = T0; t < T1; ++t) ti[t] = lds4(Tl + tidx(wave + 4 * t, J - 1) * 256 + 4 * lane);
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-            for (int t = T0; t < T1; ++t) bacc[t] = mfma4(tjl[s4], ti[t][s4], bacc[t]);
-    }
-#pragma unroll
-    for (int t = T0; t < T1; ++t) tij[t] = z;
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-        for (int t = T0; t < T1; ++t) tij[t] = mfma4(wtn[s4], bacc[t][s4], tij[t]);
-#pragma unroll
-    for (int t = T0; t < T1; ++t) *reinterpret_cast<f32x4*>(Tl + tidx(wave + 4 * t, J) * 256 + 4 * lane) = tij[t];
-    return tij[T0];
-}
 // sum_K T(D, K)' T(D, K) for K < Kend (the diagonal tile D)
 __device__ __forceinline__ f32x4 schur_diag(const float* Tl, int lane, int D, int Kend) {
     f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
@@ -456,10 +402,14 @@ __global__ void __launch_bounds__(wgk::WG, 1) ftmpc_solve_wg32_kernel(const Devi
         }
 
         // ---------------- KKT factorisation (see the header) ----------------
-        // rows of wave w: I = w + 4 t (t = 0..3); its tiles in block column Jc are those with Jc < I < nb
+        // Phase J (W_J and every tile of the columns < J visible) has one wave on the critical chain and three helpers:
+        //   owner (J+1) & 3 : tile (J+1, J), the last two terms of diagonal tile J+1, its Cholesky + inverse, W_{J+1}
+        //   helpers         : the other tiles (I, J) of column J (panel solve), the Schur sums of column J+1 and of
+        //                     diagonal tile J+2 over the columns < J -- dealt tile by tile over the three of them.
+        // Partial sums travel through the LDS slot of the tile they belong to (written in one phase, finished in the next),
+        // so no tile is tied to a wave and the owner carries nothing but the chain.
         auto factor = [&]() {
             if (tid == 0) s_flag = 1;
-            f32x4 bacc[4], dacc = zero4;
             auto potrf_publish = [&](int D, const f32x4& dsum) {
                 // diagonal tile D: H + Sigma - sum, Cholesky + inverse in registers, W and W' to LDS
                 const float sg = sigv[16 * D + li];
@@ -477,81 +427,101 @@ __global__ void __launch_bounds__(wgk::WG, 1) ftmpc_solve_wg32_kernel(const Devi
                 for (int rr = 0; rr < 4; ++rr) wt[rr] = S17[li * 17 + 4 * lq + rr];
                 stt(tidx(D, D), wt);
             };
-            // prologue: diagonal tile 0 (wave 0), H of diagonal tile 1 (wave 1), column 0 of every wave
             if (wave == 0) potrf_publish(0, ldh(tidx(0, 0)));
-            if (wave == 1 && nb > 1) dacc = ldh(tidx(1, 1));
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int I = wave + 4 * t;
-                bacc[t] = (I > 0 && I < nb) ? ldh(tidx(I, 0)) : zero4;
-            }
             __syncthreads();   // W_0 published
-            const int t1 = (nb - wave + 3) >> 2;           // slots t < t1 have I < nb
-            for (int J = 0; J < nb; ++J) {
-                // ---- phase J: W_J and every tile of the columns < J are visible ----
-                // Hessian tiles of the next column (and of the diagonal two ahead): requested now, used at the end
-                f32x4 hn[4], hd = zero4;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int I = wave + 4 * t;
-                    hn[t] = (I > J + 1 && I < nb) ? ldh(tidx(I, J + 1)) : zero4;
-                }
-                const bool two_ahead = (wave == ((J + 2) & 3)) && (J + 2 < nb);
-                if (two_ahead) hd = ldh(tidx(J + 2, J + 2));
+            for (int J = 0; J + 1 < nb; ++J) {
+                const int owner = (J + 1) & 3;
+                const int r = (wave - owner - 1) & 3;          // 0..2: helper rank, 3: the owner
                 f32x4 wtn = ldt(tidx(J, J));
                 wtn = -wtn;
                 const f32x4 tjl = (J > 0) ? ldt(tidx(J, J - 1)) : zero4;       // T(J, J-1): the last Schur term of column J
-                {
-                    int p0 = (J + 1 - wave + 3) >> 2;      // first slot with I > J
-                    p0 = p0 < 0 ? 0 : p0;
-                    f32x4 tfirst = zero4;
-                    switch (p0 * 8 + t1) {
-                        case 0 * 8 + 1: tfirst = panel_tiles<0, 1>(Tl, lane, wave, J, wtn, tjl, bacc); break;
-                        case 0 * 8 + 2: tfirst = panel_tiles<0, 2>(Tl, lane, wave, J, wtn, tjl, bacc); break;
-                        case 0 * 8 + 3: tfirst = panel_tiles<0, 3>(Tl, lane, wave, J, wtn, tjl, bacc); break;
-                        case 0 * 8 + 4: tfirst = panel_tiles<0, 4>(Tl, lane, wave, J, wtn, tjl, bacc); break;
-                        case 1 * 8 + 2: tfirst = panel_tiles<1, 2>(Tl, lane, wave, J, wtn, tjl, bacc); break;
-                        case 1 * 8 + 3: tfirst = panel_tiles<1, 3>(Tl, lane, wave, J, wtn, tjl, bacc); break;
-                        case 1 * 8 + 4: tfirst = panel_tiles<1, 4>(Tl, lane, wave, J, wtn, tjl, bacc); break;
-                        case 2 * 8 + 3: tfirst = panel_tiles<2, 3>(Tl, lane, wave, J, wtn, tjl, bacc); break;
-                        case 2 * 8 + 4: tfirst = panel_tiles<2, 4>(Tl, lane, wave, J, wtn, tjl, bacc); break;
-                        case 3 * 8 + 4: tfirst = panel_tiles<3, 4>(Tl, lane, wave, J, wtn, tjl, bacc); break;
-                        default: break;
+                if (r == 3) {
+                    f32x4 part, dsum;
+                    if (J > 0) {
+                        const f32x4 tl = ldt(tidx(J + 1, J - 1));
+                        part = ldt(tidx(J + 1, J));
+                        dsum = ldt(tidx(J + 1, J + 1));
+                        part = mm_tn(tjl, tl, part);
+                        dsum = mm_tn(tl, tl, dsum);
+                    } else {
+                        part = ldh(tidx(1, 0));
+                        dsum = ldh(tidx(1, 1));
                     }
-                    if (wave == ((J + 1) & 3) && J + 1 < nb) {
-                        // this wave owns the next diagonal tile (its first tile of this column is (J+1, J)): finish and factorise it
-                        if (J > 0) {
-                            const f32x4 tl = ldt(tidx(J + 1, J - 1));
-                            dacc = mm_tn(tl, tl, dacc);
-                        }
-                        dacc = mm_tn(tfirst, tfirst, dacc);
-                        potrf_publish(J + 1, dacc);
-                    }
-                }
-                STAMP(9);
-                // Schur sums of the NEXT column over the columns < J (column J itself joins after the barrier)
-                f32x4 nacc[4] = {zero4, zero4, zero4, zero4};
-                if (J + 1 < nb && J > 0) {
-                    int t0 = (J + 2 - wave + 3) >> 2;      // first slot with I > J + 1
-                    t0 = t0 < 0 ? 0 : t0;
-                    switch (t0 * 8 + t1) {
-                        case 0 * 8 + 1: schur_cols<0, 1>(Tl, lane, wave, J + 1, J, nacc); break;
-                        case 0 * 8 + 2: schur_cols<0, 2>(Tl, lane, wave, J + 1, J, nacc); break;
-                        case 0 * 8 + 3: schur_cols<0, 3>(Tl, lane, wave, J + 1, J, nacc); break;
-                        case 0 * 8 + 4: schur_cols<0, 4>(Tl, lane, wave, J + 1, J, nacc); break;
-                        case 1 * 8 + 2: schur_cols<1, 2>(Tl, lane, wave, J + 1, J, nacc); break;
-                        case 1 * 8 + 3: schur_cols<1, 3>(Tl, lane, wave, J + 1, J, nacc); break;
-                        case 1 * 8 + 4: schur_cols<1, 4>(Tl, lane, wave, J + 1, J, nacc); break;
-                        case 2 * 8 + 3: schur_cols<2, 3>(Tl, lane, wave, J + 1, J, nacc); break;
-                        case 2 * 8 + 4: schur_cols<2, 4>(Tl, lane, wave, J + 1, J, nacc); break;
-                        case 3 * 8 + 4: schur_cols<3, 4>(Tl, lane, wave, J + 1, J, nacc); break;
-                        default: break;
-                    }
-                }
-                // diagonal tile two columns ahead over the columns < J
-                if (two_ahead) dacc = schur_diag(Tl, lane, J + 2, J) + hd;
+                    const f32x4 tij = mm_tn(wtn, part, zero4);
+                    stt(tidx(J + 1, J), tij);
+                    dsum = mm_tn(tij, tij, dsum);
+                    potrf_publish(J + 1, dsum);
+                } else {
+                    // the other tiles of column J, two at a time (independent MFMA chains)
+                    for (int I = J + 2 + r; I < nb; I += 6) {
+                        const int I2 = I + 3;
+                        if (I2 < nb) {
+                            f32x4 pa, pb;
+                            if (J > 0) {
+                                const f32x4 ta = ldt(tidx(I, J - 1)), tb = ldt(tidx(I2, J - 1));
+                                pa = ldt(tidx(I, J));
+                                pb = ldt(tidx(I2, J));
 #pragma unroll
-                for (int t = 0; t < 4; ++t) bacc[t] = nacc[t] + hn[t];
+                                for (int s4 = 0; s4 < 4; ++s4) {
+                                    pa = mfma4(tjl[s4], ta[s4], pa);
+                                    pb = mfma4(tjl[s4], tb[s4], pb);
+                                }
+                            } else {
+                                pa = ldh(tidx(I, 0));
+                                pb = ldh(tidx(I2, 0));
+                            }
+                            f32x4 xa = zero4, xb = zero4;
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; ++s4) {
+                                xa = mfma4(wtn[s4], pa[s4], xa);
+                                xb = mfma4(wtn[s4], pb[s4], xb);
+                            }
+                            stt(tidx(I, J), xa);
+                            stt(tidx(I2, J), xb);
+                        } else {
+                            f32x4 pa;
+                            if (J > 0) {
+                                const f32x4 ta = ldt(tidx(I, J - 1));
+                                pa = ldt(tidx(I, J));
+                                pa = mm_tn(tjl, ta, pa);
+                            } else {
+                                pa = ldh(tidx(I, 0));
+                            }
+                            stt(tidx(I, J), mm_tn(wtn, pa, zero4));
+                        }
+                    }
+                    // Schur sums of column J+1 over the columns < J, Hessian tile included, into the tiles' own slots
+                    const float* pj = Tl + tidx(J + 1, 0) * 256 + 4 * lane;
+                    for (int I = J + 2 + r; I < nb; I += 6) {
+                        const int I2 = I + 3;
+                        const float* pa = Tl + tidx(I, 0) * 256 + 4 * lane;
+                        if (I2 < nb) {
+                            const float* pb = Tl + tidx(I2, 0) * 256 + 4 * lane;
+                            const f32x4 ha = ldh(tidx(I, J + 1)), hb = ldh(tidx(I2, J + 1));
+                            f32x4 a0 = zero4, a1 = zero4, b0 = zero4, b1 = zero4;
+                            for (int K = 0; K < J; ++K) {
+                                const f32x4 tj = lds4(pj + K * 256), ta = lds4(pa + K * 256), tb = lds4(pb + K * 256);
+                                mm_tn2(tj, ta, a0, a1);
+                                mm_tn2(tj, tb, b0, b1);
+                            }
+                            stt(tidx(I, J + 1), a0 + a1 + ha);
+                            stt(tidx(I2, J + 1), b0 + b1 + hb);
+                        } else {
+                            const f32x4 ha = ldh(tidx(I, J + 1));
+                            f32x4 a0 = zero4, a1 = zero4;
+                            for (int K = 0; K < J; ++K) {
+                                const f32x4 tj = lds4(pj + K * 256), ta = lds4(pa + K * 256);
+                                mm_tn2(tj, ta, a0, a1);
+                            }
+                            stt(tidx(I, J + 1), a0 + a1 + ha);
+                        }
+                    }
+                    // diagonal tile two columns ahead over the columns < J (the helper with the fewest tiles)
+                    if (r == 2 && J + 2 < nb) {
+                        const f32x4 hd = ldh(tidx(J + 2, J + 2));
+                        stt(tidx(J + 2, J + 2), schur_diag(Tl, lane, J + 2, J) + hd);
+                    }
+                }
                 STAMP(10);
                 __syncthreads();   // column J and W_{J+1} published
                 STAMP(11);

@@ -25,9 +25,18 @@ Rule table (gfx940/gfx950; names of the LLVM GCNHazardRecognizer checks they res
   valu_mfma       VALU writes VGPR -> MFMA reads it as A/B/C                        2   (reported for asm producers only)
 A wait state is one issued instruction; `s_nop N` is N+1.
 
-The compiler is the authority for pairs it scheduled itself: a "violation" between two compiler instructions means the
-rule here is stricter than the hardware needs, and is reported separately (calibration), not as an error.  Exit code 1
-when a pair with at least one side inside an asm body violates a rule.
+Pairs the compiler scheduled itself are reported separately ("compiler-only").  For most of the project's life that
+list was empty and served as the calibration of the rule table -- until the workgroup kernel's helper loops produced
+    v_mfma_f32_16x16x4_f32 a[0:3], ...   (end of a chain)
+    v_mfma_f32_16x16x4_f32 a[4:7], ...
+    s_cbranch_execnz .LBB15_3508
+  .LBB15_3508:
+    s_waitcnt vmcnt(1)
+    v_accvgpr_read_b32 v7, a3            (3 wait states after the producer; the table says 10)
+and the kernel returned wrong factors on the GPU (3861 of 4096 instances not converged) until the consumer was padded.
+So `--elide` also PADS every compiler-only pair up to the table, and the audit of its output fails on any pair left,
+whichever side wrote it.  Exit code 1 when a pair with at least one side inside an asm body violates a rule, or (after
+--elide) when any pair does.
 """
 import argparse
 import re
@@ -324,6 +333,15 @@ def elide(asm_in, asm_out):
         for it in items:
             if not isinstance(it, tuple) and it.mn == "s_nop" and it.in_asm:
                 new_ws[it.line] = it.ws
+    # pairs the compiler scheduled itself below the table (seen once: an MFMA chain, a branch, v_accvgpr_read of the
+    # result three wait states later): pad the consumer rather than argue about which side is right
+    pad = {}
+    for name, items in funcs.items():
+        for f in check_function(items):
+            if not f["asm"]:
+                ln = f["cons"].line
+                pad[ln] = max(pad.get(ln, 0), f["need"] - f["have"])
+        stats[name]["padded"] = sum(1 for it in items if not isinstance(it, tuple) and it.line in pad)
     out = []
     for ln, raw in enumerate(open(asm_in), 1):
         if ln in new_ws:
@@ -331,6 +349,11 @@ def elide(asm_in, asm_out):
             if w == 0:
                 continue
             raw = re.sub(r"s_nop\s+\S+", f"s_nop {w - 1}", raw, count=1)
+        if ln in pad:
+            w = pad[ln]
+            while w > 0:
+                out.append(f"\ts_nop {min(w, 8) - 1}\n")
+                w -= min(w, 8)
         out.append(raw)
     Path(asm_out).write_text("".join(out))
     return stats
@@ -369,26 +392,28 @@ def main():
         for name, v in st.items():
             if v["asm_wait_states"]:
                 print(f"elide {re.sub(r'^_ZN5ftmpc[0-9]+', '', name)[:50]:52s} asm wait states {v['asm_wait_states']:6d} -> {v['asm_wait_states'] - v['saved']:6d}"
-                      f"  ({v['nops_removed']} s_nop removed)")
+                      f"  ({v['nops_removed']} s_nop removed)" + (f", {v['padded']} compiler-side pairs padded" if v.get("padded") else ""))
         path = Path(args.elide)
     summary = audit(path)
     bad = 0
     for name, s in summary.items():
         short = re.sub(r"^_ZN5ftmpc\d+", "", name)[:60]
         print(f"{short:62s} {s['n_inst']:7d} instructions, {s['n_asm_inst']:5d} inside asm: "
-              f"{len(s['asm'])} asm-side violations, {len(s['compiler'])} compiler-only (calibration)")
+              f"{len(s['asm'])} asm-side violations, {len(s['compiler'])} compiler-only")
         for f in s["asm"][:50]:
             bad += 1
             print(f"   !! {f['rule']}: need {f['need']} wait states, have {f['have']} on {f['reg']}\n"
                   f"        producer L{f['prod'].line}{' [asm]' if f['prod'].in_asm else ''}: {f['prod'].text}\n"
                   f"        consumer L{f['cons'].line}{' [asm]' if f['cons'].in_asm else ''}: {f['cons'].text}")
-        if args.verbose:
+        if args.elide:
+            bad += len(s["compiler"])
+        if args.verbose or (args.elide and s["compiler"]):
             by = defaultdict(list)
             for f in s["compiler"]:
                 by[f["rule"]].append(f)
             for r, fs in by.items():
                 f = fs[0]
-                print(f"   (calibration) {r}: {len(fs)} compiler pairs below {f['need']}; e.g. have {f['have']}: L{f['prod'].line} {f['prod'].text}  ->  L{f['cons'].line} {f['cons'].text}")
+                print(f"   (compiler-only) {r}: {len(fs)} compiler pairs below {f['need']}; e.g. have {f['have']}: L{f['prod'].line} {f['prod'].text}  ->  L{f['cons'].line} {f['cons'].text}")
     print("asm-side violations:", bad)
     return 1 if bad else 0
 

@@ -27,20 +27,25 @@ def test_no_hazard_in_any_kernel(device_asm):
     assert any("ftmpc_solve_f64_kernel" in n and summary[n]["n_asm_inst"] > 100 for n in summary)
     bad = [(n, f["rule"], f["prod"].text, f["cons"].text) for n, s in summary.items() for f in s["asm"]]
     assert not bad, bad[:5]
-    # pairs the compiler scheduled itself also satisfy the table: the rules are not stricter than hipcc's own
-    assert sum(len(s["compiler"]) for s in summary.values()) == 0
+    # Pairs the compiler scheduled itself satisfy the table everywhere except at one pattern of the workgroup kernel: an
+    # MFMA chain, a branch, v_accvgpr_read of the result 3 wait states later (table: 10).  That one is real -- the GPU
+    # returned wrong factors until the consumer was padded (scripts/check_hazards.py header) -- so the build pads it.
+    comp = [(n, f) for n, s in summary.items() for f in s["compiler"]]
+    assert all(f["rule"] == "mfma_use" and "ftmpc_solve_wg32_kernel" in n for n, f in comp), [(n, f["rule"]) for n, f in comp][:5]
 
 
 def test_elided_stream_is_clean_and_shorter(device_asm, tmp_path):
-    """What the build ships: the asm-side wait states lowered to what the final schedule needs (csrc/Makefile step 2).
-    The lowered stream passes the same audit and drops most of the conservative s_nops of the fp32 kernels."""
+    """What the build ships: the asm-side wait states lowered to what the final schedule needs, compiler-side pairs below
+    the table padded (csrc/Makefile step 2).  The result passes the audit with NO pair left on either side and drops
+    most of the conservative s_nops of the fp32 kernels."""
     out = tmp_path / "final.s"
     stats = ch.elide(device_asm, out)
     summary = ch.audit(out)
     assert not [f for s in summary.values() for f in s["asm"]] and sum(len(s["compiler"]) for s in summary.values()) == 0
     k8 = next(v for n, v in stats.items() if "ftmpc_solve_f32_kernelILi8" in n)
     assert k8["saved"] > 0.5 * k8["asm_wait_states"]
-    # every change is an s_nop line lowered or dropped: nothing else differs
+    assert sum(v.get("padded", 0) for v in stats.values()) == len({f["cons"].line for s in ch.audit(device_asm).values() for f in s["compiler"]})
+    # every change is an s_nop line lowered, dropped or added: nothing else differs
     a = [l for l in device_asm.read_text().split("\n") if not l.strip().startswith("s_nop")]
     b = [l for l in out.read_text().split("\n") if not l.strip().startswith("s_nop")]
     assert a == b
@@ -79,5 +84,8 @@ def test_rule_table_on_hand_written_sequences(tmp_path):
     assert run(["v_mfma_f32_16x16x4_f32 v[0:3], v4, v5, v[0:3]"] + ["s_nop 7"] + ["v_add_f32_e32 v9, v0, v0"]) == ["mfma_use"]
     assert run(["v_mfma_f32_16x16x4_f32 v[0:3], v4, v5, v[0:3]"] + ["s_nop 7", "s_nop 1"] + ["v_add_f32_e32 v9, v0, v0"]) == []
     assert run(["v_mfma_f32_16x16x4_f32 v[0:3], v4, v5, v[0:3]", "v_mfma_f32_16x16x4_f32 v[0:3], v6, v7, v[0:3]"]) == []   # accumulate chain
+    # the sequence hipcc emitted in the workgroup kernel (wrong results on the GPU until padded)
+    assert run(["v_mfma_f32_16x16x4_f32 a[0:3], v25, v7, a[0:3]", "v_mfma_f32_16x16x4_f32 a[4:7], v25, v15, a[4:7]", "s_cbranch_execnz .LBB0_8",
+                "s_branch .LBB0_9", ".LBB0_8:", "s_waitcnt vmcnt(1)", "v_accvgpr_read_b32 v7, a3", ".LBB0_9:"]) == ["mfma_use"]
     # across a branch edge: the producer sits before the branch, the consumer behind the label
     assert run(["v_mov_b32_e32 v1, v2", "s_cbranch_scc1 .LBB0_2", "s_nop 3", ".LBB0_2:", "v_add_f32_dpp v3, v1, v1 row_ror:8 row_mask:0xf bank_mask:0xf"]) == ["dpp_vgpr"]

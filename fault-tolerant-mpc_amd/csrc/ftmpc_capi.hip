@@ -72,7 +72,7 @@ struct ftmpc_handle {
     hipStream_t s_in = nullptr, s_out = nullptr;
     static constexpr int MAX_CHUNKS = 8;
     hipEvent_t ev_in[MAX_CHUNKS] = {}, ev_k[MAX_CHUNKS] = {}, ev_out[MAX_CHUNKS] = {};
-    int stage_chunks = 4;
+    int stage_chunks = 0;   // 0: whole blocks of 65 536 instances (a persistent launch below that does not fill the device twice)
     // fp32 workgroup-per-instance kernel with the factor in LDS (160 < N*NT <= 240)
     bool use_wg = false;
     float* wg_slot = nullptr;
@@ -678,7 +678,11 @@ int ftmpc_solve_batch(ftmpc_handle* h, int64_t B, const double* x0, const double
     double* pout = static_cast<double*>(h->pin_out.p);
     int32_t* pst = reinterpret_cast<int32_t*>(pout + out_words);
     int32_t* pit = pst + B;
-    int nch = (int)std::min<int64_t>(h->stage_chunks, (B + 16383) / 16384);
+    // Measured at B = 65 536 (scripts/host_entry_perf.py): one range 3.20 M QP/s, four ranges 2.74 M -- a range of 16 384
+    // instances leaves the persistent grid with a ragged tail four times per call; so ranges are whole 65 536-blocks
+    // unless FTMPC_STAGE_CHUNKS says otherwise.
+    int nch = h->stage_chunks > 0 ? (int)std::min<int64_t>(h->stage_chunks, (B + 16383) / 16384)
+                                  : (int)std::min<int64_t>(ftmpc_handle::MAX_CHUNKS, (B + 65535) / 65536);
     if (nch < 1) nch = 1;
     int64_t edge[ftmpc_handle::MAX_CHUNKS + 1];
     for (int c = 0; c <= nch; ++c) edge[c] = (c == nch) ? B : ((B * c / nch) / 64) * 64;

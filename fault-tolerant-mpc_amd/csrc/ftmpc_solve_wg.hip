@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(wgk::WG, 1) ftmpc_solve_wg32_kernel(const Devi
                         stt(tidx(J + 2, J + 2), schur_diag(Tl, lane, J + 2, J) + hd);
                     }
                 }
-                STAMP(10);
+                if (r == 3) STAMP(9); else STAMP(10);
                 __syncthreads();   // column J and W_{J+1} published
                 STAMP(11);
             }

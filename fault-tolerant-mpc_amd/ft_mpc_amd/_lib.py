@@ -12,7 +12,8 @@ from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
 _CSRC = _HERE.parent / "csrc"
-_SO = _HERE / "libftmpc_hip.so"
+# FTMPC_LIB selects another build of the SAME library (csrc/Makefile targets `stamps`, `plain`, experiments): diagnostics only
+_SO = Path(os.environ["FTMPC_LIB"]).resolve() if os.environ.get("FTMPC_LIB") else _HERE / "libftmpc_hip.so"
 
 MAX_NT = 16
 MAX_TERM_ROWS = 80

@@ -321,14 +321,14 @@ def elide_function(items):
     return saved, removed
 
 
-def elide(asm_in, asm_out):
+def elide(asm_in, asm_out, lower=True):
     """Writes asm_out = asm_in with the asm-side wait states minimised; returns statistics.  The result is audited again."""
     funcs = parse(asm_in)
     new_ws = {}
     stats = {}
     for name, items in funcs.items():
         before = sum(it.ws for it in items if not isinstance(it, tuple) and it.mn == "s_nop" and it.in_asm)
-        saved, removed = elide_function(items)
+        saved, removed = elide_function(items) if lower else (0, 0)
         stats[name] = dict(asm_wait_states=before, saved=saved, nops_removed=removed)
         for it in items:
             if not isinstance(it, tuple) and it.mn == "s_nop" and it.in_asm:
@@ -380,7 +380,8 @@ def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--asm", help="device assembly to audit (default: compile csrc/ftmpc_capi.hip)")
     ap.add_argument("-v", "--verbose", action="store_true")
-    ap.add_argument("--elide", metavar="OUT", help="write the assembly with minimised asm-side wait states to OUT, then audit OUT")
+    ap.add_argument("--elide", metavar="OUT", help="write the assembly with minimised asm-side wait states (and padded compiler-side pairs) to OUT, then audit OUT")
+    ap.add_argument("--pad-only", action="store_true", help="with --elide: keep the asm-side wait states as written, only pad")
     args = ap.parse_args()
     if args.asm:
         path = Path(args.asm)
@@ -388,7 +389,7 @@ def main():
         path = Path(tempfile.mkdtemp(prefix="ftmpc_haz_")) / "ftmpc_dev.s"
         build_asm(path)
     if args.elide:
-        st = elide(path, args.elide)
+        st = elide(path, args.elide, lower=not args.pad_only)
         for name, v in st.items():
             if v["asm_wait_states"]:
                 print(f"elide {re.sub(r'^_ZN5ftmpc[0-9]+', '', name)[:50]:52s} asm wait states {v['asm_wait_states']:6d} -> {v['asm_wait_states'] - v['saved']:6d}"

@@ -19,7 +19,7 @@ buf=np.zeros((cnt,12),np.uint64)
 f=mpc.lib.ftmpc_debug_read_stamps; f.argtypes=[C.c_void_p,C.c_int64,C.c_void_p]
 assert f(mpc._h,cnt,buf.ctypes.data_as(C.c_void_p))==0
 names=["prologue","build:propagate","build:mfma","finalize+store","matvec","chol","solves(2)","elementwise","refine (f64 grad)","output","x10","x11"]
-if N*NT>160: names=["prologue","build 1: condense","build 2: H tiles","start gradient","factor","solves(2)","elementwise","refine (f64 grad)","output","(unused)","factor: work of wave 0 (owner chain or helper tiles)","factor: barrier wait (wave 0)"]
+if N*NT>160: names=["prologue","build 1: condense","build 2: H tiles","start gradient","factor","solves(2)","elementwise","refine (f64 grad)","output","factor: wave 0 on the chain (3-4 of 14 phases)","factor: wave 0 as a helper","factor: barrier wait (wave 0)"]
 m=buf.astype(np.float64).mean(axis=0); tot=m.sum()
 print("iters mean %.2f   total cycles/QP %.0f"%(out['iters'].mean(),tot))
 for n_,v in zip(names,m):

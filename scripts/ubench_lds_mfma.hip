@@ -14,6 +14,50 @@ __global__ void __launch_bounds__(256, 1) k(float* out, unsigned long long* cyc,
     const float* pj = Tl + (wave * 7) * 256 + 4 * lane;
     const float* pi = Tl + (40 + wave * 11) * 256 + 4 * lane;
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (MODE == 3) {   // ping-pong: two register sets, the loads of step K+1 issued before the MFMAs of step K, no copies
+        for (int rep = 0; rep < 200; ++rep) {
+            f32x4 tj0 = lds4(pj), ti0[4], tj1 = tj0, ti1[4];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) ti0[t] = ti1[t] = lds4(pi + t * 4096);
+            int K = 0;
+            for (; K + 1 < J; K += 2) {
+                tj1 = lds4(pj + (K + 1) * 256);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) ti1[t] = lds4(pi + t * 4096 + (K + 1) * 256);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    a[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(tj0.x, ti0[t].x, a[t], 0, 0, 0);
+                    b[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(tj0.y, ti0[t].y, b[t], 0, 0, 0);
+                    a[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(tj0.z, ti0[t].z, a[t], 0, 0, 0);
+                    b[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(tj0.w, ti0[t].w, b[t], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int K2 = (K + 2 < J) ? K + 2 : K;
+                tj0 = lds4(pj + K2 * 256);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) ti0[t] = lds4(pi + t * 4096 + K2 * 256);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    a[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(tj1.x, ti1[t].x, a[t], 0, 0, 0);
+                    b[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(tj1.y, ti1[t].y, b[t], 0, 0, 0);
+                    a[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(tj1.z, ti1[t].z, a[t], 0, 0, 0);
+                    b[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(tj1.w, ti1[t].w, b[t], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (K < J) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    a[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(tj0.x, ti0[t].x, a[t], 0, 0, 0);
+                    b[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(tj0.y, ti0[t].y, b[t], 0, 0, 0);
+                    a[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(tj0.z, ti0[t].z, a[t], 0, 0, 0);
+                    b[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(tj0.w, ti0[t].w, b[t], 0, 0, 0);
+                }
+            }
+        }
+    } else
     for (int rep = 0; rep < 200; ++rep) {
         f32x4 tj = lds4(pj), ti[4];
         for (int t = 0; t < NT; ++t) ti[t] = lds4(pi + t * 4096);
@@ -63,9 +107,11 @@ void run(float* d, unsigned long long* c, int threads, int J) {
 int main() {
     float* d; unsigned long long* c; hipMalloc(&d, 4096); hipMalloc(&c, 64);
     for (int threads : {64, 256}) {
-        run<2, 1>(d, c, threads, 8); run<0, 1>(d, c, threads, 8); run<1, 1>(d, c, threads, 8);
-        run<2, 2>(d, c, threads, 8); run<0, 2>(d, c, threads, 8); run<1, 2>(d, c, threads, 8);
-        run<2, 4>(d, c, threads, 8); run<0, 4>(d, c, threads, 8); run<1, 4>(d, c, threads, 8);
+        run<2, 1>(d, c, threads, 8); run<0, 1>(d, c, threads, 8); run<1, 1>(d, c, threads, 8); run<3, 1>(d, c, threads, 8);
+        run<2, 2>(d, c, threads, 8); run<0, 2>(d, c, threads, 8); run<1, 2>(d, c, threads, 8); run<3, 2>(d, c, threads, 8);
+        run<2, 3>(d, c, threads, 8); run<0, 3>(d, c, threads, 8); run<3, 3>(d, c, threads, 8);
+        run<2, 4>(d, c, threads, 8); run<0, 4>(d, c, threads, 8); run<1, 4>(d, c, threads, 8); run<3, 4>(d, c, threads, 8);
+        run<0, 2>(d, c, threads, 3); run<3, 2>(d, c, threads, 3); run<0, 2>(d, c, threads, 5); run<3, 2>(d, c, threads, 5);
     }
     return 0;
 }

@@ -560,10 +560,14 @@ __global__ void __launch_bounds__(wgk::WG, 1) ftmpc_solve_wg32_kernel(const Devi
                 refined = true;
                 STAMP(7);
             } else if (it == 0) {
-                // gradient at the start point: g + H d (every tile once: -H' in register order serves both triangles)
+                // gradient at the start point: g + H d (every tile once: -H' in register order serves both triangles).
+                // Each wave sums its tiles into its own copy of the vector (the factor area is idle here) and the four
+                // copies are added in a fixed order: the result does not depend on how the waves interleave.
+                float* const yw = Tl + wave * NPAD;
                 if (tid < npad) {
                     dnat[tid] = dcur;
-                    yv[tid] = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NWAVE; ++w) Tl[w * NPAD + tid] = 0.f;
                 }
                 __syncthreads();
                 for (int t = wave; t < ntl; t += NWAVE) {
@@ -574,20 +578,25 @@ __global__ void __launch_bounds__(wgk::WG, 1) ftmpc_solve_wg32_kernel(const Devi
                     const f32x4 t4 = ldh(t);      // lane (q, col): -H[16I + col][16J + 4q + r]
                     const f32x4 d4 = lds4(dnat + 16 * J + 4 * lq);
                     const float rowp = quad_sum(t4.x * d4.x + t4.y * d4.y + t4.z * d4.z + t4.w * d4.w);
-                    if (lq == 0) atomicAdd(&yv[16 * I + li], -rowp);
+                    if (lq == 0) yw[16 * I + li] -= rowp;
                     if (I != J) {
                         const float dI = dnat[16 * I + li];
                         float c0 = t4.x * dI, c1 = t4.y * dI, c2 = t4.z * dI, c3 = t4.w * dI;
                         row_sum16x4(c0, c1, c2, c3);
+                        wave_lds_fence();
                         if (li == 0) {
-                            atomicAdd(&yv[16 * J + 4 * lq + 0], -c0);
-                            atomicAdd(&yv[16 * J + 4 * lq + 1], -c1);
-                            atomicAdd(&yv[16 * J + 4 * lq + 2], -c2);
-                            atomicAdd(&yv[16 * J + 4 * lq + 3], -c3);
+                            f32x4 y4 = lds4(yw + 16 * J + 4 * lq);
+                            y4.x -= c0;
+                            y4.y -= c1;
+                            y4.z -= c2;
+                            y4.w -= c3;
+                            *reinterpret_cast<f32x4*>(yw + 16 * J + 4 * lq) = y4;
                         }
                     }
+                    wave_lds_fence();
                 }
                 __syncthreads();
+                if (tid < npad) yv[tid] = (Tl[tid] + Tl[NPAD + tid]) + (Tl[2 * NPAD + tid] + Tl[3 * NPAD + tid]);
                 grad = valid ? yv[tid] + gv : 0.f;
                 STAMP(3);
             }

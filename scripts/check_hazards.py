@@ -22,6 +22,7 @@ Rule table (gfx940/gfx950; names of the LLVM GCNHazardRecognizer checks they res
   mfma_use        MFMA writes D -> VALU read/write, LDS / VMEM read of D            f32 16x16x4: 10, 32x32x2: 18, 4x4x1: 4
                                                                                     f64 16x16x4: 11 (memory read 18), 4x4x4: 6 (9)
                                                                                     checkMAIVALUHazards (SMFMA N-pass: N+2; DMFMA)
+  mfma_srcab      MFMA writes D -> another MFMA reads it as its A or B operand      as mfma_use (checkMAIHazards90A, SrcA/B overlap)
   valu_mfma       VALU writes VGPR -> MFMA reads it as A/B/C                        2   (reported for asm producers only)
 A wait state is one issued instruction; `s_nop N` is N+1.
 
@@ -95,7 +96,7 @@ def split_ops(s):
 
 
 class Inst:
-    __slots__ = ("mn", "ops", "line", "in_asm", "wr", "rd", "ws", "kind", "dpp", "lanesel", "text")
+    __slots__ = ("mn", "ops", "line", "in_asm", "wr", "rd", "ws", "kind", "dpp", "lanesel", "text", "ab")
 
     def __init__(self, text, line, in_asm):
         self.text, self.line, self.in_asm = text, line, in_asm
@@ -153,6 +154,7 @@ class Inst:
             for i, r in enumerate(opregs):
                 (wr if (i == 0 and is_load) else rd).extend(r)
         self.wr, self.rd = set(wr), set(rd)
+        self.ab = set(opregs[1] + opregs[2]) if self.kind == "mfma" and len(opregs) >= 3 else set()
 
 
 def parse(path):
@@ -261,7 +263,7 @@ def check_consumer(items, preds, i, found):
         rules.append(("sgpr_vmem", 5, lambda p: p.kind == "valu", srd))
     touched = (c.rd | c.wr) if c.kind == "valu" else c.rd
     vt = {r for r in touched if r[0] in "va"}
-    budget = max([r[1] for r in rules] + [MAXW if vt else 0])
+    budget = max([r[1] for r in rules] + [MAXW if (vt or c.kind == "mfma") else 0])
     if budget == 0:
         return
     for p, dist in walk_back(items, preds, i, budget):
@@ -270,6 +272,14 @@ def check_consumer(items, preds, i, found):
                 hit = p.wr & regs
                 if hit:
                     report(name, need, p, c, dist, sorted(hit)[0])
+        if p.kind == "mfma" and c.kind == "mfma" and c.ab:
+            # an MFMA result read as the A or B operand of another MFMA (srcC of the same shape is forwarded by the hardware)
+            for pre, (wv, wm) in MFMA_WAIT.items():
+                if p.mn.startswith(pre):
+                    hit = p.wr & c.ab
+                    if hit and dist < wv:
+                        report("mfma_srcab", wv, p, c, dist, sorted(hit)[0])
+                    break
         if p.kind == "mfma" and vt and c.kind != "mfma":
             for pre, (wv, wm) in MFMA_WAIT.items():
                 if p.mn.startswith(pre):

@@ -135,6 +135,21 @@ def test_wg_kernel_u0_against_the_c_oracle(gpu_mpc_factory, N, nfault, B):
     assert (out["u0"][ub == 0] == 0).all() and out["iters"].max() <= 30
 
 
+@pytest.mark.parametrize("N,NT,dtype", [(15, 16, "f32"), (15, 16, "f64"), (20, 8, "f32")])
+def test_results_are_bitwise_repeatable(gpu_mpc_factory, N, NT, dtype):
+    """The same batch twice on one handle and once on a fresh one: identical bits.  (Kernel 7's start gradient once summed
+    its tiles with LDS float atomics from four waves: right to 1e-6, different on every run.)"""
+    B = 1024
+    x0, ub, stuck, xref = qo.make_batch(B, N, NT, 2, 3600 + N)
+    xr = xref.reshape(-1, order="F")
+    mpc = gpu_mpc_factory(N=N, NT=NT, dtype=dtype)
+    a = mpc.solve(x0, ub, stuck, xr, return_U=True)
+    b = mpc.solve(x0, ub, stuck, xr, return_U=True)
+    c = gpu_mpc_factory(N=N, NT=NT, dtype=dtype).solve(x0, ub, stuck, xr, return_U=True)
+    for k in ("u0", "U", "status", "iters"):
+        assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]), k
+
+
 def test_wg_kernel_whole_batch_mixed_fault_counts_warm_start_and_uref(gpu_mpc_factory):
     """4096 instances (16 per workgroup), fault counts 0..10 mixed in one batch (routed between the one-wave kernels
     NB = 8 / 9 / 10 and the workgroup kernel), then a warm-started step with a circle reference window."""

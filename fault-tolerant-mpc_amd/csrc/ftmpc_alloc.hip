@@ -206,6 +206,67 @@ __global__ void __launch_bounds__(64) ftmpc_allocate_kernel(const DeviceConsts C
         for (int g = 0; g < 6; ++g) fmaxabs = fmax(fmaxabs, fabs(F[g]));
         status = (fmaxabs <= tol) ? 0 : (it >= P.max_iters ? 1 : 2);
     }
+    if (status != 0) {
+        // A tau on the boundary of the attainable set (an MPC solution with active hull rows: several thrusters exactly at a
+        // bound) leaves the dual flat and the Newton iteration stalls a few 1e-7 short.  Polish: thrusters within 1e-6 f_max
+        // of a bound are put ON it, the rest take the least-norm share of what is left; accepted if the residual passes.
+        double ubmax = 0.0;
+#pragma unroll
+        for (int i = 0; i < MAX_NT; ++i) ubmax = fmax(ubmax, ubv[i]);
+        const double band = 1e-6 * ubmax;
+        double up[MAX_NT], r[6], J[6][6], lf[6];
+        bool fr[MAX_NT];
+#pragma unroll
+        for (int g = 0; g < 6; ++g) r[g] = tau[g];
+#pragma unroll
+        for (int r6 = 0; r6 < 6; ++r6)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) J[r6][c] = 0.0;
+        bool any_free = false;
+#pragma unroll
+        for (int i = 0; i < MAX_NT; ++i) {
+            const bool healthy = i < NT && ubv[i] > 0.0;
+            const bool lo = healthy && u[i] <= band, hi = healthy && u[i] >= ubv[i] - band;
+            fr[i] = healthy && !lo && !hi;
+            up[i] = hi ? ubv[i] : 0.0;
+            any_free = any_free || fr[i];
+            if (hi) {
+#pragma unroll
+                for (int g = 0; g < 6; ++g) r[g] -= C.D[g * MAX_NT + i] * ubv[i];
+            }
+            if (fr[i]) {
+#pragma unroll
+                for (int r6 = 0; r6 < 6; ++r6)
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) J[r6][c] += C.D[r6 * MAX_NT + i] * C.D[c * MAX_NT + i];
+            }
+        }
+        if (any_free) {
+            solve6(J, r, lf);
+#pragma unroll
+            for (int i = 0; i < MAX_NT; ++i)
+                if (fr[i]) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int g = 0; g < 6; ++g) v += C.D[g * MAX_NT + i] * lf[g];
+                    up[i] = fmin(fmax(v, 0.0), ubv[i]);
+                }
+        }
+        double res = 0.0;
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            double t = -tau[g];
+#pragma unroll
+            for (int i = 0; i < MAX_NT; ++i)
+                if (i < NT) t += C.D[g * MAX_NT + i] * up[i];
+            res = fmax(res, fabs(t));
+        }
+        if (res <= tol) {
+#pragma unroll
+            for (int i = 0; i < MAX_NT; ++i) u[i] = up[i];
+            status = 0;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MAX_NT; ++i)
         if (i < NT) P.out_u[b * NT + i] = u[i];

@@ -168,6 +168,9 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4 && MODE == 0) ? 2 :
     __shared__ int s_act[MAX_NT];
     __shared__ int s_flag;
     __shared__ double s_ctr[12];     // GEN: hull centre | D stuck
+    // finished tiles of the current block row J (K < J), one conflict-free 32-byte slice per lane: every tile of column J
+    // multiplies against them, so they are fetched from L2 once per column instead of once per tile
+    __shared__ __attribute__((aligned(32))) double Pj[(16 * NVT - 1) * 256];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -469,11 +472,15 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4 && MODE == 0) ? 2 :
         if (tid == 0) s_flag = 1;
         for (int J = 0; J < nb; ++J) {
             __syncthreads();
+            for (int K = wave; K < J; K += NWAVE)
+                *reinterpret_cast<f64x4*>(Pj + K * 256 + 4 * lane) = ld4(Ls + (int64_t)t64idx(J, K) * 256 + 16 * li + 4 * lq);
+            __syncthreads();
             // wave 0 takes the diagonal tile and its potrf + inverse (the serial part of the column); the first six
             // off-diagonal tiles go round-robin over waves 1..3 (about the time of the potrf), the rest over all four
-            for (int I = J; I < nb; ++I) {
-                if (col_owner(I - J) != wave) continue;
-                f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+            const double* rowJ = Pj + 4 * lane;
+            const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
+            auto tile_init = [&](int I) {
+                f64x4 acc = zero4;
                 if constexpr (TSET) {   // acc = sum L L' - ET_I' ET_J, so that c = H - acc carries + ET' ET
                     const double* ETs = Eall + (int64_t)(N + 1) * 9 * npad;
 #pragma unroll
@@ -484,63 +491,9 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4 && MODE == 0) ? 2 :
                         acc = mfma(ea, eb, acc);
                     }
                 }
-                const double* rowI = Ls + (int64_t)t64idx(I, 0) * 256 + 16 * li + 4 * lq;
-                const double* rowJ = Ls + (int64_t)t64idx(J, 0) * 256 + 16 * li + 4 * lq;
-                int K = 0;
-                // the tiles come from L2 (~800 cycles): four tile pairs in flight, two accumulators
-                f64x4 acc2 = {0.0, 0.0, 0.0, 0.0};
-                if (I == J) {   // diagonal tile: both operands are the same row, load it once
-                    for (; K + 3 < J; K += 4) {
-                        const f64x4 a0 = ld4(rowI + K * 256), a1 = ld4(rowI + (K + 1) * 256);
-                        const f64x4 a2 = ld4(rowI + (K + 2) * 256), a3 = ld4(rowI + (K + 3) * 256);
-                        acc = mfma(a0.x, a0.x, acc); acc2 = mfma(a1.x, a1.x, acc2);
-                        acc = mfma(a0.y, a0.y, acc); acc2 = mfma(a1.y, a1.y, acc2);
-                        acc = mfma(a0.z, a0.z, acc); acc2 = mfma(a1.z, a1.z, acc2);
-                        acc = mfma(a0.w, a0.w, acc); acc2 = mfma(a1.w, a1.w, acc2);
-                        acc = mfma(a2.x, a2.x, acc); acc2 = mfma(a3.x, a3.x, acc2);
-                        acc = mfma(a2.y, a2.y, acc); acc2 = mfma(a3.y, a3.y, acc2);
-                        acc = mfma(a2.z, a2.z, acc); acc2 = mfma(a3.z, a3.z, acc2);
-                        acc = mfma(a2.w, a2.w, acc); acc2 = mfma(a3.w, a3.w, acc2);
-                    }
-                    for (; K < J; ++K) {
-                        const f64x4 a0 = ld4(rowI + K * 256);
-                        acc = mfma(a0.x, a0.x, acc); acc = mfma(a0.y, a0.y, acc);
-                        acc = mfma(a0.z, a0.z, acc); acc = mfma(a0.w, a0.w, acc);
-                    }
-                }
-                for (; K + 3 < J; K += 4) {
-                    const f64x4 a0 = ld4(rowI + K * 256), b0 = ld4(rowJ + K * 256);
-                    const f64x4 a1 = ld4(rowI + (K + 1) * 256), b1 = ld4(rowJ + (K + 1) * 256);
-                    const f64x4 a2 = ld4(rowI + (K + 2) * 256), b2 = ld4(rowJ + (K + 2) * 256);
-                    const f64x4 a3 = ld4(rowI + (K + 3) * 256), b3 = ld4(rowJ + (K + 3) * 256);
-                    acc = mfma(a0.x, b0.x, acc); acc2 = mfma(a1.x, b1.x, acc2);
-                    acc = mfma(a0.y, b0.y, acc); acc2 = mfma(a1.y, b1.y, acc2);
-                    acc = mfma(a0.z, b0.z, acc); acc2 = mfma(a1.z, b1.z, acc2);
-                    acc = mfma(a0.w, b0.w, acc); acc2 = mfma(a1.w, b1.w, acc2);
-                    acc = mfma(a2.x, b2.x, acc); acc2 = mfma(a3.x, b3.x, acc2);
-                    acc = mfma(a2.y, b2.y, acc); acc2 = mfma(a3.y, b3.y, acc2);
-                    acc = mfma(a2.z, b2.z, acc); acc2 = mfma(a3.z, b3.z, acc2);
-                    acc = mfma(a2.w, b2.w, acc); acc2 = mfma(a3.w, b3.w, acc2);
-                }
-                acc += acc2;
-                for (; K + 1 < J; K += 2) {
-                    const f64x4 a0 = ld4(rowI + K * 256), b0 = ld4(rowJ + K * 256);
-                    const f64x4 a1 = ld4(rowI + (K + 1) * 256), b1 = ld4(rowJ + (K + 1) * 256);
-                    acc = mfma(a0.x, b0.x, acc); acc = mfma(a0.y, b0.y, acc);
-                    acc = mfma(a0.z, b0.z, acc); acc = mfma(a0.w, b0.w, acc);
-                    acc = mfma(a1.x, b1.x, acc); acc = mfma(a1.y, b1.y, acc);
-                    acc = mfma(a1.z, b1.z, acc); acc = mfma(a1.w, b1.w, acc);
-                }
-                for (; K < J; ++K) {
-                    const f64x4 a0 = ld4(rowI + K * 256), b0 = ld4(rowJ + K * 256);
-                    acc = mfma(a0.x, b0.x, acc); acc = mfma(a0.y, b0.y, acc);
-                    acc = mfma(a0.z, b0.z, acc); acc = mfma(a0.w, b0.w, acc);
-                }
-                double* tij = Ls + (int64_t)t64idx(I, J) * 256;
-                const double* hij = Hs + (int64_t)t64idx(I, J) * 256;
-                double c[4];
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) c[rr] = hij[t64off(lq + 4 * rr, li)] - acc[rr];
+                return acc;
+            };
+            auto hull_blocks = [&](int I, double (&c)[4]) {
                 if constexpr (GEN) {   // hull rows: same-stage pairs get their 6x6 block of A' W A (stages straddle tile borders)
                     if (I - J <= 1) {
                         const int e2 = 16 * J + li;
@@ -553,41 +506,163 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4 && MODE == 0) ? 2 :
                         }
                     }
                 }
-                if (I == J) {   // wave 0 only (I = J + wave)
-                    const double sg = dv[16 * J + li];
+            };
+            if (wave == 0) {   // diagonal tile: both operands are row J (LDS), then potrf + inverse
+                f64x4 acc = tile_init(J), acc2 = zero4;
+                int K = 0;
+                for (; K + 1 < J; K += 2) {
+                    const f64x4 a0 = ld4(rowJ + K * 256), a1 = ld4(rowJ + (K + 1) * 256);
+                    acc = mfma(a0.x, a0.x, acc); acc2 = mfma(a1.x, a1.x, acc2);
+                    acc = mfma(a0.y, a0.y, acc); acc2 = mfma(a1.y, a1.y, acc2);
+                    acc = mfma(a0.z, a0.z, acc); acc2 = mfma(a1.z, a1.z, acc2);
+                    acc = mfma(a0.w, a0.w, acc); acc2 = mfma(a1.w, a1.w, acc2);
+                }
+                for (; K < J; ++K) {
+                    const f64x4 a0 = ld4(rowJ + K * 256);
+                    acc = mfma(a0.x, a0.x, acc); acc = mfma(a0.y, a0.y, acc);
+                    acc = mfma(a0.z, a0.z, acc); acc = mfma(a0.w, a0.w, acc);
+                }
+                acc += acc2;
+                double* tjj = Ls + (int64_t)t64idx(J, J) * 256;
+                const double* hjj = Hs + (int64_t)t64idx(J, J) * 256;
+                double c[4];
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        if (lq + 4 * rr == li) c[rr] += sg;
-                        Sbuf[(lq + 4 * rr) * 17 + li] = c[rr];
+                for (int rr = 0; rr < 4; ++rr) c[rr] = hjj[t64off(lq + 4 * rr, li)] - acc[rr];
+                hull_blocks(J, c);
+                const double sg = dv[16 * J + li];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    if (lq + 4 * rr == li) c[rr] += sg;
+                    Sbuf[(lq + 4 * rr) * 17 + li] = c[rr];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                double w[16];
+                const bool ok = potrf_inv16_f64(Sbuf, li, w);
+                if (!ok && lane == 0) s_flag = 0;
+                if (lq == 0) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) tjj[t64off(i, li)] = w[i];
+                }
+            }
+            // off-diagonal tiles of this wave as ONE stream of (tile, batch of four block columns): the loads of the next
+            // step -- the same tile's next batch or the next tile's first -- are requested before the MFMAs of the current
+            // one (two register sets, no copies; a batch beyond J is zero-filled), the Hessian tile at the tile's first step.
+            auto next_tile = [&](int I) {
+                do ++I; while (I < nb && col_owner(I - J) != wave);
+                return I;
+            };
+            auto store_c = [&](int I, const f64x4& acc, const double (&h)[4]) {
+                double* tij = Ls + (int64_t)t64idx(I, J) * 256;
+                double c[4];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) c[rr] = h[rr] - acc[rr];
+                hull_blocks(I, c);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) tij[t64off(lq + 4 * rr, li)] = c[rr];
+            };
+            auto load_h = [&](int I, double (&h)[4]) {
+                const double* hij = Hs + (int64_t)t64idx(I, J) * 256;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) h[rr] = hij[t64off(lq + 4 * rr, li)];
+            };
+            {
+                const int nq = (J + 3) >> 2;
+                int I = next_tile(J), q = 0;
+                f64x4 A0[4], A1[4], acc = zero4, acc2 = zero4;
+                double hreg[4] = {0.0, 0.0, 0.0, 0.0};
+                auto fetch = [&](f64x4 (&A)[4], int It, int qq) {
+                    const double* rowI = Ls + (int64_t)t64idx(It, 0) * 256 + 16 * li + 4 * lq;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int K = 4 * qq + i;
+                        A[i] = zero4;
+                        if (K < J) A[i] = ld4(rowI + K * 256);
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    double w[16];
-                    const bool ok = potrf_inv16_f64(Sbuf, li, w);
-                    if (!ok && lane == 0) s_flag = 0;
-                    if (lq == 0) {
+                };
+                auto batch = [&](const f64x4 (&A)[4], int qq) {
+                    f64x4 b[4];
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) tij[t64off(i, li)] = w[i];
+                    for (int i = 0; i < 4; ++i) {
+                        const int K = 4 * qq + i;
+                        b[i] = zero4;
+                        if (K < J) b[i] = ld4(rowJ + K * 256);
                     }
-                } else {
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) tij[t64off(lq + 4 * rr, li)] = c[rr];
+                    acc = mfma(A[0].x, b[0].x, acc); acc2 = mfma(A[1].x, b[1].x, acc2);
+                    acc = mfma(A[0].y, b[0].y, acc); acc2 = mfma(A[1].y, b[1].y, acc2);
+                    acc = mfma(A[0].z, b[0].z, acc); acc2 = mfma(A[1].z, b[1].z, acc2);
+                    acc = mfma(A[0].w, b[0].w, acc); acc2 = mfma(A[1].w, b[1].w, acc2);
+                    acc = mfma(A[2].x, b[2].x, acc); acc2 = mfma(A[3].x, b[3].x, acc2);
+                    acc = mfma(A[2].y, b[2].y, acc); acc2 = mfma(A[3].y, b[3].y, acc2);
+                    acc = mfma(A[2].z, b[2].z, acc); acc2 = mfma(A[3].z, b[3].z, acc2);
+                    acc = mfma(A[2].w, b[2].w, acc); acc2 = mfma(A[3].w, b[3].w, acc2);
+                };
+                auto step = [&](const f64x4 (&Ac)[4], f64x4 (&An)[4]) -> bool {
+                    if (q == 0) {
+                        acc = tile_init(I);
+                        acc2 = zero4;
+                        load_h(I, hreg);
+                    }
+                    int In = I, qn = q + 1;
+                    if (qn >= nq) {
+                        In = next_tile(I);
+                        qn = 0;
+                    }
+                    if (In < nb) fetch(An, In, qn);
+                    batch(Ac, q);
+                    if (qn == 0) {
+                        acc += acc2;
+                        store_c(I, acc, hreg);
+                    }
+                    I = In;
+                    q = qn;
+                    return I >= nb;
+                };
+                if (nq == 0) {   // first column: nothing to subtract
+                    for (; I < nb; I = next_tile(I)) {
+                        load_h(I, hreg);
+                        store_c(I, tile_init(I), hreg);
+                    }
+                } else if (I < nb) {
+                    fetch(A0, I, 0);
+                    for (;;) {
+                        if (step(A0, A1)) break;
+                        if (step(A1, A0)) break;
+                    }
                 }
             }
             __syncthreads();
+            // L_IJ = C_IJ W_J' for the tiles this wave produced, four at a time (C_IJ comes back from L2 in operand order)
             const f64x4 w4 = ld4(Ls + (int64_t)t64idx(J, J) * 256 + 16 * li + 4 * lq);
-            for (int I = J + 1; I < nb; ++I) {   // same wave that produced C_IJ
-                if (col_owner(I - J) != wave) continue;
-                double* tij = Ls + (int64_t)t64idx(I, J) * 256;
-                const f64x4 a4 = ld4(tij + 16 * li + 4 * lq);
-                f64x4 x = {0.0, 0.0, 0.0, 0.0};
-                x = mfma(a4.x, w4.x, x); x = mfma(a4.y, w4.y, x);
-                x = mfma(a4.z, w4.z, x); x = mfma(a4.w, w4.w, x);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();   // the whole wave has read C_IJ before it is overwritten
+            for (int I = next_tile(J); I < nb;) {
+                int Is[4] = {nb, nb, nb, nb};
+                f64x4 a4[4], x[4];
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) tij[t64off(lq + 4 * rr, li)] = x[rr];
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    a4[c4] = zero4;
+                    if (I < nb) {
+                        Is[c4] = I;
+                        a4[c4] = ld4(Ls + (int64_t)t64idx(I, J) * 256 + 16 * li + 4 * lq);
+                        I = next_tile(I);
+                    }
+                }
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    x[c4] = zero4;
+                    x[c4] = mfma(a4[c4].x, w4.x, x[c4]); x[c4] = mfma(a4[c4].y, w4.y, x[c4]);
+                    x[c4] = mfma(a4[c4].z, w4.z, x[c4]); x[c4] = mfma(a4[c4].w, w4.w, x[c4]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();   // the whole wave has read its C_IJ before they are overwritten
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    if (Is[c4] < nb) {
+                        double* tij = Ls + (int64_t)t64idx(Is[c4], J) * 256;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) tij[t64off(lq + 4 * rr, li)] = x[c4][rr];
+                    }
+                }
             }
         }
         };

@@ -169,9 +169,13 @@ __global__ void __launch_bounds__(wgk::WG, 1) ftmpc_solve_wg32_kernel(const Devi
 
     // the allocation matrix goes to LDS through CONSTANT indices: one dynamically indexed access to the by-value
     // argument block would move the whole block (2.5 KiB per lane) to scratch and turn every later C.x into a scratch load
+    // (as a chain of selects: `if (tid == i) s_D[i] = ...` became a 60 000-instruction decision tree on tid, run once per launch)
+    {
+        double dsel = 0.0;
 #pragma unroll
-    for (int i = 0; i < 6 * MAX_NT; ++i)
-        if (tid == i) s_D[i] = (float)C.D[i];
+        for (int i = 0; i < 6 * MAX_NT; ++i) dsel = (tid == i) ? C.D[i] : dsel;
+        if (tid < 6 * MAX_NT) s_D[tid] = (float)dsel;
+    }
     const float dtf = (float)C.dt;
     const int qn = *P.qcount;
     for (;;) {

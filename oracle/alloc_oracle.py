@@ -55,6 +55,22 @@ def allocate(D, tau, ub, max_iters=50, tol=1e-8, return_lambda=False):
         it = max_iters
     if status == 1:
         status = 0 if np.abs(F).max() <= thr else (1 if it >= max_iters else 2)
+    if status != 0:
+        # A tau on the boundary of the attainable set (an MPC solution with active hull rows: several thrusters exactly at a
+        # bound) leaves the dual flat and the Newton iteration stalls a few 1e-7 short.  Polish: thrusters within 1e-6 f_max
+        # of a bound are put ON it, the rest take the least-norm share of what is left; accepted if the residual passes.
+        band = 1e-6 * ub.max()
+        lo = healthy & (u <= band)
+        hi = healthy & (u >= ub - band)
+        free = healthy & ~lo & ~hi
+        up = np.where(hi, ub, 0.0)
+        r = tau - D @ up
+        if free.any():
+            Jf = D[:, free] @ D[:, free].T
+            lf = np.linalg.solve(Jf + (1e-12 * np.trace(Jf) + 1e-300) * np.eye(6), r)
+            up[free] = np.clip(D[:, free].T @ lf, 0.0, ub[free])
+        if np.abs(D @ up - tau).max() <= thr:
+            u, status = up, 0
     return (u, status, it, lam) if return_lambda else (u, status, it)
 
 

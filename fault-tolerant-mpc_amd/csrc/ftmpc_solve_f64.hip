@@ -475,6 +475,7 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4 && MODE == 0) ? 2 :
             for (int K = wave; K < J; K += NWAVE)
                 *reinterpret_cast<f64x4*>(Pj + K * 256 + 4 * lane) = ld4(Ls + (int64_t)t64idx(J, K) * 256 + 16 * li + 4 * lq);
             __syncthreads();
+            S64(3);    // (diagnostic) barrier + row staging
             // wave 0 takes the diagonal tile and its potrf + inverse (the serial part of the column); the first six
             // off-diagonal tiles go round-robin over waves 1..3 (about the time of the potrf), the rest over all four
             const double* rowJ = Pj + 4 * lane;
@@ -546,6 +547,7 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4 && MODE == 0) ? 2 :
                     for (int i = 0; i < 16; ++i) tjj[t64off(i, li)] = w[i];
                 }
             }
+            S64(8);    // (diagnostic) wave 0: diagonal tile + potrf
             // off-diagonal tiles of this wave as ONE stream of (tile, batch of four block columns): the loads of the next
             // step -- the same tile's next batch or the next tile's first -- are requested before the MFMAs of the current
             // one (two register sets, no copies; a batch beyond J is zero-filled), the Hessian tile at the tile's first step.
@@ -632,7 +634,9 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4 && MODE == 0) ? 2 :
                     }
                 }
             }
+            S64(10);   // (diagnostic) wave 0: its off-diagonal stream
             __syncthreads();
+            S64(11);   // (diagnostic) wave 0: waiting for the other waves
             // L_IJ = C_IJ W_J' for the tiles this wave produced, four at a time (C_IJ comes back from L2 in operand order)
             const f64x4 w4 = ld4(Ls + (int64_t)t64idx(J, J) * 256 + 16 * li + 4 * lq);
             for (int I = next_tile(J); I < nb;) {

@@ -16,8 +16,8 @@ cnt=min(B,512)
 buf=np.zeros((cnt,12),np.uint64)
 f=mpc.lib.ftmpc_debug_read_stamps; f.argtypes=[C.c_void_p,C.c_int64,C.c_void_p]
 assert f(mpc._h,cnt,buf.ctypes.data_as(C.c_void_p))==0
-names=["prologue","phase1: E panels","phase2: H tiles","x3","gradient+mu","chol","solves(2)","elementwise","x8","output","x10","x11"]
+names=["prologue","phase1: E panels","phase2: H tiles","chol: barrier + row staging","gradient+mu","chol: W phase","solves(2)","elementwise","chol: diagonal tile + potrf (wave 0)","output","chol: off-diagonal stream (wave 0)","chol: wait for the other waves (wave 0)"]
 m=buf.astype(np.float64).mean(axis=0); tot=m.sum(); it=out['iters'].mean()
 print("N=%d NT=%d B=%d iters mean %.2f   total ticks/QP %.0f"%(N,NT,B,it,tot))
 for n_,v in zip(names,m):
-    if n_: print("  %-18s %10.0f  %5.1f%%   per-iter %8.0f"%(n_,v,100*v/tot,v/it))
+    if n_: print("  %-44s %10.0f  %5.1f%%   per-iter %8.0f"%(n_,v,100*v/tot,v/it))

@@ -72,6 +72,7 @@ struct ftmpc_handle {
     hipStream_t s_in = nullptr, s_out = nullptr;
     static constexpr int MAX_CHUNKS = 8;
     hipEvent_t ev_in[MAX_CHUNKS] = {}, ev_k[MAX_CHUNKS] = {}, ev_out[MAX_CHUNKS] = {};
+    int64_t lin_split_max = 8192;   // FTMPC_LIN_SPLIT_MAX overrides (0: never split)
     int stage_chunks = 0;   // 0: whole blocks of 65 536 instances (a persistent launch below that does not fill the device twice)
     // fp32 workgroup-per-instance kernel with the factor in LDS (160 < N*NT <= 240)
     bool use_wg = false;
@@ -213,6 +214,19 @@ int grow(ftmpc_handle* h, T** p, int64_t count) {
 
 int tiles_of(int nb) { return nb * (nb + 1) / 2; }
 // per-workgroup global slot of the fp32 kernels (layout: ftmpc_common.h): sweep scratch, then the Hessian tiles
+// Linearisation: full records per wave for large batches; below `lin_split_max` instances the direction-split grid
+// (13 blocks per 64 instances, ftmpc_linearize.hip), which fills the device from a few hundred instances on.
+void launch_linearize(ftmpc_handle* h, int64_t B, int blocks, hipStream_t s, const ftmpc::LinParams& lp) {
+    // shares of the 13 directions per 64 instances: as many as keep about one wave per SIMD (1024 on the device)
+    const int shares = B <= h->lin_split_max ? 13 : (B <= 2 * h->lin_split_max ? 4 : (B <= 5 * h->lin_split_max ? 2 : 1));
+    if (shares == 13)
+        hipLaunchKernelGGL((ftmpc::ftmpc_linearize_kernel<double, 1>), dim3(blocks, 13), dim3(64), 0, s, h->dc, lp);
+    else if (shares > 1)
+        hipLaunchKernelGGL((ftmpc::ftmpc_linearize_kernel<double, 2>), dim3(blocks, shares), dim3(64), 0, s, h->dc, lp);
+    else
+        hipLaunchKernelGGL((ftmpc::ftmpc_linearize_kernel<double, 0>), dim3(blocks), dim3(64), 0, s, h->dc, lp);
+}
+
 int64_t slot_words(int nb, int N) { return ftmpc::slot_tile_off_words(N) + (int64_t)tiles_of(nb) * 256; }
 
 int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, const double* stuck,
@@ -238,7 +252,7 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
     const int lin_blocks = (int)((B + 63) / 64);
     for (bool& u : h->ev_used) u = false;
     if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[0], s));
-    hipLaunchKernelGGL(ftmpc::ftmpc_linearize_kernel<double>, dim3(lin_blocks), dim3(64), 0, s, h->dc, lp);
+    launch_linearize(h, B, lin_blocks, s, lp);
     HIP_TRY(h, hipGetLastError());
     if (h->profiling) {
         HIP_TRY(h, hipEventRecord(h->ev[1], s));
@@ -463,6 +477,7 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
         ftmpc_destroy(h);
         return FTMPC_ERR_HIP;
     }
+    if (const char* e = std::getenv("FTMPC_LIN_SPLIT_MAX")) h->lin_split_max = std::atoll(e);
     if (const char* e = std::getenv("FTMPC_STAGE_CHUNKS")) {
         const int c = std::atoi(e);
         if (c >= 1 && c <= ftmpc_handle::MAX_CHUNKS) h->stage_chunks = c;
@@ -852,7 +867,7 @@ int ftmpc_solve_wrench_batch(ftmpc_handle* h, int64_t B, const double* x0, const
     lp.warmG = warmG ? h->d_warmG : nullptr;
     lp.out_eN = h->d_eN;
     lp.tcost = h->d_tcost;
-    hipLaunchKernelGGL(ftmpc::ftmpc_linearize_kernel<double>, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, h->dc, lp);
+    launch_linearize(h, B, (int)((B + 63) / 64), s, lp);
     HIP_TRY(h, hipGetLastError());
     Solve64Params q;
     std::memset(&q, 0, sizeof(q));

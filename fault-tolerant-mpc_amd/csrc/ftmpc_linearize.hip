@@ -127,27 +127,45 @@ __device__ inline void stage_eval(const DeviceConsts& C, const double w[3], cons
 
 constexpr int STG_WORDS = (REC_BPF > REC_STRIDE - REC_BPF) ? REC_BPF : REC_STRIDE - REC_BPF;   // 79: 40 448 B of LDS per wave
 
-template <typename OutT>
+// DIRS = false: the whole record of 64 instances per wave (full batches).  DIRS = true: blockIdx.y picks a contiguous
+// share of the 13 tangent directions (gridDim.y = 13, 4 or 2 shares; y = 0 also writes the words that are not tangents,
+// the work lists and e_N); every block repeats the cheap nonlinear rollout and stage blocks, so a small batch spreads
+// over more waves and each wave does a fraction of the work -- same arithmetic per direction, same record bits
+// (tests/test_gpu_parity.py).  The host takes it where the full-record kernel would leave most of the device idle.
+template <typename OutT, int SHARE>   // 0: full records; 1: one direction per block; 2: gridDim.y shares of the 13 directions
 __global__ void __launch_bounds__(64) ftmpc_linearize_kernel(const DeviceConsts C, const LinParams P) {
     static_assert(sizeof(OutT) == 8, "records are float64");
-    __shared__ double stg[STG_WORDS * 64];
+    constexpr bool DIRS = SHARE != 0;
+    __shared__ double stg[DIRS ? 1 : STG_WORDS * 64];
     const int lane = threadIdx.x;
     const int64_t b0 = (int64_t)blockIdx.x * 64;
     // lanes past the end of the batch redo the last instance (they take part in the cooperative stores)
     const int64_t b = (b0 + lane < P.B) ? b0 + lane : P.B - 1;
     const int N = C.N, NT = C.NT;
     OutT* const recw = reinterpret_cast<OutT*>(P.rec);
+    const int jlo = SHARE == 0 ? 0 : (SHARE == 1 ? (int)blockIdx.y : 13 * (int)blockIdx.y / (int)gridDim.y);
+    const int jhi = SHARE == 0 ? 13 : (SHARE == 1 ? jlo + 1 : 13 * ((int)blockIdx.y + 1) / (int)gridDim.y);
+    const bool writes_rest = !DIRS || blockIdx.y == 0;
+    int pk = 0, pbase = 0;     // DIRS: stage and half (0 / REC_BPF) the next put belongs to
     // stage one record word of this lane (word index relative to the current half)
-    auto put = [&](int wd, double v) { stg[wd * 64 + (lane ^ (wd & 63))] = v; };
+    auto put = [&](int wd, double v) {
+        if constexpr (DIRS) {
+            if (b0 + lane < P.B) recw[(b * N + pk) * (int64_t)REC_STRIDE + pbase + wd] = (OutT)v;
+        } else {
+            stg[wd * 64 + (lane ^ (wd & 63))] = v;
+        }
+    };
     // the wave writes words [base, base + W) of stage k for its 64 instances: contiguous W-word runs
     auto flush = [&](int k, int base, int W) {
-        __syncthreads();
-        for (int idx = lane; idx < 64 * W; idx += 64) {
-            const int inst = idx / W, wd = idx - inst * W;
-            const double v = stg[wd * 64 + (inst ^ (wd & 63))];
-            if (b0 + inst < P.B) recw[((b0 + inst) * N + k) * (int64_t)REC_STRIDE + base + wd] = (OutT)v;
+        if constexpr (!DIRS) {
+            __syncthreads();
+            for (int idx = lane; idx < 64 * W; idx += 64) {
+                const int inst = idx / W, wd = idx - inst * W;
+                const double v = stg[wd * 64 + (inst ^ (wd & 63))];
+                if (b0 + inst < P.B) recw[((b0 + inst) * N + k) * (int64_t)REC_STRIDE + base + wd] = (OutT)v;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     };
 
     // ---- robot -> orbit-centre state (spiral_model.py:91-109) ----
@@ -173,7 +191,7 @@ __global__ void __launch_bounds__(64) ftmpc_linearize_kernel(const DeviceConsts 
         stk[i] = P.stuck[b * NT + i];
     }
     // ---- work lists of the fp32 solve instantiations: one atomic per wave and list ----
-    if (P.qlist) {
+    if (P.qlist && writes_rest) {
         int na = 0;
         for (int i = 0; i < NT; ++i) na += (ubv[i] > 0.0) ? 1 : 0;
         const int nbk = (N * na + 15) >> 4;
@@ -240,7 +258,9 @@ __global__ void __launch_bounds__(64) ftmpc_linearize_kernel(const DeviceConsts 
         }
 
         // ---- tangents for the 13 input directions [w0(3), q0(4), F(3), tau(3)] ----
-        for (int j = 0; j < 13; ++j) {
+        pk = k;
+        for (int j = jlo; j < jhi; ++j) {
+            pbase = (j < 7) ? 0 : REC_BPF;
             double tw0[3] = {0, 0, 0}, tq0[4] = {0, 0, 0, 0}, tF[3] = {0, 0, 0}, tT[3] = {0, 0, 0};
             if (j < 3) tw0[j] = 1.0;
             else if (j < 7) tq0[j - 3] = 1.0;
@@ -302,7 +322,7 @@ __global__ void __launch_bounds__(64) ftmpc_linearize_kernel(const DeviceConsts 
                 }
                 for (int a = 0; a < 4; ++a) put(REC_BQT - REC_BPF + 3 * a + jj, c6 * sq[a]);
             }
-            if (j == 6) flush(k, 0, REC_BPF);   // the A blocks (words 0..78) are complete
+            if (!DIRS && j == 6) flush(k, 0, REC_BPF);   // the A blocks (words 0..78) are complete
         }
 
         // ---- advance the nonlinear rollout (no quaternion renormalisation, sys_model.py:152-158) ----
@@ -314,7 +334,8 @@ __global__ void __launch_bounds__(64) ftmpc_linearize_kernel(const DeviceConsts 
         for (int a = 0; a < 4; ++a) q[a] += dt / 6.0 * (kq[0][a] + 2 * kq[1][a] + 2 * kq[2][a] + kq[3][a]);
 
         // ---- weighted tracking error of stage k+1: W (c[0:9] - xref) ----
-        {
+        pbase = REC_BPF;
+        if (writes_rest) {
             double e[9];
             for (int a = 0; a < 3; ++a) {
                 e[a] = pos[a] - xref[9 * (k + 1) + a];
@@ -342,7 +363,9 @@ __global__ void __launch_bounds__(64) ftmpc_linearize_kernel(const DeviceConsts 
     }
 }
 
-template __global__ void ftmpc_linearize_kernel<double>(const DeviceConsts, const LinParams);
+template __global__ void ftmpc_linearize_kernel<double, 0>(const DeviceConsts, const LinParams);
+template __global__ void ftmpc_linearize_kernel<double, 1>(const DeviceConsts, const LinParams);
+template __global__ void ftmpc_linearize_kernel<double, 2>(const DeviceConsts, const LinParams);
 
 // ---------------------------------------------------------------------------------------------------------
 // Cost of the nonlinear program for given thruster sequences (merit function of the line-search SQP; include/ftmpc.h

@@ -150,6 +150,33 @@ def test_results_are_bitwise_repeatable(gpu_mpc_factory, N, NT, dtype):
         assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]), k
 
 
+@pytest.mark.parametrize("N,NT,dtype,B", [(20, 8, "f32", 700), (20, 8, "f32", 9000), (20, 8, "f32", 20000), (15, 16, "f32", 700),
+                                          (15, 16, "f64", 700)])
+def test_direction_split_linearisation_gives_the_same_bits(gpu_mpc_factory, monkeypatch, N, NT, dtype, B):
+    """Batches of <= 8192 instances are linearised by 13 blocks per 64 instances (one tangent direction each), up to 16 384
+    by 4 and up to 40 960 by 2 shares of the directions; the records, and with them every output bit, equal those of the
+    full-record kernel (forced here through FTMPC_LIN_SPLIT_MAX = 0).  So a batch split into shards gives the bits of
+    the unsplit call whichever kernel each piece takes."""
+    x0, ub, stuck, xref = qo.make_batch(B, N, NT, 2, 3700 + N)
+    xr = xref.reshape(-1, order="F")
+    traj = rm.circle_trajectory(0.1, 10, radius=0.65, s_per_circle=40.0)
+    xr_all, ur_all = rm.assign_trajectory(traj, N)
+    xw, uw = rm.trajectory_window(xr_all, ur_all, 1.0, N)
+    W = np.ascontiguousarray(np.random.default_rng(5).uniform(0, 1, (B, N, NT)) * ub[:, None, :])
+    split = gpu_mpc_factory(N=N, NT=NT, dtype=dtype)
+    monkeypatch.setenv("FTMPC_LIN_SPLIT_MAX", "0")
+    full = gpu_mpc_factory(N=N, NT=NT, dtype=dtype)
+    monkeypatch.delenv("FTMPC_LIN_SPLIT_MAX")
+    for warm in (False, True):
+        xx = xw.reshape(-1, order="F") if warm else xr
+        ka = dict(uref=uw.reshape(-1, order="F"), warmU=W.copy()) if warm else {}
+        kb = dict(uref=uw.reshape(-1, order="F"), warmU=W.copy()) if warm else {}
+        a = split.solve(x0, ub, stuck, xx, return_U=True, **ka)
+        b = full.solve(x0, ub, stuck, xx, return_U=True, **kb)
+        for k in ("u0", "U", "status", "iters"):
+            assert np.array_equal(a[k], b[k]), k
+
+
 def test_wg_kernel_whole_batch_mixed_fault_counts_warm_start_and_uref(gpu_mpc_factory):
     """4096 instances (16 per workgroup), fault counts 0..10 mixed in one batch (routed between the one-wave kernels
     NB = 8 / 9 / 10 and the workgroup kernel), then a warm-started step with a circle reference window."""

@@ -25,6 +25,7 @@
 #include "ftmpc_solve.hip"
 #include "ftmpc_solve_f64.hip"
 #include "ftmpc_solve_wg.hip"
+#include "ftmpc_solve_ws.hip"
 #include "ftmpc_sim.hip"
 #include "ftmpc_alloc.hip"
 
@@ -75,6 +76,10 @@ struct ftmpc_handle {
     int64_t lin_split_max = 8192;   // FTMPC_LIN_SPLIT_MAX overrides (0: never split)
     int stage_chunks = 0;   // 0: whole blocks of 65 536 instances (a persistent launch below that does not fill the device twice)
     // fp32 workgroup-per-instance kernel with the factor in LDS (160 < N*NT <= 240)
+    bool use_ws = false;            // kernel 8 (wrench-space Schur form) takes the lists of NB = 9, 10 and of the workgroup kernel
+    int ws_nb = 8, grid_ws = 0;
+    float* ws_slot = nullptr;
+    int64_t ws_slot_words = 0;
     bool use_wg = false;
     float* wg_slot = nullptr;
     int grid_wg = 0;
@@ -308,6 +313,27 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
     // fp32 instantiations NB = 8, 9, 10: each pulls the instances with ceil(n/16) <= NB (the first also the empty
     // ones, the last also shapes beyond every instantiation, which it reports) from the list the linearise kernel
     // wrote for it; a launch whose list is empty returns at once
+    auto launch_ws = [&](int v, int ev_slot) -> int {   // kernel 8 on work list v
+        SolveWgParams w;
+        w.base = sp;
+        w.base.hscratch = nullptr;
+        w.base.tile_words = 0;
+        w.base.qlist = h->d_qlist + (int64_t)v * B;
+        w.base.qcount = h->d_qctl + v;
+        w.base.qhead = h->d_qctl + 4 + v;
+        w.slot = h->ws_slot;
+        w.slot_words = h->ws_slot_words;
+        const int grid = (int)std::min<int64_t>(B, h->grid_ws);
+        if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[2 * ev_slot], s));
+        if (h->ws_nb == 6) hipLaunchKernelGGL(ftmpc::ftmpc_solve_ws32_kernel<6>, dim3(grid), dim3(ftmpc::wsk::WG), 0, s, h->dc, w);
+        else hipLaunchKernelGGL(ftmpc::ftmpc_solve_ws32_kernel<8>, dim3(grid), dim3(ftmpc::wsk::WG), 0, s, h->dc, w);
+        HIP_TRY(h, hipGetLastError());
+        if (h->profiling) {
+            HIP_TRY(h, hipEventRecord(h->ev[2 * ev_slot + 1], s));
+            h->ev_used[ev_slot] = true;
+        }
+        return FTMPC_OK;
+    };
     for (int v = 0; v < nvar; ++v) {
         const int NBv = 8 + v;
         sp.hscratch = h->hs[v];
@@ -326,7 +352,10 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
             h->ev_used[1 + v] = true;
         }
     }
-    if (h->use_wg) {
+    if (h->use_wg && h->use_ws) {
+        const int rc = launch_ws(3, 5);
+        if (rc != FTMPC_OK) return rc;
+    } else if (h->use_wg) {
         SolveWgParams w;
         w.base = sp;
         w.base.hscratch = nullptr;
@@ -442,6 +471,15 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
     // beyond that, and for dtype F64, the float64 workgroup kernel with its tiles in a global slot
     h->use_f64 = (cfg->dtype == FTMPC_DTYPE_F64) || h->nb_max > 15;
     h->use_wg = !h->use_f64 && h->nb_max > 10;
+    // kernel 8 (the thruster QP through wrench space) takes the workgroup kernel's list -- ceil(n / 16) >= 11 -- when one
+    // variable per thread covers N * NT and the wrench-space system fits eight tiles a side (FTMPC_WS=0: kernel 7 instead).
+    // The one-wave kernels keep n <= 160: a workgroup per instance does not compete with a wave per instance there.
+    {
+        const char* e = std::getenv("FTMPC_WS");
+        const bool want = e ? std::atoi(e) != 0 : true;
+        h->use_ws = want && h->use_wg && cfg->N * cfg->NT <= 256 && 6 * cfg->N <= 128;
+        h->ws_nb = (6 * cfg->N <= 96) ? 6 : 8;
+    }
     h->tset = cfg->terminal_set != 0;
     if (h->tset) {
         const char* why = nullptr;
@@ -521,6 +559,14 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
               (h->nb_max > 8 && grow(h, &h->hs[1], (int64_t)h->grid[1] * slot_words(9, cfg->N)) != FTMPC_OK) ||
               (h->nb_max > 9 && grow(h, &h->hs[2], (int64_t)h->grid[2] * slot_words(10, cfg->N)) != FTMPC_OK) ||
               grow(h, &h->d_dbgH, 4096 * 24 + 256 * 256) != FTMPC_OK || grow(h, &h->d_dbgv, 3 * 256 + 4) != FTMPC_OK;
+        if (!bad && h->use_ws) {
+            int per = 0;
+            if (h->ws_nb == 6) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_ws32_kernel<6>, ftmpc::wsk::WG, 0);
+            else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_ws32_kernel<8>, ftmpc::wsk::WG, 0);
+            h->grid_ws = h->num_cu * (per > 0 ? per : 1);
+            h->ws_slot_words = ftmpc::wsk::slot_words(h->ws_nb, cfg->N);
+            bad = grow(h, &h->ws_slot, (int64_t)h->grid_ws * h->ws_slot_words) != FTMPC_OK;
+        }
         if (!bad && h->use_wg) {
             h->grid_wg = h->num_cu;      // ~150 KiB of LDS: one workgroup per CU
             h->wg_slot_words = ftmpc::wgk::slot_words(15, cfg->N);
@@ -567,7 +613,7 @@ int ftmpc_destroy(ftmpc_handle* h) {
     void* ptrs[] = {h->rec, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, h->d_uref, h->d_warm, h->d_u0, h->d_U,
                     h->d_status, h->d_iters, h->hs[0], h->hs[1], h->hs[2], h->d_dbgH, h->d_dbgv, h->Hs, h->Ls, h->Eall, h->d_dbgH64, h->d_dbgv64,
                     h->d_atau, h->d_aub, h->d_au, h->d_ast, h->d_ait, h->d_qlist, h->d_qctl, h->d_term, h->d_eN, h->gHs, h->gLs,
-                    h->gEall, h->wg_slot, h->d_tcost, h->d_cost, h->d_hullA, h->d_hullb, h->d_warmG, h->d_tau0, h->d_G, h->d_taud, h->d_hullset, h->d_ast2};
+                    h->gEall, h->wg_slot, h->ws_slot, h->d_tcost, h->d_cost, h->d_hullA, h->d_hullb, h->d_warmG, h->d_tau0, h->d_G, h->d_taud, h->d_hullset, h->d_ast2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->pin_in.p) (void)hipHostFree(h->pin_in.p);
@@ -1013,8 +1059,11 @@ int ftmpc_debug_build_qp(ftmpc_handle* h, int64_t B, const double* x0, const dou
     if ((rc = stage_refs(h, B, xref, xref_stride, uref, uref_stride)) != FTMPC_OK) return rc;
     if (warmU) HIP_TRY(h, hipMemcpyAsync(h->d_warm, warmU, B * N * NT * sizeof(double), hipMemcpyHostToDevice, s));
     if (!h->use_f64) HIP_TRY(h, hipMemsetAsync(h->d_dbgv, 0, (3 * 256 + 4) * sizeof(float), s));
+    const bool ws_was = h->use_ws;
+    h->use_ws = false;     // the dump hook (the condensed thruster-space QP) lives in kernel 7; kernel 8 never forms that matrix
     rc = enqueue(h, B, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, xref_stride, uref ? h->d_uref : nullptr, uref_stride,
                  warmU ? h->d_warm : nullptr, h->d_u0, nullptr, h->d_status, h->d_iters, s, inst);
+    h->use_ws = ws_was;
     if (rc != FTMPC_OK) return rc;
     if (h->use_f64) {
         const int64_t pm = h->npad_max;

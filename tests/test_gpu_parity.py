@@ -120,10 +120,13 @@ def test_wg_kernel_build_matches_oracle(gpu_mpc_factory, nfault):
         assert np.allclose(lo, -qp["Ubar"], atol=1e-6) and np.allclose(hi, qp["ub"] - qp["Ubar"], atol=1e-6)
 
 
+@pytest.mark.parametrize("ws", ["1", "0"])
 @pytest.mark.parametrize("N,nfault,B", [(15, 2, 64), (15, 0, 32), (15, 1, 32), (12, 0, 32), (13, 2, 32)])
-def test_wg_kernel_u0_against_the_c_oracle(gpu_mpc_factory, N, nfault, B):
-    """n = 210 (reactive.yaml's horizon, two faults), 240 (nominal), 225, 192 and 182: block counts 12..15."""
+def test_wg_kernel_u0_against_the_c_oracle(gpu_mpc_factory, monkeypatch, N, nfault, B, ws):
+    """n = 210 (reactive.yaml's horizon, two faults), 240 (nominal), 225, 192 and 182: block counts 12..15.
+    ws = 1: kernel 8 (the same QP through wrench space, the default for these shapes); ws = 0: kernel 7 (dense)."""
     NT = 16
+    monkeypatch.setenv("FTMPC_WS", ws)
     mpc = gpu_mpc_factory(N=N, NT=NT)
     x0, ub, stuck, xref = qo.make_batch(B, N, NT, nfault, 3400 + N + nfault)
     out = mpc.solve(x0, ub, stuck, xref.reshape(-1, order="F"), return_U=True)
@@ -133,6 +136,30 @@ def test_wg_kernel_u0_against_the_c_oracle(gpu_mpc_factory, N, nfault, B):
     assert np.abs(out["u0"] - ref["u0"]).max() / F_MAX <= 1e-4
     assert np.abs(out["U"] - ref["U"]).max() / F_MAX <= 2e-3
     assert (out["u0"][ub == 0] == 0).all() and out["iters"].max() <= 30
+
+
+def test_wrench_space_kernel_agrees_with_the_dense_workgroup_kernel(gpu_mpc_factory, monkeypatch):
+    """Kernel 8 solves the Newton systems of the SAME interior-point iteration through the 6N-variable wrench-space form
+    x = Dg^-1 (r - DD' L (I + L' S L)^-1 L' DD Dg^-1 r): same iterates as the dense kernel 7 up to fp32 rounding, also
+    where the healthy thrusters do not span R^6 (faults 12 + 13: S is singular, the form does not care)."""
+    N, NT, B = 15, 16, 1024
+    x0, ub, stuck, xref = qo.make_batch(B, N, NT, 2, 3800)
+    for b in range(0, B, 8):            # every eighth instance: the degenerate pair
+        ub[b], stuck[b] = rm.F_MAX, 0.0
+        ub[b, [12, 13]] = 0.0
+        stuck[b, [12, 13]] = [0.3 * rm.F_MAX, 0.9 * rm.F_MAX]
+    for b in range(4, B, 8):            # and a heavily damaged vehicle (8 faults: n = 120 goes to the one-wave kernel)
+        idx = np.random.default_rng(b).choice(NT, 8, replace=False)
+        ub[b, idx] = 0.0
+    xr = xref.reshape(-1, order="F")
+    monkeypatch.setenv("FTMPC_WS", "1")
+    a = gpu_mpc_factory(N=N, NT=NT).solve(x0, ub, stuck, xr, return_U=True)
+    monkeypatch.setenv("FTMPC_WS", "0")
+    b = gpu_mpc_factory(N=N, NT=NT).solve(x0, ub, stuck, xr, return_U=True)
+    assert (a["status"] == 0).all() and (b["status"] == 0).all()
+    assert np.abs(a["U"] - b["U"]).max() / F_MAX <= 2e-5
+    assert np.abs(a["u0"] - b["u0"]).max() / F_MAX <= 5e-6
+    assert (np.abs(a["iters"].astype(int) - b["iters"]) <= 1).all() and (a["iters"] == b["iters"]).mean() > 0.97
 
 
 @pytest.mark.parametrize("N,NT,dtype", [(15, 16, "f32"), (15, 16, "f64"), (20, 8, "f32")])
@@ -177,11 +204,13 @@ def test_direction_split_linearisation_gives_the_same_bits(gpu_mpc_factory, monk
             assert np.array_equal(a[k], b[k]), k
 
 
-def test_wg_kernel_whole_batch_mixed_fault_counts_warm_start_and_uref(gpu_mpc_factory):
+@pytest.mark.parametrize("ws", ["1", "0"])
+def test_wg_kernel_whole_batch_mixed_fault_counts_warm_start_and_uref(gpu_mpc_factory, monkeypatch, ws):
     """4096 instances (16 per workgroup), fault counts 0..10 mixed in one batch (routed between the one-wave kernels
-    NB = 8 / 9 / 10 and the workgroup kernel), then a warm-started step with a circle reference window."""
+    NB = 8 / 9 / 10 and the workgroup kernel 8 or 7), then a warm-started step with a circle reference window."""
     import os
     N, NT, B = 15, 16, 4096
+    monkeypatch.setenv("FTMPC_WS", ws)
     mpc = gpu_mpc_factory(N=N, NT=NT)
     x0, ub, stuck, xref = qo.make_batch(B, N, NT, 2, 3500)
     rng = np.random.default_rng(9)

@@ -321,8 +321,11 @@ __global__ void __launch_bounds__(wsk::WG, (NB <= 6) ? 2 : 1) ftmpc_solve_ws32_k
         if (tid < npad) gwv[tid] = valid ? 2.f * gacc : 0.f;     // wrench-space gradient at the linearisation point
         const float lo = -ubar, hi = ubv - ubar;
         float sl = 0.5f * ubv, su = 0.5f * ubv, zl = 0.f, zu = 0.f, grad = 0.f;
-        bool keep_l = true;
+        bool keep_l = true, k_in_lds = false;
 
+        // the matrix to factorise comes as -M' tiles: H_w from the global slot (once), K = I + L' S L from the factor's own LDS
+        // slots, where the assembly left it (read before the slot is overwritten with the partial sum or the tile)
+        auto ldk = [&](int t) { return k_in_lds ? ldt(t) : ldh(t); };
         auto factor = [&]() {
             if (tid == 0) s_flag = 1;
             auto potrf_publish = [&](int D, const f32x4& dsum) {
@@ -344,7 +347,7 @@ __global__ void __launch_bounds__(wsk::WG, (NB <= 6) ? 2 : 1) ftmpc_solve_ws32_k
                 // first factorisation (of H_w itself): keep the diagonal block of the factor, L_DD = C W' (C = L L', W = L^-1)
                 if (keep_l) *reinterpret_cast<f32x4*>(Lu + tidx(D, D) * 256 + 4 * lane) = mm_tn(cd, wt, zero4);
             };
-            if (wave == 0) potrf_publish(0, ldh(tidx(0, 0)));
+            if (wave == 0) potrf_publish(0, ldk(tidx(0, 0)));
             __syncthreads();   // W_0 published
             for (int J = 0; J + 1 < nb; ++J) {
                 const int owner = (J + 1) & 3;
@@ -361,8 +364,8 @@ __global__ void __launch_bounds__(wsk::WG, (NB <= 6) ? 2 : 1) ftmpc_solve_ws32_k
                         part = mm_tn(tjl, tl, part);
                         dsum = mm_tn(tl, tl, dsum);
                     } else {
-                        part = ldh(tidx(1, 0));
-                        dsum = ldh(tidx(1, 1));
+                        part = ldk(tidx(1, 0));
+                        dsum = ldk(tidx(1, 1));
                     }
                     const f32x4 tij = mm_tn(wtn, part, zero4);
                     stt(tidx(J + 1, J), tij);
@@ -384,8 +387,8 @@ __global__ void __launch_bounds__(wsk::WG, (NB <= 6) ? 2 : 1) ftmpc_solve_ws32_k
                                     pb = mfma4(tjl[s4], tb[s4], pb);
                                 }
                             } else {
-                                pa = ldh(tidx(I, 0));
-                                pb = ldh(tidx(I2, 0));
+                                pa = ldk(tidx(I, 0));
+                                pb = ldk(tidx(I2, 0));
                             }
                             f32x4 xa = zero4, xb = zero4;
 #pragma unroll
@@ -402,7 +405,7 @@ __global__ void __launch_bounds__(wsk::WG, (NB <= 6) ? 2 : 1) ftmpc_solve_ws32_k
                                 pa = ldt(tidx(I, J));
                                 pa = mm_tn(tjl, ta, pa);
                             } else {
-                                pa = ldh(tidx(I, 0));
+                                pa = ldk(tidx(I, 0));
                             }
                             stt(tidx(I, J), mm_tn(wtn, pa, zero4));
                         }
@@ -414,7 +417,7 @@ __global__ void __launch_bounds__(wsk::WG, (NB <= 6) ? 2 : 1) ftmpc_solve_ws32_k
                         const float* pa = Tl + tidx(I, 0) * 256 + 4 * lane;
                         if (I2 < nb) {
                             const float* pb = Tl + tidx(I2, 0) * 256 + 4 * lane;
-                            const f32x4 ha = ldh(tidx(I, J + 1)), hb = ldh(tidx(I2, J + 1));
+                            const f32x4 ha = ldk(tidx(I, J + 1)), hb = ldk(tidx(I2, J + 1));
                             f32x4 a0 = zero4, a1 = zero4, b0 = zero4, b1 = zero4;
                             for (int K = 0; K < J; ++K) {
                                 const f32x4 tj = lds4(pj + K * 256), ta = lds4(pa + K * 256), tb = lds4(pb + K * 256);
@@ -424,7 +427,7 @@ __global__ void __launch_bounds__(wsk::WG, (NB <= 6) ? 2 : 1) ftmpc_solve_ws32_k
                             stt(tidx(I, J + 1), a0 + a1 + ha);
                             stt(tidx(I2, J + 1), b0 + b1 + hb);
                         } else {
-                            const f32x4 ha = ldh(tidx(I, J + 1));
+                            const f32x4 ha = ldk(tidx(I, J + 1));
                             f32x4 a0 = zero4, a1 = zero4;
                             for (int K = 0; K < J; ++K) {
                                 const f32x4 tj = lds4(pj + K * 256), ta = lds4(pa + K * 256);
@@ -435,7 +438,7 @@ __global__ void __launch_bounds__(wsk::WG, (NB <= 6) ? 2 : 1) ftmpc_solve_ws32_k
                     }
                     // diagonal tile two columns ahead over the columns < J (the helper with the fewest tiles)
                     if (r == 2 && J + 2 < nb) {
-                        const f32x4 hd = ldh(tidx(J + 2, J + 2));
+                        const f32x4 hd = ldk(tidx(J + 2, J + 2));
                         stt(tidx(J + 2, J + 2), schur_diag(Tl, lane, J + 2, J) + hd);
                     }
                 }
@@ -506,6 +509,7 @@ __global__ void __launch_bounds__(wsk::WG, (NB <= 6) ? 2 : 1) ftmpc_solve_ws32_k
         __syncthreads();
         factor();
         keep_l = false;
+        k_in_lds = true;
         if (__builtin_amdgcn_readfirstlane(s_flag) == 0) {   // H_w not positive definite in fp32: report, do not iterate
             for (int i = tid; i < NT; i += WG) P.out_u0[inst * NT + i] = 0.0;
             if (P.out_U)
@@ -675,12 +679,27 @@ __global__ void __launch_bounds__(wsk::WG, (NB <= 6) ? 2 : 1) ftmpc_solve_ws32_k
 #ifdef FTMPC_STAMPS_FINE
             STAMP(8);
 #endif
-            for (int t = wave; t < ntl; t += NWAVE) {     // X_IJ' = sum_{M >= I} P_MJ' L_MI
-                int I, J;
-                tile_of(t, I, J);
-                f32x4 a0 = zero4, a1 = zero4;
-                for (int M = I; M < nb; ++M) mm_tn2(ldt(tidx(M, J)), ldl(tidx(M, I)), a0, a1);
-                *reinterpret_cast<f32x4*>(Hs + (int64_t)t * 256 + 4 * lane) = -(a0 + a1);
+            {   // X_IJ' = sum_{M >= I} P_MJ' L_MI, held in registers until every wave is done with P, then -X' into the factor's slots
+                constexpr int XPW = (NT_ALL + NWAVE - 1) / NWAVE;
+                f32x4 xt[XPW];
+#pragma unroll
+                for (int i = 0; i < XPW; ++i) {
+                    const int t = wave + NWAVE * i;
+                    xt[i] = zero4;
+                    if (t < ntl) {
+                        int I, J;
+                        tile_of(t, I, J);
+                        f32x4 a0 = zero4, a1 = zero4;
+                        for (int M = I; M < nb; ++M) mm_tn2(ldt(tidx(M, J)), ldl(tidx(M, I)), a0, a1);
+                        xt[i] = -(a0 + a1);
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < XPW; ++i) {
+                    const int t = wave + NWAVE * i;
+                    if (t < ntl) stt(t, xt[i]);
+                }
             }
             __syncthreads();
 #ifdef FTMPC_STAMPS_FINE

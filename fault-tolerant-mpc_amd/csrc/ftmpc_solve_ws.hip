@@ -36,20 +36,21 @@ __host__ __device__ constexpr int64_t slot_words(int nbmax, int N) { return slot
 }  // namespace wsk
 
 template <int NB>   // block rows of the wrench-space system: 6 N <= 16 NB
-__global__ void __launch_bounds__(wsk::WG, (NB <= 6) ? 2 : 1) ftmpc_solve_ws32_kernel(const DeviceConsts C, const SolveWgParams Q) {
+__global__ void __launch_bounds__(wsk::WG) __attribute__((amdgpu_waves_per_eu((NB <= 6) ? 2 : 1, (NB <= 6) ? 2 : 1))) ftmpc_solve_ws32_kernel(const DeviceConsts C, const SolveWgParams Q) {
     using namespace wsk;
     constexpr int NPAD = 16 * NB;
     constexpr int NT_ALL = ntiles(NB);
     const SolveParams& P = Q.base;
     __shared__ __attribute__((aligned(16))) float Tl[(NT_ALL + NB) * 256];   // factor of K (diagonal slot: W') | W of every diagonal block
     __shared__ __attribute__((aligned(16))) float Lu[NT_ALL * 256];           // L (H_w = L L'), tiles L_IJ in accumulator layout
-    __shared__ __attribute__((aligned(16))) float xv[NPAD], yv[NPAD], sigv[NPAD], dnat[NPAD], gwv[NPAD], tw[NPAD];
-    __shared__ __attribute__((aligned(16))) float rv[NTP], rdg[NTP], dT[NTP];
-    __shared__ __attribute__((aligned(16))) float Sblk[32 * 36];
+    constexpr int NSTG = (16 * NB) / 6;                                        // stages: 6 N <= 16 NB
+    __shared__ __attribute__((aligned(16))) float xv[NPAD], yv[NPAD], sigv[NPAD], gwv[NPAD], tw[NPAD];
+    __shared__ __attribute__((aligned(16))) float rv[NTP], rdg[NTP];
+    __shared__ __attribute__((aligned(16))) float Sblk[NSTG * 36];
     __shared__ __attribute__((aligned(16))) double recd[REC_STRIDE + 4];
-    __shared__ __attribute__((aligned(16))) double sSl[9 * 33];
+    __shared__ __attribute__((aligned(16))) double sSl[9 * (NSTG + 1)];
     __shared__ __attribute__((aligned(16))) float recf[REC_STRIDE];
-    __shared__ float S17[16 * 17], S17w[NWAVE][16 * 17];
+    __shared__ float S17[16 * 17];
     __shared__ __attribute__((aligned(16))) float s_Da[6 * MAX_NT], s_DaT[6 * MAX_NT];   // identity (condensing) | the healthy columns of D
     __shared__ float s_MR[MAX_NT * MAX_NT];
     __shared__ float red[NWAVE];
@@ -62,6 +63,9 @@ __global__ void __launch_bounds__(wsk::WG, (NB <= 6) ? 2 : 1) ftmpc_solve_ws32_k
     __shared__ __attribute__((aligned(16))) float Stl[(3 * NB - 2) * 256];
     __shared__ __attribute__((aligned(16))) float s_DD[21 * MAX_NT];          // D_a[g][a] D_a[h][a] for the 21 pairs g >= h
     float* const Wdl = Tl + NT_ALL * 256;
+    float* const dnat = tw;     // start gradient only
+    float* const dT = rv;       // reference gradient only
+    static_assert((3 * NB - 2) * 256 >= NWAVE * 16 * 17, "transposition scratch lives in the S tiles");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -525,7 +529,7 @@ __global__ void __launch_bounds__(wsk::WG, (NB <= 6) ? 2 : 1) ftmpc_solve_ws32_k
             tile_of(t, I, J);
             if (I == J) continue;                     // diagonal blocks: written by potrf_publish
             const f32x4 tt = ldt(t);                  // L_IJ'
-            float* sc = S17w[wave];
+            float* sc = Stl + wave * 16 * 17;   // (the S tiles are not in use yet)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) sc[(4 * lq + rr) * 17 + li] = tt[rr];
             wave_lds_fence();

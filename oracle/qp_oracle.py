@@ -616,3 +616,50 @@ def sqp_linesearch(cfg: QPConfig, x0, ub, stuck, xref, uref=None, warmU=None, te
         if done:
             break
     return U, J, hist
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The Newton systems of ipm_box through wrench space (what kernel 8, csrc/ftmpc_solve_ws.hip, does).
+#   The thrusters enter the dynamics only through the stage wrenches D_a u_k, so the condensed Hessian of build_qp is
+#       H = DD' H_w DD + 2 rho I,      DD = blockdiag(D_a) (6N x N na),  H_w = the Hessian of build_qp_wrench,
+#   and (H + Sigma) x = r with Dg = 2 rho + Sigma (diagonal) has the solution
+#       x = Dg^-1 (r - DD' L K^-1 L' DD Dg^-1 r),     H_w = L L',  K = I + L' S L,  S = DD Dg^-1 DD' (6 x 6 blocks).
+#   K is 6N x 6N with eigenvalues >= 1 whatever Sigma does; S may be singular (thrusters on their bounds, or healthy
+#   thrusters that do not span R^6).  The forms with S^-1 or H_w^-1 are the ones that fail in float32.
+# ---------------------------------------------------------------------------------------------------------
+def wrench_form(cfg: QPConfig, x0, ub, stuck, xref, uref=None, warmU=None):
+    """-> (H_w [6N,6N], D_a [6,na]) with build_qp(...)['H'] == kron(I_N, D_a)' H_w kron(I_N, D_a) + 2 rho I."""
+    ub = np.asarray(ub, float)
+    act = ub > 0
+    stuck = np.asarray(stuck, float)
+    warmG = None
+    if warmU is not None:
+        Ub = np.clip(np.asarray(warmU, float).reshape(cfg.N, cfg.NT), 0.0, ub)
+        warmG = (cfg.D @ (Ub + stuck).T).T
+    qw = build_qp_wrench(cfg, x0, ub, stuck, xref, uref=uref, warmG=warmG, hull=(np.zeros((1, 6)), np.ones(1)))
+    return qw["H"], cfg.D[:, act]
+
+
+def schur_newton_solver(Hw, Da, N, rho, dtype=np.float64):
+    """-> make(Sig) -> solve(r): the wrench-space form above in the given arithmetic (float32 emulates kernel 8)."""
+    T = dtype
+    na = Da.shape[1]
+    Da_t = Da.astype(T)
+    Lw = (np.linalg.cholesky(Hw) if T is np.float64 else _chol(Hw.astype(T))).astype(T)
+
+    def make(Sig):
+        Dg = (T(2 * rho) + Sig.astype(T)).astype(T)
+        S = np.zeros((6 * N, 6 * N), T)
+        for k in range(N):
+            S[6 * k:6 * k + 6, 6 * k:6 * k + 6] = (Da_t * (T(1) / Dg[k * na:(k + 1) * na])) @ Da_t.T
+        K = (np.eye(6 * N, dtype=T) + Lw.T @ (S @ Lw)).astype(T)
+        L = np.linalg.cholesky(K) if T is np.float64 else _chol(K)
+
+        def solve(r):
+            r = r.astype(T)
+            t = np.concatenate([Da_t @ (r[k * na:(k + 1) * na] / Dg[k * na:(k + 1) * na]) for k in range(N)]).astype(T)
+            p = _solve(L, (Lw.T @ t).astype(T))
+            y = (Lw @ p).astype(T)
+            return np.concatenate([(r[k * na:(k + 1) * na] - Da_t.T @ y[6 * k:6 * k + 6]) / Dg[k * na:(k + 1) * na] for k in range(N)])
+        return solve
+    return make

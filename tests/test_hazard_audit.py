@@ -31,7 +31,7 @@ def test_no_hazard_in_any_kernel(device_asm):
     # MFMA chain, a branch, v_accvgpr_read of the result 3 wait states later (table: 10).  That one is real -- the GPU
     # returned wrong factors until the consumer was padded (scripts/check_hazards.py header) -- so the build pads it.
     comp = [(n, f) for n, s in summary.items() for f in s["compiler"]]
-    assert all(f["rule"] == "mfma_use" and ("ftmpc_solve_wg32_kernel" in n or "ftmpc_solve_ws32_kernel" in n) for n, f in comp), \
+    assert all(f["rule"] in ("mfma_use", "mfma_srcab") and ("ftmpc_solve_wg32_kernel" in n or "ftmpc_solve_ws32_kernel" in n) for n, f in comp), \
         [(n, f["rule"]) for n, f in comp][:5]   # the workgroup kernels 7 and 8 share the factorisation where the pattern sits
 
 

@@ -139,6 +139,12 @@ def make_line(args, world, elapsed, B, N, NT, iters, status, ub, kernel_ms, para
     peak = F64_PEAK_TFLOPS if f64 else F32_PEAK_TFLOPS
     achieved = flops / (sol_ms * 1e-3) / 1e12
     traffic, traffic_src = traffic_for(dom, B, N, NT)
+    # the workgroup slot runs kernel 8 (Newton systems through the 6N-variable wrench-space form) when it applies: the flop model
+    # above is SURVEY.md 8(d)'s dense one, i.e. the work the QP step stands for, not what that kernel executes
+    note = {}
+    if "ws32" in dom:
+        note = {"work_model_note": "algorithmic flops of the dense condensed IPM (SURVEY.md 8(d)); this kernel factorises 6N x 6N "
+                                   "matrices instead of (N na) x (N na) and executes fewer"}
     return {
         "metric": METRIC,
         "value": args.steps * B * world / elapsed, "unit": "QP-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -153,7 +159,7 @@ def make_line(args, world, elapsed, B, N, NT, iters, status, ub, kernel_ms, para
                      "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": dom, "kernel_ms": sol_ms,
                      "other_kernels_ms": {"ftmpc_linearize_kernel": lin_ms, **{k: v for k, v in kernel_ms.items() if k != dom}},
-                     "flops_per_launch": flops, "csrc_sha": csrc_hash()},
+                     "flops_per_launch": flops, "csrc_sha": csrc_hash(), **note},
     }
 
 

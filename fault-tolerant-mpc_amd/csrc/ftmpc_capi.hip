@@ -1038,7 +1038,7 @@ int ftmpc_last_kernel_ms(ftmpc_handle* h, float ms[6]) {
 }
 
 static const char* const k_kernel_names[6] = {"ftmpc_linearize_kernel", "ftmpc_solve_f32_kernel<8>", "ftmpc_solve_f32_kernel<9>",
-                                              "ftmpc_solve_f32_kernel<10>", "ftmpc_solve_f64_kernel", "ftmpc_solve_wg32_kernel<15>"};
+                                              "ftmpc_solve_f32_kernel<10>", "ftmpc_solve_f64_kernel", "ftmpc_solve_ws32_kernel | ftmpc_solve_wg32_kernel<15>"};
 
 const char* ftmpc_kernel_name(int32_t slot) { return (slot >= 0 && slot < 6) ? k_kernel_names[slot] : ""; }
 

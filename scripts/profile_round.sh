@@ -12,4 +12,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_SQ -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_SQ.err
 timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_SQ2 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_SQ2.err || true
+# the reference's own vehicle (N = 15, 16 thrusters, two faults, B = 4096): kernel 8
+python3 bench.py --horizon 15 --thrusters 16 --batch 4096 --no-cpu-baseline > $OUT/bench_refvehicle.json 2> $OUT/bench_refvehicle.err || true
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_refvehicle -- python3 bench.py --horizon 15 --thrusters 16 --batch 4096 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/prof_refvehicle.err || true
 cat $OUT/bench.json

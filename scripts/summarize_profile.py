@@ -10,6 +10,10 @@ dst.mkdir(exist_ok=True)
 shutil.copy(src / "bench.json", dst / f"{tag}_bench.json")
 for f in glob.glob(str(src / "stats" / "*" / "*kernel_stats.csv")):
     shutil.copy(f, dst / f"{tag}_kernel_stats.csv")
+for f in glob.glob(str(src / "stats_refvehicle" / "*" / "*kernel_stats.csv")):
+    shutil.copy(f, dst / f"{tag}_refvehicle_kernel_stats.csv")
+if (src / "bench_refvehicle.json").exists():
+    shutil.copy(src / "bench_refvehicle.json", dst / f"{tag}_refvehicle_bench.json")
 out = {}
 for f in glob.glob(str(src / "pmc_*" / "*" / "*counter_collection.csv")):
     agg = collections.defaultdict(list)

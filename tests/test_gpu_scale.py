@@ -141,6 +141,23 @@ def test_config3_full_batch_against_the_c_oracle(gpu_mpc_factory):
     assert (out["u0"][ub == 0] == 0).all()
 
 
+def test_reference_vehicle_large_batch_against_the_c_oracle(gpu_mpc_factory):
+    """The reference's own vehicle (N = 15, 16 thrusters, two faults) at 16 384 instances -- 32 per workgroup of kernel 8
+    (Newton systems through wrench space), two workgroups per CU -- every instance against the C oracle."""
+    N, NT, B = 15, 16, 16384
+    mpc = gpu_mpc_factory(N=N, NT=NT)
+    x0, ub, stuck, xref = qo.make_batch(B, N, NT, 2, 2222)
+    out = mpc.solve(x0, ub, stuck, xref.reshape(-1, order="F"))
+    assert (out["status"] == 0).all(), np.bincount(out["status"])
+    ref = co.solve_batch(qo.QPConfig(N=N, NT=NT), x0, ub, stuck, xref, nthreads=_threads(), max_iters=60, mu_stop=1e-13,
+                         return_U=False)
+    assert (ref["status"] == 0).all()
+    err = np.abs(out["u0"] - ref["u0"]).max(axis=1) / F_MAX
+    assert err.max() <= 1e-4, (err.max(), int(err.argmax()))
+    assert np.median(err) <= 1e-6
+    assert (out["u0"][ub == 0] == 0).all()
+
+
 # ---------------------------------------------------------------------------------------------
 # BASELINE configs[3]: 262 144 instances sharded over ranks (two ranks on the one device of this box)
 # ---------------------------------------------------------------------------------------------

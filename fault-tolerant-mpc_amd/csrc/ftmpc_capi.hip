@@ -475,9 +475,11 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
     // variable per thread covers N * NT and the wrench-space system fits eight tiles a side (FTMPC_WS=0: kernel 7 instead).
     // The one-wave kernels keep n <= 160: a workgroup per instance does not compete with a wave per instance there.
     {
+        // By default for N <= 16 only (the reference horizon is 15): on a 21-stage synthetic vehicle with cond(H) = 1e7 its
+        // worst instance of 96 was 3e-4 f_max from the exact solution where kernel 7 stays at 2e-5; FTMPC_WS=1 takes it up to N = 21.
         const char* e = std::getenv("FTMPC_WS");
-        const bool want = e ? std::atoi(e) != 0 : true;
-        h->use_ws = want && h->use_wg && cfg->N * cfg->NT <= 256 && 6 * cfg->N <= 128;
+        const int want = e ? std::atoi(e) : -1;
+        h->use_ws = want != 0 && h->use_wg && cfg->N * cfg->NT <= 256 && 6 * cfg->N <= (want > 0 ? 128 : 96);
         h->ws_nb = (6 * cfg->N <= 96) ? 6 : 8;
     }
     h->tset = cfg->terminal_set != 0;

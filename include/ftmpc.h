@@ -258,7 +258,7 @@ int ftmpc_simulate_batch(ftmpc_handle* h, int64_t B, int32_t T, double* x, const
  * traces:  0 linearise, 1..3 condense+IPM fp32 (one wave per instance) for n <= 128 / 144 / 160,
  * 4 condense+IPM fp64 (workgroup per instance, general n), 5 condense+IPM fp32 with the factor in LDS (workgroup per
  * instance, 160 < n <= 240): ftmpc_solve_ws32_kernel (Newton systems through the 6N-variable wrench-space form) when
- * N*NT <= 256 and 6N <= 128, else -- or with FTMPC_WS=0 in the environment -- the dense ftmpc_solve_wg32_kernel<15>
+ * N*NT <= 256 and N <= 16 (N <= 21 with FTMPC_WS=1), else -- or with FTMPC_WS=0 in the environment -- the dense ftmpc_solve_wg32_kernel<15>
  * (the slot reports both names). */
 int ftmpc_set_profiling(ftmpc_handle* h, int32_t enabled);
 int ftmpc_last_kernel_ms(ftmpc_handle* h, float ms[6]);

@@ -114,6 +114,21 @@ def test_on_device_closed_loop_f32_campaign(gpu_mpc_factory):
     assert np.abs(out["x"] - xo).max() < 1e-4
 
 
+def test_on_device_closed_loop_f32_campaign_reference_vehicle(gpu_mpc_factory):
+    """The reference's vehicle (16 thrusters, N = 15) on kernel 8 in the on-device loop: warm starts, shifted references,
+    faults -- against the float64 oracle loop."""
+    from oracle import closed_loop as cl
+    N, NT, B, T = 15, 16, 16, 6
+    mpc = gpu_mpc_factory(N=N, NT=NT)
+    x0, ub, stuck, _ = qo.make_batch(B, N, NT, 2, 1235)
+    xr = _hover_traj(N, T)
+    out = mpc.simulate(x0, ub, stuck, xr, T, seed=12, return_inputs=True)
+    xo, uo = cl.simulate(qo.QPConfig(N=N, NT=NT), x0, ub, stuck, xr, T, seed=12)
+    assert out["not_converged"].sum() == 0
+    assert np.abs(out["u"] - uo).max() / 3.4 < 5e-4
+    assert np.abs(out["x"] - xo).max() < 1e-4
+
+
 def test_relinearisation_converges_and_matches_oracle(gpu_mpc_factory):
     """Sequential QP (re-linearise about the previous solution): the GPU loop equals the oracle loop and
     the iterates contract (first step: nonlinear dynamics, quadratic terminal cost)."""

@@ -142,8 +142,9 @@ def test_wg_kernel_u0_against_the_c_oracle(gpu_mpc_factory, monkeypatch, N, nfau
 def test_wrench_space_kernel_other_vehicles_and_horizons(gpu_mpc_factory, monkeypatch, N, NT, seed):
     """Kernel 8 away from the reference shape: 11..16 thrusters (a random allocation matrix of full row rank), horizons
     11..21 (both instantiations: six and eight tiles a side), mixed fault counts, warm start; against the C oracle.
-    Up to N = 16 (the default range) within the 1e-4 f_max of the specification; beyond -- only with FTMPC_WS=1 -- the tail
-    of these ill-conditioned synthetic vehicles (cond(H) ~ 1e7) reaches a few 1e-4, which is why it is not the default there."""
+    Up to N = 16 (the default range) within the 1e-4 f_max of the specification; beyond -- only with FTMPC_WS=1, where the
+    kernel adds a polish step from the float64 gradient at the final iterate -- the worst instance of these ill-conditioned
+    synthetic vehicles (cond(H) ~ 1e7) sits at 1e-4 (1e-3 without the polish), which is why it is not the default there."""
     rng = np.random.default_rng(900 + seed)
     B = 96
     D = None
@@ -165,7 +166,7 @@ def test_wrench_space_kernel_other_vehicles_and_horizons(gpu_mpc_factory, monkey
     ok = ref["status"] == 0
     assert ok.mean() > 0.95 and (out["status"][ok] == 0).all()
     err = np.abs(out["u0"][ok] - ref["u0"][ok]).max(axis=1) / F_MAX
-    assert err.max() <= (1e-4 if N <= 16 else 1e-3) and np.percentile(err, 90) <= 1e-5, (err.max(), np.percentile(err, 90))
+    assert err.max() <= (1e-4 if N <= 16 else 3e-4) and np.percentile(err, 90) <= 1e-5, (err.max(), np.percentile(err, 90))
     assert (out["u0"][ub == 0] == 0).all()
 
 

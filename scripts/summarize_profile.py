@@ -24,6 +24,17 @@ for f in glob.glob(str(src / "pmc_*" / "*" / "*counter_collection.csv")):
     for (k, c), v in sorted(agg.items()):
         out.setdefault(k, {})[c] = sum(v) / len(v)
 (dst / f"{tag}_pmc_summary.json").write_text(json.dumps(out, indent=1))
+outrv = {}
+for f in glob.glob(str(src / "pmcrv_*" / "*" / "*counter_collection.csv")):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "ftmpc" in k:
+            agg[(k.split("(")[0].replace("void ", ""), r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for (k, c), v in sorted(agg.items()):
+        outrv.setdefault(k, {})[c] = sum(v) / len(v)
+if outrv:
+    (dst / f"{tag}_refvehicle_pmc_summary.json").write_text(json.dumps(outrv, indent=1))
 bench = json.loads((src / "bench.json").read_text())
 dom = bench["roofline"]["kernel"]
 pm = out.get("ftmpc::" + dom, {})

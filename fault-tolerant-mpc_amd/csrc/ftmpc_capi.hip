@@ -73,7 +73,7 @@ struct ftmpc_handle {
     hipStream_t s_in = nullptr, s_out = nullptr;
     static constexpr int MAX_CHUNKS = 8;
     hipEvent_t ev_in[MAX_CHUNKS] = {}, ev_k[MAX_CHUNKS] = {}, ev_out[MAX_CHUNKS] = {};
-    int64_t lin_split_max = 8192;   // FTMPC_LIN_SPLIT_MAX overrides (0: never split)
+    int64_t lin_split_max = 8192;   // ftmpc_config.lin_split_max overrides (0 here: never split)
     int stage_chunks = 0;   // 0: whole blocks of 65 536 instances (a persistent launch below that does not fill the device twice)
     // fp32 workgroup-per-instance kernel with the factor in LDS (160 < N*NT <= 240)
     bool use_ws = false;            // kernel 8 (wrench-space Schur form) takes the lists of NB = 9, 10 and of the workgroup kernel
@@ -109,9 +109,9 @@ struct ftmpc_handle {
     float *d_dbgH = nullptr, *d_dbgv = nullptr;
     // profiling
     bool profiling = false;
-    hipEvent_t ev[12] = {};  // start/stop per kernel slot
+    hipEvent_t ev[2 * FTMPC_KERNEL_SLOTS] = {};  // start/stop per kernel slot
     bool ev_valid = false;
-    bool ev_used[6] = {false, false, false, false, false, false};
+    bool ev_used[FTMPC_KERNEL_SLOTS] = {};
 };
 
 namespace {
@@ -382,11 +382,12 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
 
 extern "C" {
 
-int32_t ftmpc_version(void) { return 300; }
+int32_t ftmpc_version(void) { return 400; }
 
 int ftmpc_default_config(ftmpc_config* cfg, int32_t N, int32_t NT) {
     if (!cfg || N < 1 || N > 64 || NT < 1 || NT > FTMPC_MAX_NT) return FTMPC_ERR_ARG;
     std::memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = (int32_t)sizeof(ftmpc_config);
     cfg->N = N;
     cfg->NT = NT;
     cfg->dtype = FTMPC_DTYPE_F32;
@@ -440,6 +441,10 @@ int ftmpc_default_config(ftmpc_config* cfg, int32_t N, int32_t NT) {
 int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
     if (!cfg || !out) return fail(nullptr, FTMPC_ERR_ARG, "null argument");
     *out = nullptr;
+    // ABI guard first: nothing beyond the first 24 bytes of *cfg is read before the caller's struct is known to be ours
+    if (cfg->struct_size != (int32_t)sizeof(ftmpc_config))
+        return fail(nullptr, FTMPC_ERR_ARG, "ftmpc_config.struct_size is " + std::to_string(cfg->struct_size) + ", this library expects " +
+                                                std::to_string(sizeof(ftmpc_config)) + " (caller built against another include/ftmpc.h? use ftmpc_default_config)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, FTMPC_ERR_NODEVICE, "no HIP device visible (this library has no CPU fallback)");
@@ -451,6 +456,10 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
         return fail(nullptr, FTMPC_ERR_NODEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
     if (cfg->dtype != FTMPC_DTYPE_F32 && cfg->dtype != FTMPC_DTYPE_F64)
         return fail(nullptr, FTMPC_ERR_ARG, "dtype must be FTMPC_DTYPE_F32 or FTMPC_DTYPE_F64");
+    if (cfg->kernel_select != FTMPC_KERNEL_AUTO && cfg->kernel_select != FTMPC_KERNEL_DENSE)
+        return fail(nullptr, FTMPC_ERR_ARG, "kernel_select must be FTMPC_KERNEL_AUTO or FTMPC_KERNEL_DENSE");
+    if (cfg->stage_chunks < 0 || cfg->stage_chunks > ftmpc_handle::MAX_CHUNKS)
+        return fail(nullptr, FTMPC_ERR_ARG, "stage_chunks out of range 0..8");
     ftmpc_handle* h = new (std::nothrow) ftmpc_handle();
     if (!h) return fail(nullptr, FTMPC_ERR_ALLOC, "out of host memory");
     h->cfg = *cfg;
@@ -469,19 +478,15 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
     // workgroup-per-instance kernel
     // fp32: one-wave register-resident kernels up to n = 160, the workgroup kernel with the factor in LDS up to n = 240;
     // beyond that, and for dtype F64, the float64 workgroup kernel with its tiles in a global slot
-    h->use_f64 = (cfg->dtype == FTMPC_DTYPE_F64) || h->nb_max > 15;
-    h->use_wg = !h->use_f64 && h->nb_max > 10;
-    // kernel 8 (the thruster QP through wrench space) takes the workgroup kernel's list -- ceil(n / 16) >= 11 -- when one
-    // variable per thread covers N * NT and the wrench-space system fits eight tiles a side (FTMPC_WS=0: kernel 7 instead).
+    // kernel 8 (the thruster QP through wrench space) takes the workgroup kernel's list -- ceil(n / 16) >= 11 -- when the
+    // wrench-space system fits eight tiles a side (N <= 21) and the thruster variables fit its threads (one per thread up
+    // to N = 16, two beyond); kernel_select = FTMPC_KERNEL_DENSE: kernel 7 (n <= 240) or the float64 kernel instead.
     // The one-wave kernels keep n <= 160: a workgroup per instance does not compete with a wave per instance there.
-    {
-        // By default for N <= 16 only (the reference horizon is 15): on a 21-stage synthetic vehicle with cond(H) = 1e7 its
-        // worst instance of 96 was 3e-4 f_max from the exact solution where kernel 7 stays at 2e-5; FTMPC_WS=1 takes it up to N = 21.
-        const char* e = std::getenv("FTMPC_WS");
-        const int want = e ? std::atoi(e) : -1;
-        h->use_ws = want != 0 && h->use_wg && cfg->N * cfg->NT <= 256 && 6 * cfg->N <= (want > 0 ? 128 : 96);
-        h->ws_nb = (6 * cfg->N <= 96) ? 6 : 8;
-    }
+    h->ws_nb = (6 * cfg->N <= 96) ? 6 : 8;
+    h->use_ws = cfg->dtype != FTMPC_DTYPE_F64 && cfg->kernel_select != FTMPC_KERNEL_DENSE && h->nb_max > 10 && 6 * cfg->N <= 128 &&
+                cfg->N * cfg->NT <= ftmpc::wsk::WG * ftmpc::wsk::nvt_of(h->ws_nb);
+    h->use_f64 = (cfg->dtype == FTMPC_DTYPE_F64) || (h->nb_max > 15 && !h->use_ws);
+    h->use_wg = !h->use_f64 && h->nb_max > 10;
     h->tset = cfg->terminal_set != 0;
     if (h->tset) {
         const char* why = nullptr;
@@ -505,7 +510,7 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
         delete h;
         return fail(nullptr, FTMPC_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
-    for (int i = 0; i < 12; ++i) (void)hipEventCreate(&h->ev[i]);
+    for (int i = 0; i < 2 * FTMPC_KERNEL_SLOTS; ++i) (void)hipEventCreate(&h->ev[i]);
     bool sbad = hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking) != hipSuccess ||
                 hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking) != hipSuccess;
     for (int i = 0; i < ftmpc_handle::MAX_CHUNKS; ++i)
@@ -517,11 +522,8 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
         ftmpc_destroy(h);
         return FTMPC_ERR_HIP;
     }
-    if (const char* e = std::getenv("FTMPC_LIN_SPLIT_MAX")) h->lin_split_max = std::atoll(e);
-    if (const char* e = std::getenv("FTMPC_STAGE_CHUNKS")) {
-        const int c = std::atoi(e);
-        if (c >= 1 && c <= ftmpc_handle::MAX_CHUNKS) h->stage_chunks = c;
-    }
+    if (cfg->lin_split_max != 0) h->lin_split_max = cfg->lin_split_max < 0 ? 0 : cfg->lin_split_max;
+    if (cfg->stage_chunks >= 1 && cfg->stage_chunks <= ftmpc_handle::MAX_CHUNKS) h->stage_chunks = cfg->stage_chunks;
     // persistent grids: resident workgroups per CU from the occupancy query (LDS-bound)
     int per[3] = {0, 0, 0};
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per[0], ftmpc::ftmpc_solve_f32_kernel<8>, 64, 0);
@@ -620,7 +622,7 @@ int ftmpc_destroy(ftmpc_handle* h) {
         if (p) (void)hipFree(p);
     if (h->pin_in.p) (void)hipHostFree(h->pin_in.p);
     if (h->pin_out.p) (void)hipHostFree(h->pin_out.p);
-    for (int i = 0; i < 12; ++i)
+    for (int i = 0; i < 2 * FTMPC_KERNEL_SLOTS; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (int i = 0; i < ftmpc_handle::MAX_CHUNKS; ++i) {
         if (h->ev_in[i]) (void)hipEventDestroy(h->ev_in[i]);
@@ -643,6 +645,10 @@ int ftmpc_reserve(ftmpc_handle* h, int64_t max_batch) {
     const int N = h->cfg.N, NT = h->cfg.NT;
     const int64_t B = max_batch;
     float* recf = nullptr;
+    // every buffer below is freed before it is re-allocated: until all of them exist again the handle holds NO batch
+    // capacity, so a failure part-way (out of memory) makes the next call grow everything again instead of launching on
+    // freed pointers
+    h->cap_batch = 0;
     if (h->rec) (void)hipFree(h->rec);
     h->rec = nullptr;
     int rc = grow(h, &recf, B * N * ftmpc::REC_STRIDE * 2);   // float64 records
@@ -667,6 +673,7 @@ static int stage_refs(ftmpc_handle* h, int64_t B, const double* xref, int64_t xr
     const int N = h->cfg.N;
     const int64_t nx = xref_stride == 0 ? 9 * (N + 1) : B * xref_stride;
     if (nx > h->cap_xref) {
+        h->cap_xref = 0;   // (a failed growth must not leave a stale capacity)
         int rc = grow(h, &h->d_xref, nx);
         if (rc != FTMPC_OK) return rc;
         h->cap_xref = nx;
@@ -675,6 +682,7 @@ static int stage_refs(ftmpc_handle* h, int64_t B, const double* xref, int64_t xr
     if (uref) {
         const int64_t nu = uref_stride == 0 ? 6 * (N + 1) : B * uref_stride;
         if (nu > h->cap_uref) {
+            h->cap_uref = 0;   // (a failed growth must not leave a stale capacity)
             int rc = grow(h, &h->d_uref, nu);
             if (rc != FTMPC_OK) return rc;
             h->cap_uref = nu;
@@ -724,10 +732,12 @@ int ftmpc_solve_batch(ftmpc_handle* h, int64_t B, const double* x0, const double
     const int64_t nxr = xref_stride == 0 ? 9 * (N + 1) : B * xref_stride;
     const int64_t nur = !uref ? 0 : (uref_stride == 0 ? 6 * (N + 1) : B * uref_stride);
     if (nxr > h->cap_xref) {
+        h->cap_xref = 0;   // (a failed growth must not leave a stale capacity)
         if ((rc = grow(h, &h->d_xref, nxr)) != FTMPC_OK) return rc;
         h->cap_xref = nxr;
     }
     if (nur > h->cap_uref) {
+        h->cap_uref = 0;   // (a failed growth must not leave a stale capacity)
         if ((rc = grow(h, &h->d_uref, nur)) != FTMPC_OK) return rc;
         h->cap_uref = nur;
     }
@@ -743,7 +753,7 @@ int ftmpc_solve_batch(ftmpc_handle* h, int64_t B, const double* x0, const double
     int32_t* pit = pst + B;
     // Measured at B = 65 536 (scripts/host_entry_perf.py): one range 3.20 M QP/s, four ranges 2.74 M -- a range of 16 384
     // instances leaves the persistent grid with a ragged tail four times per call; so ranges are whole 65 536-blocks
-    // unless FTMPC_STAGE_CHUNKS says otherwise.
+    // unless ftmpc_config.stage_chunks says otherwise.
     int nch = h->stage_chunks > 0 ? (int)std::min<int64_t>(h->stage_chunks, (B + 16383) / 16384)
                                   : (int)std::min<int64_t>(ftmpc_handle::MAX_CHUNKS, (B + 65535) / 65536);
     if (nch < 1) nch = 1;
@@ -805,6 +815,7 @@ int ftmpc_eval_cost_batch(ftmpc_handle* h, int64_t B, const double* x0, const do
     HIP_TRY(h, hipSetDevice(h->device));
     if ((rc = ftmpc_reserve(h, B)) != FTMPC_OK) return rc;
     if (B > h->cap_cost) {
+        h->cap_cost = 0;   // (a failed growth must not leave a stale capacity)
         if ((rc = grow(h, &h->d_cost, B)) != FTMPC_OK) return rc;
         h->cap_cost = B;
     }
@@ -841,6 +852,7 @@ int ftmpc_solve_batch_device(ftmpc_handle* h, int64_t B, const double* x0, const
     if (rc != FTMPC_OK) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
     if (B > h->cap_batch) {
+        h->cap_batch = 0;   // (a failed growth must not leave a stale capacity)
         // growing the workspace allocates: callers that time or graph-capture must ftmpc_reserve first
         if ((rc = ftmpc_reserve(h, B)) != FTMPC_OK) return rc;
     }
@@ -861,6 +873,10 @@ int ftmpc_solve_wrench_batch(ftmpc_handle* h, int64_t B, const double* x0, const
     if (hull_rows < 1 || hull_rows > FTMPC_MAX_HULL_ROWS || (int64_t)N * hull_rows > 1024 || n_sets < 1)
         return fail(h, FTMPC_ERR_ARG, "hull_rows out of range (1..32, N * hull_rows <= 1024) or no hull table");
     if (h->cfg.terminal_set && (h->cfg.term_rows < 1 || h->cfg.term_rows > FTMPC_MAX_TERM_ROWS)) return fail(h, FTMPC_ERR_ARG, "term_rows out of range");
+    if (hull_set)   // the kernel indexes hull_A by these: a table number outside [0, n_sets) would be an out-of-bounds device read
+        for (int64_t b = 0; b < B; ++b)
+            if (hull_set[b] < 0 || hull_set[b] >= n_sets)
+                return fail(h, FTMPC_ERR_ARG, "hull_set[" + std::to_string(b) + "] = " + std::to_string(hull_set[b]) + " is not a table number in [0, n_sets)");
     int rc = check_strides(h, xref_stride, uref_stride, uref);
     if (rc != FTMPC_OK) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -885,10 +901,12 @@ int ftmpc_solve_wrench_batch(ftmpc_handle* h, int64_t B, const double* x0, const
     }
     const int64_t nA = (int64_t)n_sets * hull_rows * 6;
     if (nA > h->cap_hullA) {
+        h->cap_hullA = 0;   // (a failed growth must not leave a stale capacity)
         if ((rc = grow(h, &h->d_hullA, nA)) != FTMPC_OK) return rc;
         h->cap_hullA = nA;
     }
     if (B > h->cap_wrench) {
+        h->cap_wrench = 0;   // (a failed growth must not leave a stale capacity)
         if ((rc = grow(h, &h->d_hullb, B * FTMPC_MAX_HULL_ROWS)) != FTMPC_OK || (rc = grow(h, &h->d_hullset, B)) != FTMPC_OK ||
             (rc = grow(h, &h->d_warmG, B * N * 6)) != FTMPC_OK || (rc = grow(h, &h->d_tau0, B * 6)) != FTMPC_OK ||
             (rc = grow(h, &h->d_G, B * N * 6)) != FTMPC_OK || (rc = grow(h, &h->d_taud, B * 6)) != FTMPC_OK || (rc = grow(h, &h->d_ast2, 2 * B)) != FTMPC_OK)
@@ -982,6 +1000,7 @@ int ftmpc_allocate_batch(ftmpc_handle* h, int64_t B, const double* tau, const do
     HIP_TRY(h, hipSetDevice(h->device));
     const int NT = h->cfg.NT;
     if (B > h->cap_alloc) {
+        h->cap_alloc = 0;   // (a failed growth must not leave a stale capacity)
         int rc;
         if ((rc = grow(h, &h->d_atau, B * 6)) != FTMPC_OK || (rc = grow(h, &h->d_aub, B * NT)) != FTMPC_OK ||
             (rc = grow(h, &h->d_au, B * NT)) != FTMPC_OK || (rc = grow(h, &h->d_ast, B)) != FTMPC_OK ||
@@ -1027,10 +1046,10 @@ int ftmpc_set_profiling(ftmpc_handle* h, int32_t enabled) {
     return FTMPC_OK;
 }
 
-int ftmpc_last_kernel_ms(ftmpc_handle* h, float ms[6]) {
-    if (!h || !ms) return FTMPC_ERR_ARG;
+int ftmpc_last_kernel_ms(ftmpc_handle* h, float* ms, int32_t n_slots) {
+    if (!h || !ms || n_slots < 0) return FTMPC_ERR_ARG;
     if (!h->ev_valid) return fail(h, FTMPC_ERR_ARG, "no profiled solve recorded");
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < std::min<int>(n_slots, FTMPC_KERNEL_SLOTS); ++k) {
         ms[k] = 0.f;
         if (!h->ev_used[k]) continue;
         HIP_TRY(h, hipEventSynchronize(h->ev[2 * k + 1]));
@@ -1039,10 +1058,11 @@ int ftmpc_last_kernel_ms(ftmpc_handle* h, float ms[6]) {
     return FTMPC_OK;
 }
 
-static const char* const k_kernel_names[6] = {"ftmpc_linearize_kernel", "ftmpc_solve_f32_kernel<8>", "ftmpc_solve_f32_kernel<9>",
-                                              "ftmpc_solve_f32_kernel<10>", "ftmpc_solve_f64_kernel", "ftmpc_solve_ws32_kernel | ftmpc_solve_wg32_kernel<15>"};
+static const char* const k_kernel_names[FTMPC_KERNEL_SLOTS] = {"ftmpc_linearize_kernel", "ftmpc_solve_f32_kernel<8>", "ftmpc_solve_f32_kernel<9>",
+                                                                "ftmpc_solve_f32_kernel<10>", "ftmpc_solve_f64_kernel", "ftmpc_solve_ws32_kernel | ftmpc_solve_wg32_kernel<15>",
+                                                                "ftmpc_solve_ws64_kernel"};
 
-const char* ftmpc_kernel_name(int32_t slot) { return (slot >= 0 && slot < 6) ? k_kernel_names[slot] : ""; }
+const char* ftmpc_kernel_name(int32_t slot) { return (slot >= 0 && slot < FTMPC_KERNEL_SLOTS) ? k_kernel_names[slot] : ""; }
 
 int ftmpc_debug_build_qp(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, const double* stuck,
                          const double* xref, int64_t xref_stride, const double* uref, int64_t uref_stride,
@@ -1061,6 +1081,8 @@ int ftmpc_debug_build_qp(ftmpc_handle* h, int64_t B, const double* x0, const dou
     if ((rc = stage_refs(h, B, xref, xref_stride, uref, uref_stride)) != FTMPC_OK) return rc;
     if (warmU) HIP_TRY(h, hipMemcpyAsync(h->d_warm, warmU, B * N * NT * sizeof(double), hipMemcpyHostToDevice, s));
     if (!h->use_f64) HIP_TRY(h, hipMemsetAsync(h->d_dbgv, 0, (3 * 256 + 4) * sizeof(float), s));
+    if (h->use_ws && h->nb_max > 15)
+        return fail(h, FTMPC_ERR_ARG, "the QP dump needs N * NT <= 240 on the fp32 path (create the handle with dtype FTMPC_DTYPE_F64 for larger shapes)");
     const bool ws_was = h->use_ws;
     h->use_ws = false;     // the dump hook (the condensed thruster-space QP) lives in kernel 7; kernel 8 never forms that matrix
     rc = enqueue(h, B, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, xref_stride, uref ? h->d_uref : nullptr, uref_stride,

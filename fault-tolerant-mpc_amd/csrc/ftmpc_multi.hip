@@ -14,6 +14,8 @@
 #include <mutex>
 #include <thread>
 
+#include <sched.h>
+
 struct ftmpc_multi {
     struct Dev {
         int device = 0;
@@ -29,6 +31,11 @@ struct ftmpc_multi {
                *U = nullptr;
         int32_t *status = nullptr, *iters = nullptr;
         hipStream_t s = nullptr;
+        // pinned staging of the resident upload: two halves, so that the host copy of one piece runs under the DMA of the other
+        void* pin = nullptr;
+        hipEvent_t pin_ev[2] = {nullptr, nullptr};
+        int pin_turn = 0;
+        int cpus_pinned = 0;     // host cores this device's worker thread is bound to (0: affinity left alone)
     };
     ftmpc_config cfg;
     std::vector<Dev> dev;
@@ -46,9 +53,51 @@ namespace {
 
 thread_local std::string g_multi_create_error;
 
+// Binds the calling thread to the host cores nearest `device` (the PCI function's local_cpulist in sysfs, intersected with
+// the cores this process may use); when the two do not meet -- containers often grant cores of one socket only -- the
+// affinity is left alone.  Returns the number of cores bound to.
+int pin_thread_near(int device) {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) return 0;
+    for (char* c = bus; *c; ++c)
+        if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/local_cpulist";
+    FILE* f = std::fopen(path.c_str(), "r");
+    if (!f) return 0;
+    char line[4096] = {0};
+    const bool got = std::fgets(line, (int)sizeof(line), f) != nullptr;
+    std::fclose(f);
+    if (!got) return 0;
+    cpu_set_t allowed, want;
+    CPU_ZERO(&allowed);
+    CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return 0;
+    int n = 0;
+    for (const char* p = line; *p;) {     // "0-15,128-143"
+        char* end = nullptr;
+        const long a = std::strtol(p, &end, 10);
+        if (end == p) break;
+        long b = a;
+        p = end;
+        if (*p == '-') {
+            b = std::strtol(p + 1, &end, 10);
+            p = end;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
+            if (c >= 0 && CPU_ISSET((int)c, &allowed)) {
+                CPU_SET((int)c, &want);
+                ++n;
+            }
+        while (*p == ',' || *p == ' ' || *p == '\n') ++p;
+    }
+    if (n == 0 || sched_setaffinity(0, sizeof(want), &want) != 0) return 0;
+    return n;
+}
+
 void multi_worker(ftmpc_multi* m, int r) {
     ftmpc_multi::Dev& d = m->dev[r];
     (void)hipSetDevice(d.device);
+    d.cpus_pinned = pin_thread_near(d.device);
     uint64_t seen = 0;
     for (;;) {
         std::function<int(ftmpc_multi::Dev&)> fn;
@@ -107,6 +156,29 @@ int dev_grow(ftmpc_multi::Dev& d, T** p, int64_t count) {
         hipError_t e__ = (expr);                                                                  \
         if (e__ != hipSuccess) return dev_fail((d), FTMPC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
     } while (0)
+
+// host -> device copy of a pageable array through the device's pinned staging halves (PIN_HALF bytes each)
+constexpr size_t PIN_HALF = (size_t)8 << 20;
+int dev_upload(ftmpc_multi::Dev& d, void* dst, const void* src, size_t bytes) {
+    if (!d.pin) {
+        DEV_TRY(d, hipHostMalloc(&d.pin, 2 * PIN_HALF, hipHostMallocDefault));
+        DEV_TRY(d, hipEventCreateWithFlags(&d.pin_ev[0], hipEventDisableTiming));
+        DEV_TRY(d, hipEventCreateWithFlags(&d.pin_ev[1], hipEventDisableTiming));
+        DEV_TRY(d, hipEventRecord(d.pin_ev[0], d.s));
+        DEV_TRY(d, hipEventRecord(d.pin_ev[1], d.s));
+    }
+    for (size_t off = 0; off < bytes; off += PIN_HALF) {
+        const size_t cnt = std::min(PIN_HALF, bytes - off);
+        const int t = d.pin_turn;
+        d.pin_turn ^= 1;
+        char* half = static_cast<char*>(d.pin) + (size_t)t * PIN_HALF;
+        DEV_TRY(d, hipEventSynchronize(d.pin_ev[t]));       // the DMA that last read this half is done
+        std::memcpy(half, static_cast<const char*>(src) + off, cnt);
+        DEV_TRY(d, hipMemcpyAsync(static_cast<char*>(dst) + off, half, cnt, hipMemcpyHostToDevice, d.s));
+        DEV_TRY(d, hipEventRecord(d.pin_ev[t], d.s));
+    }
+    return FTMPC_OK;
+}
 
 void shard(int64_t B, int G, int g, int64_t& lo, int64_t& hi) {
     lo = B * g / G;
@@ -167,6 +239,9 @@ int ftmpc_multi_destroy(ftmpc_multi* m) {
         void* ptrs[] = {d.x0, d.ub, d.stuck, d.xref, d.uref, d.warm, d.u0, d.U, d.status, d.iters};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
+        if (d.pin) (void)hipHostFree(d.pin);
+        for (hipEvent_t e : d.pin_ev)
+            if (e) (void)hipEventDestroy(e);
         if (d.s) (void)hipStreamDestroy(d.s);
         if (d.h) (void)ftmpc_destroy(d.h);
         d.h = nullptr;
@@ -186,6 +261,10 @@ int ftmpc_multi_destroy(ftmpc_multi* m) {
 const char* ftmpc_multi_last_error(const ftmpc_multi* m) { return m ? m->err.c_str() : g_multi_create_error.c_str(); }
 
 int32_t ftmpc_multi_device_count(const ftmpc_multi* m) { return m ? (int32_t)m->dev.size() : 0; }
+
+int32_t ftmpc_multi_worker_cpus(const ftmpc_multi* m, int32_t slot) {
+    return (m && slot >= 0 && slot < (int32_t)m->dev.size()) ? m->dev[slot].cpus_pinned : 0;
+}
 
 int ftmpc_multi_shard_bounds(const ftmpc_multi* m, int64_t B, int32_t slot, int64_t* lo, int64_t* hi) {
     if (!m || !lo || !hi || slot < 0 || slot >= (int32_t)m->dev.size() || B < 0) return FTMPC_ERR_ARG;
@@ -246,6 +325,7 @@ int ftmpc_multi_upload(ftmpc_multi* m, int64_t B, const double* x0, const double
         if (n <= 0) return FTMPC_OK;
         int rc;
         if (n > d.cap) {
+            d.cap = 0;   // nothing is usable until every buffer below exists again (a failure part-way must not leave a stale capacity)
             if ((rc = dev_grow(d, &d.x0, n * 13)) || (rc = dev_grow(d, &d.ub, n * NT)) || (rc = dev_grow(d, &d.stuck, n * NT)) ||
                 (rc = dev_grow(d, &d.warm, n * nw)) || (rc = dev_grow(d, &d.u0, n * NT)) || (rc = dev_grow(d, &d.U, n * nw)) ||
                 (rc = dev_grow(d, &d.status, n)) || (rc = dev_grow(d, &d.iters, n)))
@@ -255,20 +335,24 @@ int ftmpc_multi_upload(ftmpc_multi* m, int64_t B, const double* x0, const double
         const int64_t nxr = xref_stride == 0 ? 9 * (N + 1) : n * xref_stride;
         const int64_t nur = !uref ? 0 : (uref_stride == 0 ? 6 * (N + 1) : n * uref_stride);
         if (nxr > d.cap_xr) {
+            d.cap_xr = 0;
             if ((rc = dev_grow(d, &d.xref, nxr))) return rc;
             d.cap_xr = nxr;
         }
         if (nur > d.cap_ur) {
+            d.cap_ur = 0;
             if ((rc = dev_grow(d, &d.uref, nur))) return rc;
             d.cap_ur = nur;
         }
         if ((rc = ftmpc_reserve(d.h, n)) != FTMPC_OK) return dev_fail(d, rc, ftmpc_last_error(d.h));
-        DEV_TRY(d, hipMemcpyAsync(d.x0, x0 + lo * 13, (size_t)n * 13 * 8, hipMemcpyHostToDevice, d.s));
-        DEV_TRY(d, hipMemcpyAsync(d.ub, ub + lo * NT, (size_t)n * NT * 8, hipMemcpyHostToDevice, d.s));
-        DEV_TRY(d, hipMemcpyAsync(d.stuck, stuck + lo * NT, (size_t)n * NT * 8, hipMemcpyHostToDevice, d.s));
-        DEV_TRY(d, hipMemcpyAsync(d.xref, xref + lo * xref_stride, (size_t)nxr * 8, hipMemcpyHostToDevice, d.s));
-        if (uref) DEV_TRY(d, hipMemcpyAsync(d.uref, uref + lo * uref_stride, (size_t)nur * 8, hipMemcpyHostToDevice, d.s));
-        if (warmU) DEV_TRY(d, hipMemcpyAsync(d.warm, warmU + lo * nw, (size_t)n * nw * 8, hipMemcpyHostToDevice, d.s));
+        // the caller's arrays are pageable: through the pinned halves, so that the DMA engine streams instead of the
+        // runtime's own bounce copies
+        if ((rc = dev_upload(d, d.x0, x0 + lo * 13, (size_t)n * 13 * 8)) || (rc = dev_upload(d, d.ub, ub + lo * NT, (size_t)n * NT * 8)) ||
+            (rc = dev_upload(d, d.stuck, stuck + lo * NT, (size_t)n * NT * 8)) ||
+            (rc = dev_upload(d, d.xref, xref + lo * xref_stride, (size_t)nxr * 8)))
+            return rc;
+        if (uref && (rc = dev_upload(d, d.uref, uref + lo * uref_stride, (size_t)nur * 8))) return rc;
+        if (warmU && (rc = dev_upload(d, d.warm, warmU + lo * nw, (size_t)n * nw * 8))) return rc;
         DEV_TRY(d, hipStreamSynchronize(d.s));
         return FTMPC_OK;
     });
@@ -317,11 +401,11 @@ int ftmpc_multi_set_profiling(ftmpc_multi* m, int32_t enabled) {
     return FTMPC_OK;
 }
 
-int ftmpc_multi_last_kernel_ms(ftmpc_multi* m, int32_t slot, float ms[6]) {
+int ftmpc_multi_last_kernel_ms(ftmpc_multi* m, int32_t slot, float* ms, int32_t n_slots) {
     if (!m || !ms || slot < 0 || slot >= (int32_t)m->dev.size()) return FTMPC_ERR_ARG;
     return multi_run(m, [=](ftmpc_multi::Dev& d) -> int {
         if ((int)(&d - m->dev.data()) != slot) return FTMPC_OK;
-        const int rc = ftmpc_last_kernel_ms(d.h, ms);
+        const int rc = ftmpc_last_kernel_ms(d.h, ms, n_slots);
         return rc == FTMPC_OK ? rc : dev_fail(d, rc, ftmpc_last_error(d.h));
     });
 }

@@ -27,11 +27,12 @@ namespace ftmpc {
 namespace wsk {
 constexpr int WG = 256;
 constexpr int NWAVE = 4;
-constexpr int NTP = 256;     // thruster-space variables, one per thread: N * na <= 256
+// thruster-space variables per thread: one up to N = 16 (six tiles a side: N * NT <= 256), two beyond (eight tiles: N * NT <= 336)
+__host__ __device__ constexpr int nvt_of(int nbmax) { return nbmax <= 6 ? 1 : 2; }
 using wgk::ntiles;
 // per-workgroup global slot (4-byte words): float64 scratch of the reference gradient | E panels N x 9 x NPAD | Hessian tiles
-__host__ __device__ constexpr int64_t slot_e_off(int N) { return ((wgk::slot_f64_words(NTP, N) + 255) / 256) * 256; }
-__host__ __device__ constexpr int64_t slot_h_off(int nbmax, int N) { return slot_e_off(N) + (int64_t)N * 9 * 16 * nbmax; }
+__host__ __device__ constexpr int64_t slot_e_off(int nbmax, int N) { return ((wgk::slot_f64_words(WG * nvt_of(nbmax), N) + 255) / 256) * 256; }
+__host__ __device__ constexpr int64_t slot_h_off(int nbmax, int N) { return slot_e_off(nbmax, N) + (int64_t)N * 9 * 16 * nbmax; }
 __host__ __device__ constexpr int64_t slot_words(int nbmax, int N) { return slot_h_off(nbmax, N) + (int64_t)ntiles(nbmax) * 256; }
 }  // namespace wsk
 
@@ -40,6 +41,8 @@ __global__ void __launch_bounds__(wsk::WG) __attribute__((amdgpu_waves_per_eu((N
     using namespace wsk;
     constexpr int NPAD = 16 * NB;
     constexpr int NT_ALL = ntiles(NB);
+    constexpr int NVT = nvt_of(NB);        // thruster-space variables per thread: variable e = v * WG + tid
+    constexpr int NTP = WG * NVT;
     const SolveParams& P = Q.base;
     __shared__ __attribute__((aligned(16))) float Tl[(NT_ALL + NB) * 256];   // factor of K (diagonal slot: W') | W of every diagonal block
     __shared__ __attribute__((aligned(16))) float Lu[NT_ALL * 256];           // L (H_w = L L'), tiles L_IJ in accumulator layout
@@ -75,7 +78,7 @@ __global__ void __launch_bounds__(wsk::WG) __attribute__((amdgpu_waves_per_eu((N
     const float mu_stop = (float)C.mu_stop;
     float* const slot = Q.slot + (int64_t)blockIdx.x * Q.slot_words;
     double* const sbuf = reinterpret_cast<double*>(slot);
-    float* const Eall = slot + slot_e_off(N);
+    float* const Eall = slot + slot_e_off(NB, N);
     float* const Hs = slot + slot_h_off(NB, N);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -174,19 +177,27 @@ __global__ void __launch_bounds__(wsk::WG) __attribute__((amdgpu_waves_per_eu((N
                 Td[a] = s_Da[(3 + a) * MAX_NT + acol];
             }
         }
-        // thruster-space role: variable (stage tk, healthy thruster ta)
-        const bool tvalid = tid < nt;
-        const int tk = tvalid ? tid / nat : 0;
-        const int ta = tvalid ? tid - tk * nat : 0;
-        float ubar = 0.f, ubv = 1.f;
-        if (tvalid) {
-            const int t = s_act[ta];
-            ubv = (float)P.ub[inst * NT + t];
-            if (P.warmU) ubar = fminf(fmaxf((float)P.warmU[(inst * N + tk) * NT + t], 0.f), ubv);
-        }
-        float dat[6];    // column ta of D_a
+        // thruster-space role: variables e = v * WG + tid = (stage tk, healthy thruster ta)
+        bool tvalid[NVT];
+        int tk[NVT], ta[NVT];
+        float ubar[NVT], ubv[NVT];
+        float dat[NVT][6];    // column ta of D_a
 #pragma unroll
-        for (int g = 0; g < 6; ++g) dat[g] = tvalid ? s_DaT[g * MAX_NT + ta] : 0.f;
+        for (int v = 0; v < NVT; ++v) {
+            const int e = v * WG + tid;
+            tvalid[v] = e < nt;
+            tk[v] = tvalid[v] ? e / nat : 0;
+            ta[v] = tvalid[v] ? e - tk[v] * nat : 0;
+            ubar[v] = 0.f;
+            ubv[v] = 1.f;
+            if (tvalid[v]) {
+                const int t = s_act[ta[v]];
+                ubv[v] = (float)P.ub[inst * NT + t];
+                if (P.warmU) ubar[v] = fminf(fmaxf((float)P.warmU[(inst * N + tk[v]) * NT + t], 0.f), ubv[v]);
+            }
+#pragma unroll
+            for (int g = 0; g < 6; ++g) dat[v][g] = tvalid[v] ? s_DaT[g * MAX_NT + ta[v]] : 0.f;
+        }
         STAMP(0);
         // ---------------- build: the E panels of every stage go to LDS when they fit (the factor area is idle during the
         // build: N x 9 x npad floats), else to the global slot; two instantiations so that each keeps its address space ----------------
@@ -343,8 +354,14 @@ __global__ void __launch_bounds__(wsk::WG) __attribute__((amdgpu_waves_per_eu((N
         if ((int64_t)N * 9 * npad <= (int64_t)(NT_ALL + NB) * 256) build(std::true_type{});
         else build(std::false_type{});
         if (tid < npad) gwv[tid] = valid ? 2.f * gacc : 0.f;     // wrench-space gradient at the linearisation point
-        const float lo = -ubar, hi = ubv - ubar;
-        float sl = 0.5f * ubv, su = 0.5f * ubv, zl = 0.f, zu = 0.f, grad = 0.f;
+        float lo[NVT], hi[NVT], sl[NVT], su[NVT], zl[NVT], zu[NVT], grad[NVT];
+#pragma unroll
+        for (int v = 0; v < NVT; ++v) {
+            lo[v] = -ubar[v];
+            hi[v] = ubv[v] - ubar[v];
+            sl[v] = su[v] = 0.5f * ubv[v];
+            zl[v] = zu[v] = grad[v] = 0.f;
+        }
         bool keep_l = true, k_in_lds = false;
 
         // the matrix to factorise comes as -M' tiles: H_w from the global slot (once), K = I + L' S L from the factor's own LDS
@@ -478,8 +495,9 @@ __global__ void __launch_bounds__(wsk::WG) __attribute__((amdgpu_waves_per_eu((N
             __syncthreads();
         };
         // ---- wrench image of a thruster-space vector held one per thread: tw = DD v ----
-        auto to_wrench = [&](float v, float* out) {
-            if (tid < NTP) rv[tid] = tvalid ? v : 0.f;
+        auto to_wrench = [&](const float (&x)[NVT], float* out) {
+#pragma unroll
+            for (int v = 0; v < NVT; ++v) rv[v * WG + tid] = tvalid[v] ? x[v] : 0.f;
             __syncthreads();
             if (tid < npad) {
                 float s = 0.f;
@@ -518,15 +536,21 @@ __global__ void __launch_bounds__(wsk::WG) __attribute__((amdgpu_waves_per_eu((N
             __syncthreads();
         };
         // ---- Newton system in thruster space through wrench space: x = Dg^-1 (r - DD' L K^-1 L' DD Dg^-1 r) ----
-        auto ws_solve = [&](float r) -> float {
-            to_wrench(r * rdg[tid & (NTP - 1)], tw);
+        auto ws_solve = [&](const float (&r)[NVT], float (&x)[NVT]) {
+            float t[NVT];
+#pragma unroll
+            for (int v = 0; v < NVT; ++v) t[v] = r[v] * rdg[v * WG + tid];
+            to_wrench(t, tw);
             tri_mv(std::true_type{}, tw, xv);
             solve();
             tri_mv(std::false_type{}, xv, yv);
-            float s = 0.f;
 #pragma unroll
-            for (int g = 0; g < 6; ++g) s += dat[g] * yv[tk * 6 + g];
-            return tvalid ? (r - s) * rdg[tid] : 0.f;
+            for (int v = 0; v < NVT; ++v) {
+                float s = 0.f;
+#pragma unroll
+                for (int g = 0; g < 6; ++g) s += dat[v][g] * yv[tk[v] * 6 + g];
+                x[v] = tvalid[v] ? (r[v] - s) * rdg[v * WG + tid] : 0.f;
+            }
         };
 
         // ---------------- H_w = L L' once: factor, keep L (transposed back out of the factor's tile order) ----------------
@@ -535,10 +559,19 @@ __global__ void __launch_bounds__(wsk::WG) __attribute__((amdgpu_waves_per_eu((N
         factor();
         keep_l = false;
         k_in_lds = true;
-        if (__builtin_amdgcn_readfirstlane(s_flag) == 0) {   // H_w not positive definite in fp32: report, do not iterate
-            for (int i = tid; i < NT; i += WG) P.out_u0[inst * NT + i] = 0.0;
+        if (__builtin_amdgcn_readfirstlane(s_flag) == 0) {   // H_w not positive definite in fp32: report the linearisation point
+            // (FTMPC_STATUS_NUMERIC, include/ftmpc.h: clip(warm start); zero at broken thrusters), do not iterate
+            __syncthreads();
+            float* const ub0 = Tl;
+            for (int i = tid; i < N * NT; i += WG) ub0[i] = 0.f;
+            __syncthreads();
+#pragma unroll
+            for (int v = 0; v < NVT; ++v)
+                if (tvalid[v]) ub0[tk[v] * NT + s_act[ta[v]]] = ubar[v];
+            __syncthreads();
+            for (int i = tid; i < NT; i += WG) P.out_u0[inst * NT + i] = (double)ub0[i];
             if (P.out_U)
-                for (int i = tid; i < N * NT; i += WG) P.out_U[inst * (int64_t)N * NT + i] = 0.0;
+                for (int i = tid; i < N * NT; i += WG) P.out_U[inst * (int64_t)N * NT + i] = (double)ub0[i];
             if (tid == 0) {
                 if (P.status) P.status[inst] = 2;
                 if (P.iters) P.iters[inst] = 0;
@@ -577,17 +610,23 @@ __global__ void __launch_bounds__(wsk::WG) __attribute__((amdgpu_waves_per_eu((N
         // ---------------- interior-point iterations (thruster space) ----------------
         int status = 1, nit = 0;
         bool first = true;
-        int refines_left = (C.mu_refine > 0.0) ? 1 : 0;
-        bool polished = false;
+        // float64 reference gradient: once, when mu falls below mu_refine, for the six-tile instantiation (N <= 16); at EVERY
+        // iterate below mu_refine for the eight-tile one.  The gradient recurrence trusts the Newton identity more than
+        // K^-1 in fp32 deserves on long horizons with ill-conditioned allocation matrices (3e-4 .. 3e-3 f_max on synthetic
+        // vehicles with cond(H) ~ 1e7); refreshed every iteration the worst instance stays below 1e-5 (kernel 8).
+        int refines_left = (C.mu_refine > 0.0) ? ((NB > 6) ? C.max_iters + 1 : 1) : 0;
         float mu_last = 3.0e38f;
         const float inv2n = 1.0f / (float)(2 * nt);
         for (int it = 0; it <= C.max_iters; ++it) {
             __syncthreads();
             const bool do_ref = __builtin_amdgcn_readfirstlane(refines_left > 0 && mu_last < (float)C.mu_refine);
-            const float dcur = tvalid ? ((sl < su) ? lo + sl : hi - su) : 0.f;
-            auto reference_gradient = [&]() {   // float64, structured, at the current iterate: wave 0, the others wait
+            float dcur[NVT];
+#pragma unroll
+            for (int v = 0; v < NVT; ++v) dcur[v] = tvalid[v] ? ((sl[v] < su[v]) ? lo[v] + sl[v] : hi[v] - su[v]) : 0.f;
+            if (do_ref) {   // float64, structured, at the current iterate: wave 0, the others wait
                 __syncthreads();
-                dT[tid] = dcur;
+#pragma unroll
+                for (int v = 0; v < NVT; ++v) dT[v * WG + tid] = dcur[v];
                 __syncthreads();
                 if (wave == 0) {
                     if ((N + 1) * 72 <= (int)sizeof(sSl))
@@ -598,10 +637,9 @@ __global__ void __launch_bounds__(wsk::WG) __attribute__((amdgpu_waves_per_eu((N
                                                   (glb_f64*)(sbuf + NTP + 8 * N), (glb_f64*)sbuf, nat, lane);
                 }
                 __syncthreads();
-                grad = tvalid ? (float)(sbuf[tid] + 2.0 * C.rho * ((double)ubar + (double)dcur)) : 0.f;
-            };
-            if (do_ref) {
-                reference_gradient();
+#pragma unroll
+                for (int v = 0; v < NVT; ++v)
+                    grad[v] = tvalid[v] ? (float)(sbuf[v * WG + tid] + 2.0 * C.rho * ((double)ubar[v] + (double)dcur[v])) : 0.f;
                 --refines_left;
                 STAMP(7);
             } else if (it == 0) {
@@ -639,41 +677,53 @@ __global__ void __launch_bounds__(wsk::WG) __attribute__((amdgpu_waves_per_eu((N
                 __syncthreads();
                 if (tid < npad) yv[tid] = (Tl[tid] + Tl[NPAD + tid]) + (Tl[2 * NPAD + tid] + Tl[3 * NPAD + tid]) + gwv[tid];
                 __syncthreads();
-                float s = 0.f;
 #pragma unroll
-                for (int g = 0; g < 6; ++g) s += dat[g] * yv[tk * 6 + g];
-                grad = tvalid ? s + 2.f * rho * (ubar + dcur) : 0.f;
+                for (int v = 0; v < NVT; ++v) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int g = 0; g < 6; ++g) s += dat[v][g] * yv[tk[v] * 6 + g];
+                    grad[v] = tvalid[v] ? s + 2.f * rho * (ubar[v] + dcur[v]) : 0.f;
+                }
                 STAMP(3);
             }
             if (first) {
-                const float gm = wg_reduce(tvalid ? fabsf(grad) : 0.f, OpMax{});
-                const float wm = wg_reduce(tvalid ? ubv : 0.f, OpMax{});
+                float gm = 0.f, wm = 0.f;
+#pragma unroll
+                for (int v = 0; v < NVT; ++v) {
+                    gm = fmaxf(gm, tvalid[v] ? fabsf(grad[v]) : 0.f);
+                    wm = fmaxf(wm, tvalid[v] ? ubv[v] : 0.f);
+                }
+                gm = wg_reduce(gm, OpMax{});
+                wm = wg_reduce(wm, OpMax{});
                 const float mu0 = fmaxf(0.02f * gm * wm, 1e-3f);
-                zl = tvalid ? mu0 / sl : 0.f;
-                zu = tvalid ? mu0 / su : 0.f;
+#pragma unroll
+                for (int v = 0; v < NVT; ++v) {
+                    zl[v] = tvalid[v] ? mu0 / sl[v] : 0.f;
+                    zu[v] = tvalid[v] ? mu0 / su[v] : 0.f;
+                }
                 first = false;
             }
-            const float mu = wg_reduce(tvalid ? sl * zl + su * zu : 0.f, OpAdd{}) * inv2n;
+            float csum = 0.f;
+#pragma unroll
+            for (int v = 0; v < NVT; ++v) csum += tvalid[v] ? sl[v] * zl[v] + su[v] * zu[v] : 0.f;
+            const float mu = wg_reduce(csum, OpAdd{}) * inv2n;
             mu_last = mu;
             if (__builtin_amdgcn_readfirstlane(!(mu >= mu_stop))) {
-                // Long horizons (the eight-tile instantiation, N = 17..21): polish.  The gradient recurrence trusts the Newton
-                // identity more than K^-1 in fp32 deserves there (kernel 8: 3e-4 .. 3e-3 f_max on ill-conditioned
-                // synthetic vehicles); one more iteration from the float64 reference gradient at the final iterate settles it.
-                if (NB > 6 && !polished && mu == mu && it < C.max_iters && C.mu_refine > 0.0) {
-                    polished = true;
-                    reference_gradient();
-                } else {
-                    status = (mu == mu) ? 0 : 2;
-                    break;
-                }
+                status = (mu == mu) ? 0 : 2;
+                break;
             }
             if (it == C.max_iters) break;
             ++nit;
-            const float rsl = __builtin_amdgcn_rcpf(sl), rsu = __builtin_amdgcn_rcpf(su);
-            const float Sig = tvalid ? zl * rsl + zu * rsu : 0.f;
+            float rsl[NVT], rsu[NVT], Sig[NVT];
             // ---- K = I + L' S L: S blocks, P = S L (into the idle factor area), X' = P' L (as -X' into the Hessian slot) ----
             __syncthreads();
-            rdg[tid] = tvalid ? 1.0f / (2.f * rho + Sig) : 0.f;
+#pragma unroll
+            for (int v = 0; v < NVT; ++v) {
+                rsl[v] = __builtin_amdgcn_rcpf(sl[v]);
+                rsu[v] = __builtin_amdgcn_rcpf(su[v]);
+                Sig[v] = tvalid[v] ? zl[v] * rsl[v] + zu[v] * rsu[v] : 0.f;
+                rdg[v * WG + tid] = tvalid[v] ? 1.0f / (2.f * rho + Sig[v]) : 0.f;
+            }
             __syncthreads();
             for (int idx = tid; idx < N * 21; idx += WG) {          // stage blocks S_k = D_a diag(1 / Dg) D_a'
                 const int k = idx / 21, p = idx - 21 * k;
@@ -753,54 +803,75 @@ __global__ void __launch_bounds__(wsk::WG) __attribute__((amdgpu_waves_per_eu((N
             }
             // predictor: (H + Sig) da = -grad
             STAMP(6);
-            const float da = ws_solve(-grad);
+            float ngrad[NVT], da[NVT];
+#pragma unroll
+            for (int v = 0; v < NVT; ++v) ngrad[v] = -grad[v];
+            ws_solve(ngrad, da);
             STAMP(5);
-            float dzl_a = 0.f, dzu_a = 0.f, ap = 1.f, ad = 1.f;
-            if (tvalid) {
-                dzl_a = -zl - zl * da * rsl;
-                dzu_a = -zu + zu * da * rsu;
-                const float rda = __builtin_amdgcn_rcpf(da);
-                if (da < 0.f) ap = fminf(ap, -sl * rda);
-                if (da > 0.f) ap = fminf(ap, su * rda);
-                if (dzl_a < 0.f) ad = fminf(ad, -zl * __builtin_amdgcn_rcpf(dzl_a));
-                if (dzu_a < 0.f) ad = fminf(ad, -zu * __builtin_amdgcn_rcpf(dzu_a));
+            float dzl_a[NVT], dzu_a[NVT], ap = 1.f, ad = 1.f;
+#pragma unroll
+            for (int v = 0; v < NVT; ++v) {
+                dzl_a[v] = dzu_a[v] = 0.f;
+                if (tvalid[v]) {
+                    dzl_a[v] = -zl[v] - zl[v] * da[v] * rsl[v];
+                    dzu_a[v] = -zu[v] + zu[v] * da[v] * rsu[v];
+                    const float rda = __builtin_amdgcn_rcpf(da[v]);
+                    if (da[v] < 0.f) ap = fminf(ap, -sl[v] * rda);
+                    if (da[v] > 0.f) ap = fminf(ap, su[v] * rda);
+                    if (dzl_a[v] < 0.f) ad = fminf(ad, -zl[v] * __builtin_amdgcn_rcpf(dzl_a[v]));
+                    if (dzu_a[v] < 0.f) ad = fminf(ad, -zu[v] * __builtin_amdgcn_rcpf(dzu_a[v]));
+                }
             }
             ap = wg_reduce(ap, OpMin{});
             ad = wg_reduce(ad, OpMin{});
-            const float mu_aff = wg_reduce(tvalid ? (sl + ap * da) * (zl + ad * dzl_a) + (su - ap * da) * (zu + ad * dzu_a) : 0.f, OpAdd{}) * inv2n;
+            csum = 0.f;
+#pragma unroll
+            for (int v = 0; v < NVT; ++v)
+                csum += tvalid[v] ? (sl[v] + ap * da[v]) * (zl[v] + ad * dzl_a[v]) + (su[v] - ap * da[v]) * (zu[v] + ad * dzu_a[v]) : 0.f;
+            const float mu_aff = wg_reduce(csum, OpAdd{}) * inv2n;
             float sigma = mu_aff / mu;
             sigma = fminf(fmaxf(sigma * sigma * sigma, 0.f), 1.f);
             // corrector
-            float rcl = 0.f, rcu = 0.f, rhs = 0.f;
-            if (tvalid) {
-                rcl = sl * zl + da * dzl_a - sigma * mu;
-                rcu = su * zu - da * dzu_a - sigma * mu;
-                rhs = -(grad - zl + zu) - rcl * rsl + rcu * rsu;
+            float rcl[NVT], rcu[NVT], rhs[NVT], dd[NVT];
+#pragma unroll
+            for (int v = 0; v < NVT; ++v) {
+                rcl[v] = rcu[v] = rhs[v] = 0.f;
+                if (tvalid[v]) {
+                    rcl[v] = sl[v] * zl[v] + da[v] * dzl_a[v] - sigma * mu;
+                    rcu[v] = su[v] * zu[v] - da[v] * dzu_a[v] - sigma * mu;
+                    rhs[v] = -(grad[v] - zl[v] + zu[v]) - rcl[v] * rsl[v] + rcu[v] * rsu[v];
+                }
             }
             STAMP(6);
-            const float dd = ws_solve(rhs);
+            ws_solve(rhs, dd);
             STAMP(5);
-            float dzl = 0.f, dzu = 0.f;
+            float dzl[NVT], dzu[NVT];
             ap = 1e30f;
             ad = 1e30f;
-            if (tvalid) {
-                dzl = (-rcl - zl * dd) * rsl;
-                dzu = (-rcu + zu * dd) * rsu;
-                const float rdd = __builtin_amdgcn_rcpf(dd);
-                if (dd < 0.f) ap = fminf(ap, -sl * rdd);
-                if (dd > 0.f) ap = fminf(ap, su * rdd);
-                if (dzl < 0.f) ad = fminf(ad, -zl * __builtin_amdgcn_rcpf(dzl));
-                if (dzu < 0.f) ad = fminf(ad, -zu * __builtin_amdgcn_rcpf(dzu));
+#pragma unroll
+            for (int v = 0; v < NVT; ++v) {
+                dzl[v] = dzu[v] = 0.f;
+                if (tvalid[v]) {
+                    dzl[v] = (-rcl[v] - zl[v] * dd[v]) * rsl[v];
+                    dzu[v] = (-rcu[v] + zu[v] * dd[v]) * rsu[v];
+                    const float rdd = __builtin_amdgcn_rcpf(dd[v]);
+                    if (dd[v] < 0.f) ap = fminf(ap, -sl[v] * rdd);
+                    if (dd[v] > 0.f) ap = fminf(ap, su[v] * rdd);
+                    if (dzl[v] < 0.f) ad = fminf(ad, -zl[v] * __builtin_amdgcn_rcpf(dzl[v]));
+                    if (dzu[v] < 0.f) ad = fminf(ad, -zu[v] * __builtin_amdgcn_rcpf(dzu[v]));
+                }
             }
             ap = fminf(1.f, 0.9995f * wg_reduce(ap, OpMin{}));
             ad = fminf(1.f, 0.9995f * wg_reduce(ad, OpMin{}));
-            if (tvalid) {
-                grad += ap * (rhs - Sig * dd);   // + ap H dd
-                sl += ap * dd;
-                su -= ap * dd;
-                zl += ad * dzl;
-                zu += ad * dzu;
-            }
+#pragma unroll
+            for (int v = 0; v < NVT; ++v)
+                if (tvalid[v]) {
+                    grad[v] += ap * (rhs[v] - Sig[v] * dd[v]);   // + ap H dd
+                    sl[v] += ap * dd[v];
+                    su[v] -= ap * dd[v];
+                    zl[v] += ad * dzl[v];
+                    zu[v] += ad * dzu[v];
+                }
         }
         STAMP(6);
         // ---------------- outputs ----------------
@@ -808,11 +879,13 @@ __global__ void __launch_bounds__(wsk::WG) __attribute__((amdgpu_waves_per_eu((N
         float* ubuf = Tl;   // N*NT <= 1024 words, zero = broken thruster
         for (int i = tid; i < N * NT; i += WG) ubuf[i] = 0.f;
         __syncthreads();
-        if (tvalid) {
-            float u = (sl < su) ? sl : ubv - su;
-            if (status == 2) u = ubar;
-            ubuf[tk * NT + s_act[ta]] = u;
-        }
+#pragma unroll
+        for (int v = 0; v < NVT; ++v)
+            if (tvalid[v]) {
+                float u = (sl[v] < su[v]) ? sl[v] : ubv[v] - su[v];
+                if (status == 2) u = ubar[v];
+                ubuf[tk[v] * NT + s_act[ta[v]]] = u;
+            }
         __syncthreads();
         if (tid < NT) P.out_u0[inst * NT + tid] = (double)ubuf[tid];
         if (P.out_U)

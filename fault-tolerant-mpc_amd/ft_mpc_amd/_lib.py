@@ -19,13 +19,15 @@ MAX_NT = 16
 MAX_TERM_ROWS = 80
 MAX_HULL_ROWS = 32
 MAX_TCOST = 24
+KERNEL_SLOTS = 7
+KERNEL_AUTO, KERNEL_DENSE = 0, 1
 
 # every symbol include/ftmpc.h declares (tests check the list against the header)
 SYMBOLS = (
     "ftmpc_default_config", "ftmpc_create", "ftmpc_destroy", "ftmpc_last_error", "ftmpc_reserve",
     "ftmpc_solve_batch", "ftmpc_solve_batch_device", "ftmpc_solve_wrench_batch", "ftmpc_eval_cost_batch", "ftmpc_simulate_batch", "ftmpc_allocate_batch", "ftmpc_shift_warm", "ftmpc_set_profiling",
     "ftmpc_last_kernel_ms", "ftmpc_kernel_name", "ftmpc_debug_build_qp", "ftmpc_version",
-    "ftmpc_multi_create", "ftmpc_multi_destroy", "ftmpc_multi_last_error", "ftmpc_multi_device_count",
+    "ftmpc_multi_create", "ftmpc_multi_destroy", "ftmpc_multi_last_error", "ftmpc_multi_device_count", "ftmpc_multi_worker_cpus",
     "ftmpc_multi_shard_bounds", "ftmpc_multi_solve_batch", "ftmpc_multi_upload", "ftmpc_multi_step",
     "ftmpc_multi_download", "ftmpc_multi_set_profiling", "ftmpc_multi_last_kernel_ms",
 )
@@ -40,7 +42,7 @@ class FtmpcError(RuntimeError):
 class ftmpc_config(C.Structure):
     _fields_ = [
         ("N", C.c_int32), ("NT", C.c_int32), ("dtype", C.c_int32), ("max_iters", C.c_int32),
-        ("device_id", C.c_int32), ("reserved0", C.c_int32),
+        ("device_id", C.c_int32), ("struct_size", C.c_int32),
         ("dt", C.c_double), ("mass", C.c_double), ("J", C.c_double * 9),
         ("D", C.c_double * (6 * MAX_NT)), ("Q", C.c_double * 9), ("R", C.c_double * 6),
         ("P", C.c_double * 81), ("r", C.c_double * 3), ("f_virt", C.c_double * 3),
@@ -51,6 +53,7 @@ class ftmpc_config(C.Structure):
         ("tc_poly_coef", C.c_double * MAX_TCOST), ("tc_poly_exp", C.c_int32 * (MAX_TCOST * 9)),
         ("tc_root_coef", C.c_double * MAX_TCOST), ("tc_root_eps", C.c_double * MAX_TCOST), ("tc_root_pow", C.c_double * MAX_TCOST),
         ("tc_root_exp", C.c_int32 * (MAX_TCOST * 9)), ("tc_const", C.c_double),
+        ("kernel_select", C.c_int32), ("stage_chunks", C.c_int32), ("lin_split_max", C.c_int64),
     ]
 
 
@@ -97,7 +100,7 @@ def load_library() -> C.CDLL:
     lib.ftmpc_allocate_batch.argtypes = [vp, C.c_int64, dp, dp, dp, ip, ip]
     lib.ftmpc_shift_warm.argtypes = [C.c_int64, C.c_int32, C.c_int32, dp]
     lib.ftmpc_set_profiling.argtypes = [vp, C.c_int32]
-    lib.ftmpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.ftmpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_int32]
     lib.ftmpc_kernel_name.argtypes = [C.c_int32]
     lib.ftmpc_kernel_name.restype = C.c_char_p
     lib.ftmpc_debug_build_qp.argtypes = [vp, C.c_int64, dp, dp, dp, dp, C.c_int64, dp, C.c_int64, dp, C.c_int64,
@@ -115,10 +118,12 @@ def load_library() -> C.CDLL:
     lib.ftmpc_multi_step.argtypes = [vp, C.c_int32, C.c_int32]
     lib.ftmpc_multi_download.argtypes = [vp, dp, dp, ip, ip]
     lib.ftmpc_multi_set_profiling.argtypes = [vp, C.c_int32]
-    lib.ftmpc_multi_last_kernel_ms.argtypes = [vp, C.c_int32, C.POINTER(C.c_float)]
+    lib.ftmpc_multi_last_kernel_ms.argtypes = [vp, C.c_int32, C.POINTER(C.c_float), C.c_int32]
+    lib.ftmpc_multi_worker_cpus.argtypes = [vp, C.c_int32]
+    lib.ftmpc_multi_worker_cpus.restype = C.c_int32
     for name in SYMBOLS:
         if name not in ("ftmpc_last_error", "ftmpc_kernel_name", "ftmpc_version", "ftmpc_multi_last_error",
-                        "ftmpc_multi_device_count"):
+                        "ftmpc_multi_device_count", "ftmpc_multi_worker_cpus"):
             getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib

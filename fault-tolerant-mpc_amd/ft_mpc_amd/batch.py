@@ -43,6 +43,12 @@ class MPCConfig:
     # TerminalIngredients object, or True for the shipped config/terminal.yaml.  Every QP then carries its exact
     # gradient at the linearisation point and eval_cost includes it (see BatchedMPC.solve_sqp).
     terminal_cost: object = None
+    # implementation switches (include/ftmpc.h ftmpc_config; diagnostics and A/B runs): "auto" | "dense" (Newton systems
+    # always in the thruster variables, never through the wrench-space form), the batch size up to which the linearisation
+    # is split by tangent direction (0: library default, < 0: never) and the staging ranges of the host-buffer entry
+    kernel_select: str = "auto"
+    lin_split_max: int = 0
+    stage_chunks: int = 0
 
 
 def _ptr(a, ct=C.c_double):
@@ -72,6 +78,10 @@ class BatchedMPC:
         if cfg.dtype not in ("f32", "f64"):
             raise ValueError("dtype must be 'f32' or 'f64'")
         c.dtype = 1 if cfg.dtype == "f64" else 0
+        if cfg.kernel_select not in ("auto", "dense"):
+            raise ValueError("kernel_select must be 'auto' or 'dense'")
+        c.kernel_select = _lib.KERNEL_DENSE if cfg.kernel_select == "dense" else _lib.KERNEL_AUTO
+        c.lin_split_max, c.stage_chunks = int(cfg.lin_split_max), int(cfg.stage_chunks)
         c.J[:] = list(_f64(cfg.J, 9))
         D = cfg.D
         if D is None:
@@ -390,9 +400,9 @@ class BatchedMPC:
 
     def last_kernel_ms(self):
         """{kernel name: device ms} of the last profiled solve (kernels that were launched)."""
-        ms = (C.c_float * 6)()
-        self._check(self.lib.ftmpc_last_kernel_ms(self._h, ms))
-        return {self.kernel_name(k): float(ms[k]) for k in range(6) if ms[k] > 0}
+        ms = (C.c_float * _lib.KERNEL_SLOTS)()
+        self._check(self.lib.ftmpc_last_kernel_ms(self._h, ms, _lib.KERNEL_SLOTS))
+        return {self.kernel_name(k): float(ms[k]) for k in range(_lib.KERNEL_SLOTS) if ms[k] > 0}
 
     # -- test hook ----------------------------------------------------------------------
     def debug_build_qp(self, x0, ub, stuck, xref, inst, uref=None, warmU=None):

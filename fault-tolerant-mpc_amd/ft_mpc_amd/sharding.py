@@ -148,9 +148,14 @@ class MultiGPUMPC:
 
     def last_kernel_ms(self, slot=0):
         C = self._C
-        ms = (C.c_float * 6)()
-        self._check(self.lib.ftmpc_multi_last_kernel_ms(self._h, int(slot), ms))
-        return {self.lib.ftmpc_kernel_name(k).decode(): float(ms[k]) for k in range(6) if ms[k] > 0}
+        from . import _lib
+        ms = (C.c_float * _lib.KERNEL_SLOTS)()
+        self._check(self.lib.ftmpc_multi_last_kernel_ms(self._h, int(slot), ms, _lib.KERNEL_SLOTS))
+        return {self.lib.ftmpc_kernel_name(k).decode(): float(ms[k]) for k in range(_lib.KERNEL_SLOTS) if ms[k] > 0}
+
+    def worker_cpus(self, slot=0):
+        """Host cores the worker thread of device slot `slot` is bound to (0: affinity left alone)."""
+        return int(self.lib.ftmpc_multi_worker_cpus(self._h, int(slot)))
 
 
 def solve_multi_gpu(cfg, x0, ub, stuck, xref, devices=None, **kw):

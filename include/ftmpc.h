@@ -72,7 +72,9 @@ typedef struct ftmpc_config {
     int32_t dtype;      /* FTMPC_DTYPE_F32 | FTMPC_DTYPE_F64 : arithmetic of the IPM/KKT solve */
     int32_t max_iters;  /* IPM iteration cap (fixed upper bound; early exit at mu_stop) */
     int32_t device_id;  /* HIP device ordinal */
-    int32_t reserved0;
+    int32_t struct_size; /* sizeof(ftmpc_config) of the header the caller was built against; ftmpc_default_config fills it and
+                            ftmpc_create refuses any other value (FTMPC_ERR_ARG), so a caller built against an older, shorter
+                            struct is told instead of being read past its end */
     double dt;
     double mass;
     double J[9];
@@ -111,11 +113,27 @@ typedef struct ftmpc_config {
     double tc_root_pow[FTMPC_MAX_TCOST_TERMS];
     int32_t tc_root_exp[FTMPC_MAX_TCOST_TERMS * FTMPC_NOPT];
     double tc_const;
+    /*
+     * Implementation switches (diagnostics and A/B runs; 0 = the library's choice everywhere).  They live here, per handle:
+     * the library reads no environment variable and keeps no process-global state.
+     *   kernel_select   FTMPC_KERNEL_AUTO | FTMPC_KERNEL_DENSE: with DENSE the Newton systems are always factorised in the
+     *                   thruster variables (kernel 7 / the dense float64 kernel) even where the library would go through
+     *                   the 6N-variable wrench-space form (kernel 8 / its float64 sibling)
+     *   lin_split_max   batch size up to which the linearisation is split by tangent direction (0: library default 8192;
+     *                   < 0: never split)
+     *   stage_chunks    ranges the host-buffer entry point stages a batch in (0: whole blocks of 65 536 instances; 1..8)
+     */
+    int32_t kernel_select;
+    int32_t stage_chunks;
+    int64_t lin_split_max;
 } ftmpc_config;
+
+#define FTMPC_KERNEL_AUTO 0
+#define FTMPC_KERNEL_DENSE 1
 
 typedef struct ftmpc_handle ftmpc_handle;
 
-/* Fills *cfg with the reference constants for (N, NT).  NT==16 gets the reference D
+/* Fills *cfg with the reference constants for (N, NT) and struct_size.  NT==16 gets the reference D
  * (sys_model.py:73-123); any other NT leaves D zero for the caller to fill. */
 int ftmpc_default_config(ftmpc_config* cfg, int32_t N, int32_t NT);
 
@@ -254,14 +272,15 @@ int ftmpc_simulate_batch(ftmpc_handle* h, int64_t B, int32_t T, double* x, const
 
 /* Per-kernel device timing of the LAST solve call, measured with hipEvents on the launch
  * stream when enabled.  ms[slot] is the duration of kernel slot `slot` (0 when that kernel was
- * not launched); ftmpc_kernel_name(slot) is the kernel's name as it appears in rocprofv3
- * traces:  0 linearise, 1..3 condense+IPM fp32 (one wave per instance) for n <= 128 / 144 / 160,
- * 4 condense+IPM fp64 (workgroup per instance, general n), 5 condense+IPM fp32 with the factor in LDS (workgroup per
- * instance, 160 < n <= 240): ftmpc_solve_ws32_kernel (Newton systems through the 6N-variable wrench-space form) when
- * N*NT <= 256 and N <= 16 (N <= 21 with FTMPC_WS=1), else -- or with FTMPC_WS=0 in the environment -- the dense ftmpc_solve_wg32_kernel<15>
- * (the slot reports both names). */
+ * not launched), for slot < min(n_slots, FTMPC_KERNEL_SLOTS); ftmpc_kernel_name(slot) is the kernel's name as it appears
+ * in rocprofv3 traces:  0 linearise, 1..3 condense+IPM fp32 (one wave per instance) for n <= 128 / 144 / 160,
+ * 4 condense+IPM fp64, dense (workgroup per instance, general n), 5 condense+IPM fp32, workgroup per instance, for
+ * 160 < N*NT: ftmpc_solve_ws32_kernel (Newton systems through the 6N-variable wrench-space form, N <= 21 and N*NT <= 512)
+ * or, with kernel_select = FTMPC_KERNEL_DENSE and N*NT <= 240, the dense ftmpc_solve_wg32_kernel<15> (the slot reports
+ * both names), 6 condense+IPM fp64 through the wrench-space form (ftmpc_solve_ws64_kernel, 6 N <= 256). */
+#define FTMPC_KERNEL_SLOTS 7
 int ftmpc_set_profiling(ftmpc_handle* h, int32_t enabled);
-int ftmpc_last_kernel_ms(ftmpc_handle* h, float ms[6]);
+int ftmpc_last_kernel_ms(ftmpc_handle* h, float* ms, int32_t n_slots);
 const char* ftmpc_kernel_name(int32_t slot);
 
 /*
@@ -297,6 +316,9 @@ int ftmpc_multi_create(const ftmpc_config* cfg, const int32_t* device_ids, int32
 int ftmpc_multi_destroy(ftmpc_multi* m);
 const char* ftmpc_multi_last_error(const ftmpc_multi* m); /* m may be NULL: last create error */
 int32_t ftmpc_multi_device_count(const ftmpc_multi* m);
+/* host cores the worker thread of device slot `slot` is bound to: the cores nearest its GPU (sysfs local_cpulist of the PCI
+ * function) that the process may use; 0 when the two sets do not meet and the affinity was left alone */
+int32_t ftmpc_multi_worker_cpus(const ftmpc_multi* m, int32_t slot);
 int ftmpc_multi_shard_bounds(const ftmpc_multi* m, int64_t B, int32_t slot, int64_t* lo, int64_t* hi);
 int ftmpc_multi_solve_batch(ftmpc_multi* m, int64_t B,
                             const double* x0, const double* ub, const double* stuck,
@@ -314,7 +336,7 @@ int ftmpc_multi_step(ftmpc_multi* m, int32_t steps, int32_t keep_U);
 int ftmpc_multi_download(ftmpc_multi* m, double* out_u0, double* out_U, int32_t* status, int32_t* iters);
 /* per-kernel device timing of device slot `slot` (see ftmpc_set_profiling / ftmpc_last_kernel_ms) */
 int ftmpc_multi_set_profiling(ftmpc_multi* m, int32_t enabled);
-int ftmpc_multi_last_kernel_ms(ftmpc_multi* m, int32_t slot, float ms[6]);
+int ftmpc_multi_last_kernel_ms(ftmpc_multi* m, int32_t slot, float* ms, int32_t n_slots);
 
 /* Library/ABI version: major*10000 + minor*100 + patch. */
 int32_t ftmpc_version(void);

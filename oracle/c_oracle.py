@@ -130,3 +130,40 @@ def plant_step(qcfg, x, u, ub, stuck):
     xx, uu, bb, ss = a(x), a(u), a(ub), a(stuck)
     f(C.byref(c), _p(xx), _p(uu), _p(bb), _p(ss), _p(xn))
     return xn
+
+
+def solve_batch_complete(qcfg, x0, ub, stuck, xref, uref=None, warmU=None, nthreads=1, max_iters=60, mu_stop=1e-13):
+    """A reference for EVERY instance of the batch (the parity tests must not drop the ones this port's interior-point
+    iteration does not finish in `max_iters`): stragglers get 400 iterations, and whatever is still not converged is
+    solved by the independent exact solver (BVLS on the same condensed QP, oracle/qp_oracle.py:solve_exact).
+    Returns the dict of solve_batch plus `how` [B]: 0 = first pass, 1 = long pass, 2 = BVLS."""
+    from . import qp_oracle as qo
+    x0 = np.ascontiguousarray(x0, float).reshape(-1, 13)
+    B = x0.shape[0]
+    N, NT = qcfg.N, qcfg.NT
+    ub = np.ascontiguousarray(ub, float).reshape(B, NT)
+    stuck = np.ascontiguousarray(stuck, float).reshape(B, NT)
+    W = None if warmU is None else np.ascontiguousarray(warmU, float).reshape(B, N, NT)
+    ref = solve_batch(qcfg, x0, ub, stuck, xref, uref=uref, warmU=None if W is None else W.copy(), max_iters=max_iters,
+                      mu_stop=mu_stop, nthreads=nthreads)
+    how = np.zeros(B, np.int32)
+    xr = np.asarray(xref, float)
+    per_x = xr.shape != (9, N + 1)
+    ur = None if uref is None else np.asarray(uref, float)
+    per_u = ur is not None and ur.shape != (6, N + 1)
+    todo = np.flatnonzero(ref["status"] != 0)
+    if todo.size:
+        sub = solve_batch(qcfg, x0[todo], ub[todo], stuck[todo], xr.reshape(B, -1)[todo] if per_x else xr,
+                          uref=None if ur is None else (ur.reshape(B, -1)[todo] if per_u else ur),
+                          warmU=None if W is None else W[todo].copy(), max_iters=400, mu_stop=mu_stop, nthreads=nthreads)
+        for k in ("u0", "U", "status", "iters"):
+            ref[k][todo] = sub[k]
+        how[todo] = 1
+    for b in np.flatnonzero(ref["status"] != 0):
+        xb = xr.reshape(B, -1)[b].reshape(9, N + 1, order="F") if per_x else xr
+        ub_ = None if ur is None else (ur.reshape(B, -1)[b].reshape(6, N + 1, order="F") if per_u else ur)
+        u0, U, _ = qo.solve_instance(qcfg, x0[b], ub[b], stuck[b], xb, uref=ub_, warmU=None if W is None else W[b], exact=True)
+        ref["u0"][b], ref["U"][b], ref["status"][b] = u0, U, 0
+        how[b] = 2
+    ref["how"] = how
+    return ref

@@ -2,8 +2,8 @@
 import sys, time
 sys.path.insert(0,'/root/repo/fault-tolerant-mpc_amd'); sys.path.insert(0,'/root/repo')
 import numpy as np, torch, ft_mpc_amd
-def run(name,B,N,NT,nf,dtype,seed,reps=3):
-    mpc=ft_mpc_amd.BatchedMPC(N=N,NT=NT,dtype=dtype)
+def run(name,B,N,NT,nf,dtype,seed,reps=3,sel="auto"):
+    mpc=ft_mpc_amd.BatchedMPC(N=N,NT=NT,dtype=dtype,kernel_select=sel)
     x0,ub,stuck,xref=ft_mpc_amd.make_synthetic_batch(B,N,NT,nf,seed)
     dev=torch.device('cuda:0'); t=lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     dx0,dub,dst,dxr=t(x0),t(ub),t(stuck),t(xref.reshape(-1,order='F'))
@@ -24,4 +24,8 @@ run("cfg4 shard (32768/GPU)",32768,20,8,2,"f32",1004)
 run("reference vehicle N=15 NT=16 2f (fp32 workgroup kernel)",4096,15,16,2,"f32",1011)
 run("reference vehicle, nominal (n=240)",4096,15,16,0,"f32",1012)
 run("reference vehicle N=15 NT=16 2f",4096,15,16,2,"f64",1011)
-run("cfg5 shard (2048/GPU) N=40 NT=16",2048,40,16,2,"f64",1005)
+run("cfg5 shard (2048/GPU) N=40 NT=16 (wrench-space f64)",2048,40,16,2,"f64",1005)
+run("cfg5 shard, dense f64 kernel",2048,40,16,2,"f64",1005,sel="dense")
+run("N=20 NT=16 2f fp32 (kernel 8, two variables per thread)",4096,20,16,2,"f32",1013)
+run("N=20 NT=16 nominal fp32",4096,20,16,0,"f32",1014)
+run("N=20 NT=16 2f f64 dense (what it ran on before)",2048,20,16,2,"f64",1013,sel="dense")

@@ -13,10 +13,9 @@ for b in range(B):
 W=np.ascontiguousarray(rng.uniform(0,0.3,(B,N,NT))*ub[:,None,:])
 ref=co.solve_batch(cfg,x0,ub,stuck,xref,warmU=W.copy(),nthreads=8,max_iters=60,mu_stop=1e-13)
 ok=ref['status']==0
-for ws in ('1','0'):
-    os.environ['FTMPC_WS']=ws
+for ws in ('auto','dense'):
     for dt in ('f32','f64'):
-        m=ft_mpc_amd.BatchedMPC(ft_mpc_amd.MPCConfig(N=N,NT=NT,D=D,dtype=dt))
+        m=ft_mpc_amd.BatchedMPC(ft_mpc_amd.MPCConfig(N=N,NT=NT,D=D,dtype=dt,kernel_select=ws))
         out=m.solve(x0,ub,stuck,xref.reshape(-1,order='F'),warmU=W.copy(),return_U=True)
         e=np.abs(out['u0']-ref['u0']).max(axis=1)/3.4
         print('ws',ws,dt,'status',np.bincount(out['status'],minlength=3),'err max %.2e p90 %.2e med %.2e'%(e[ok].max(),np.percentile(e[ok],90),np.median(e[ok])),'iters',out['iters'].mean(), 'worst',int(e.argmax()), 'oracle iters worst', ref['iters'][e.argmax()], out['iters'][e.argmax()])

@@ -59,3 +59,31 @@ def test_create_fails_loudly_without_gpu():
     with pytest.raises(ft_mpc_amd.FtmpcError) as e:
         ft_mpc_amd.BatchedMPC(N=20, NT=8)
     assert e.value.code == -3 and "no CPU fallback" in str(e.value)
+
+
+def test_config_struct_layout_matches_the_header_and_guards_the_abi(tmp_path):
+    """The ctypes mirror has the size and the field offsets a C compiler gives include/ftmpc.h; ftmpc_default_config
+    stamps that size into struct_size and ftmpc_create refuses any other value BEFORE it looks at a device (so a caller
+    built against an older, shorter struct is told instead of being read past its end)."""
+    import subprocess
+    from ft_mpc_amd import _lib
+    src = tmp_path / "layout.c"
+    fields = ["N", "struct_size", "dt", "D", "P", "mu_stop", "terminal_set", "term_A", "tc_npoly", "tc_root_exp", "tc_const",
+              "kernel_select", "stage_chunks", "lin_split_max"]
+    body = "".join(f'printf("{f} %zu\\n", offsetof(ftmpc_config, {f}));' for f in fields)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ftmpc.h"\nint main(void){printf("sizeof %zu\\n", sizeof(ftmpc_config));'
+                   + body + "return 0;}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", str(ROOT / "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    assert int(got["sizeof"]) == C.sizeof(_lib.ftmpc_config)
+    for f in fields:
+        assert int(got[f]) == getattr(_lib.ftmpc_config, f).offset, f
+    lib = _lib.load_library()
+    c = _lib.ftmpc_config()
+    assert lib.ftmpc_default_config(C.byref(c), 20, 8) == 0
+    assert c.struct_size == C.sizeof(_lib.ftmpc_config) and c.kernel_select == 0 and c.lin_split_max == 0 and c.stage_chunks == 0
+    h = C.c_void_p()
+    c.struct_size = 0                      # what a caller built against the round-2 header (reserved0 = 0) would pass
+    assert lib.ftmpc_create(C.byref(c), C.byref(h)) == -1 and not h.value
+    assert b"struct_size" in lib.ftmpc_last_error(None)

@@ -26,6 +26,7 @@
 #include "ftmpc_solve_f64.hip"
 #include "ftmpc_solve_wg.hip"
 #include "ftmpc_solve_ws.hip"
+#include "ftmpc_solve_ws64.hip"
 #include "ftmpc_sim.hip"
 #include "ftmpc_alloc.hip"
 
@@ -35,6 +36,7 @@ using ftmpc::SolveParams;
 using ftmpc::Solve64Params;
 using ftmpc::TermCost;
 using ftmpc::SolveWgParams;
+using ftmpc::SolveWs64Params;
 
 static thread_local std::string g_create_error;
 
@@ -84,6 +86,11 @@ struct ftmpc_handle {
     float* wg_slot = nullptr;
     int grid_wg = 0;
     int64_t wg_slot_words = 0;
+    // float64 through the wrench-space form (kernel 9): 6 N <= 256, N * NT <= 768, ten or more thrusters
+    bool use_ws64 = false;
+    int ws64_nvt = 1, grid_ws64 = 0;
+    double* ws64_slot = nullptr;
+    int64_t ws64_slot_doubles = 0;
     // float64 general-size path
     bool use_f64 = false;
     int npad_max = 0;
@@ -213,7 +220,10 @@ int grow(ftmpc_handle* h, T** p, int64_t count) {
     *p = nullptr;
     if (count <= 0) return FTMPC_OK;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(p), (size_t)count * sizeof(T));
-    if (e != hipSuccess) return fail(h, FTMPC_ERR_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();   // the runtime keeps the failure as its "last error": left there, the next launch check would report it
+        return fail(h, FTMPC_ERR_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
     return FTMPC_OK;
 }
 
@@ -271,6 +281,29 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
     sp.dbg_inst = dbg_inst;
     sp.dbg_H = h->d_dbgH;
     sp.dbg_vec = h->d_dbgv;
+    if (h->use_f64 && h->use_ws64) {
+        SolveWs64Params w;
+        sp.hscratch = nullptr;
+        sp.tile_words = 0;
+        sp.qlist = nullptr;
+        sp.qcount = nullptr;
+        sp.qhead = nullptr;
+        sp.dbg_H = reinterpret_cast<float*>(h->d_dbgH64);     // (diagnostic build: phase stamps)
+        w.base = sp;
+        w.slot = h->ws64_slot;
+        w.slot_doubles = h->ws64_slot_doubles;
+        const int grid = (int)std::min<int64_t>(B, h->grid_ws64);
+        if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[12], s));
+        if (h->ws64_nvt == 1) hipLaunchKernelGGL(ftmpc::ftmpc_solve_ws64_kernel<1>, dim3(grid), dim3(ftmpc::ws64k::WG), 0, s, h->dc, w);
+        else hipLaunchKernelGGL(ftmpc::ftmpc_solve_ws64_kernel<3>, dim3(grid), dim3(ftmpc::ws64k::WG), 0, s, h->dc, w);
+        HIP_TRY(h, hipGetLastError());
+        if (h->profiling) {
+            HIP_TRY(h, hipEventRecord(h->ev[13], s));
+            h->ev_used[6] = true;
+            h->ev_valid = true;
+        }
+        return FTMPC_OK;
+    }
     if (h->use_f64) {
         Solve64Params q;
         sp.hscratch = nullptr;
@@ -487,6 +520,12 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
                 cfg->N * cfg->NT <= ftmpc::wsk::WG * ftmpc::wsk::nvt_of(h->ws_nb);
     h->use_f64 = (cfg->dtype == FTMPC_DTYPE_F64) || (h->nb_max > 15 && !h->use_ws);
     h->use_wg = !h->use_f64 && h->nb_max > 10;
+    // float64: through the wrench-space form where the thrusters outnumber the wrench components by enough to pay for the
+    // assembly of K (ten or more thrusters), the wrench-space system fits sixteen tiles a side and three thruster variables
+    // per thread cover N * NT; the terminal-set mode and kernel_select = FTMPC_KERNEL_DENSE keep the dense float64 kernel
+    h->use_ws64 = h->use_f64 && cfg->terminal_set == 0 && cfg->kernel_select != FTMPC_KERNEL_DENSE && 6 * cfg->N <= ftmpc::ws64k::NPADW &&
+                  cfg->N * cfg->NT <= 3 * ftmpc::ws64k::WG && cfg->NT >= 10;
+    h->ws64_nvt = (cfg->N * cfg->NT <= ftmpc::ws64k::WG) ? 1 : 3;
     h->tset = cfg->terminal_set != 0;
     if (h->tset) {
         const char* why = nullptr;
@@ -549,6 +588,14 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
               grow(h, &h->Eall, h->grid64 * h->e_doubles) != FTMPC_OK ||
               grow(h, &h->d_dbgH64, (int64_t)h->npad_max * h->npad_max) != FTMPC_OK ||
               grow(h, &h->d_dbgv64, 3 * (int64_t)h->npad_max + 4) != FTMPC_OK;
+        if (!bad && h->use_ws64) {
+            int per = 0;
+            if (h->ws64_nvt == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_ws64_kernel<1>, ftmpc::ws64k::WG, 0);
+            else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_ws64_kernel<3>, ftmpc::ws64k::WG, 0);
+            h->grid_ws64 = h->num_cu * std::max(1, std::min(per, 2));
+            h->ws64_slot_doubles = ftmpc::ws64k::slot_doubles(cfg->N);
+            bad = grow(h, &h->ws64_slot, (int64_t)h->grid_ws64 * h->ws64_slot_doubles) != FTMPC_OK;
+        }
         if (!bad && h->tset) {
             bad = grow(h, &h->d_term, (int64_t)cfg->term_rows * 10) != FTMPC_OK;
             if (!bad) {
@@ -617,7 +664,7 @@ int ftmpc_destroy(ftmpc_handle* h) {
     void* ptrs[] = {h->rec, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, h->d_uref, h->d_warm, h->d_u0, h->d_U,
                     h->d_status, h->d_iters, h->hs[0], h->hs[1], h->hs[2], h->d_dbgH, h->d_dbgv, h->Hs, h->Ls, h->Eall, h->d_dbgH64, h->d_dbgv64,
                     h->d_atau, h->d_aub, h->d_au, h->d_ast, h->d_ait, h->d_qlist, h->d_qctl, h->d_term, h->d_eN, h->gHs, h->gLs,
-                    h->gEall, h->wg_slot, h->ws_slot, h->d_tcost, h->d_cost, h->d_hullA, h->d_hullb, h->d_warmG, h->d_tau0, h->d_G, h->d_taud, h->d_hullset, h->d_ast2};
+                    h->gEall, h->wg_slot, h->ws_slot, h->ws64_slot, h->d_tcost, h->d_cost, h->d_hullA, h->d_hullb, h->d_warmG, h->d_tau0, h->d_G, h->d_taud, h->d_hullset, h->d_ast2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->pin_in.p) (void)hipHostFree(h->pin_in.p);
@@ -706,7 +753,10 @@ static int pin_grow(ftmpc_handle* h, ftmpc_handle::Pinned& P, size_t bytes) {
     P.bytes = 0;
     const size_t want = bytes + bytes / 8;
     hipError_t e = hipHostMalloc(&P.p, want, hipHostMallocDefault);
-    if (e != hipSuccess) return fail(h, FTMPC_ERR_ALLOC, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(h, FTMPC_ERR_ALLOC, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    }
     P.bytes = want;
     return FTMPC_OK;
 }
@@ -1083,11 +1133,14 @@ int ftmpc_debug_build_qp(ftmpc_handle* h, int64_t B, const double* x0, const dou
     if (!h->use_f64) HIP_TRY(h, hipMemsetAsync(h->d_dbgv, 0, (3 * 256 + 4) * sizeof(float), s));
     if (h->use_ws && h->nb_max > 15)
         return fail(h, FTMPC_ERR_ARG, "the QP dump needs N * NT <= 240 on the fp32 path (create the handle with dtype FTMPC_DTYPE_F64 for larger shapes)");
+    const bool ws64_was = h->use_ws64;
+    h->use_ws64 = false;
     const bool ws_was = h->use_ws;
     h->use_ws = false;     // the dump hook (the condensed thruster-space QP) lives in kernel 7; kernel 8 never forms that matrix
     rc = enqueue(h, B, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, xref_stride, uref ? h->d_uref : nullptr, uref_stride,
                  warmU ? h->d_warm : nullptr, h->d_u0, nullptr, h->d_status, h->d_iters, s, inst);
     h->use_ws = ws_was;
+    h->use_ws64 = ws64_was;
     if (rc != FTMPC_OK) return rc;
     if (h->use_f64) {
         const int64_t pm = h->npad_max;

@@ -147,7 +147,10 @@ int dev_grow(ftmpc_multi::Dev& d, T** p, int64_t count) {
     *p = nullptr;
     if (count <= 0) return FTMPC_OK;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(p), (size_t)count * sizeof(T));
-    if (e != hipSuccess) return dev_fail(d, FTMPC_ERR_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();   // clear the runtime's sticky "last error"
+        return dev_fail(d, FTMPC_ERR_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
     return FTMPC_OK;
 }
 

@@ -96,10 +96,12 @@ def split_ops(s):
 
 
 class Inst:
-    __slots__ = ("mn", "ops", "line", "in_asm", "wr", "rd", "ws", "kind", "dpp", "lanesel", "text", "ab")
+    __slots__ = ("mn", "ops", "line", "in_asm", "wr", "rd", "ws", "kind", "dpp", "lanesel", "text", "ab", "target", "callee")
 
     def __init__(self, text, line, in_asm):
         self.text, self.line, self.in_asm = text, line, in_asm
+        self.target = None      # s_setpc_b64 that ends a relaxed long branch: the label it jumps to
+        self.callee = None      # s_swappc_b64: the function it calls
         body = text.split(";")[0].strip()
         parts = body.split(None, 1)
         self.mn = parts[0]
@@ -157,9 +159,19 @@ class Inst:
         self.ab = set(opregs[1] + opregs[2]) if self.kind == "mfma" and len(opregs) >= 3 else set()
 
 
+LONG_BRANCH = re.compile(r"\((\.LBB\w+)-\.Lpost_getpc\w*\)")
+CALL_SYM = re.compile(r"\b(_Z\w+)@rel32@")
+
+
 def parse(path):
-    """-> {function: (items, labels)}; items = list of Inst or ('label', name)."""
+    """-> {function: items}; items = list of Inst or ('label', name).
+    Two pseudo-branches of the final stream are resolved here, so that the backward walk crosses them:
+      * a RELAXED LONG BRANCH  s_getpc_b64 sX / s_add_u32 sX, sX, (.LBBn-.Lpost_getpc)&.. / s_addc_u32 / s_setpc_b64 sX
+        is an unconditional branch to .LBBn (Inst.target of the s_setpc_b64);
+      * a CALL  s_getpc_b64 / s_add_u32 .., SYM@rel32@lo+4 / s_addc_u32 .., SYM@rel32@hi+12 / s_swappc_b64  enters SYM
+        (Inst.callee); the callee's  s_setpc_b64 s[30:31]  returns behind it."""
     funcs, cur, name, in_asm = {}, None, None, False
+    pend_label, pend_sym = None, None
     for ln, raw in enumerate(open(path), 1):
         s = raw.rstrip("\n")
         st = s.strip()
@@ -186,7 +198,18 @@ def parse(path):
         if not st or st.startswith((";", ".", "//")):
             continue
         if re.match(r"^[a-z_0-9]+(\s|$)", st):
-            cur.append(Inst(st, ln, in_asm))
+            it = Inst(st, ln, in_asm)
+            m = LONG_BRANCH.search(st)
+            if m and it.mn.startswith("s_add"):
+                pend_label = m.group(1)
+            m = CALL_SYM.search(st)
+            if m and it.mn.startswith("s_add"):
+                pend_sym = m.group(1)
+            if it.mn == "s_setpc_b64":
+                it.target, pend_label = pend_label, None
+            if it.mn == "s_swappc_b64":
+                it.callee, pend_sym = pend_sym, None
+            cur.append(it)
     return funcs
 
 
@@ -200,35 +223,79 @@ def predecessors(items):
             tgt = it.ops[-1] if it.ops else None
             if tgt in label_pos:
                 preds[label_pos[tgt]].append(i)
+        elif it.mn == "s_setpc_b64" and it.target in label_pos:
+            preds[label_pos[it.target]].append(i)
     return preds
 
 
-def walk_back(items, preds, start, budget):
-    """Yields (inst, wait states between it and the consumer) for every instruction reachable backwards from
-    position `start` (exclusive) with fewer than `budget` wait states in between."""
-    stack = [(start - 1, 0, True)]
+class Program:
+    """All functions of the code object with what the backward walk needs to cross function boundaries."""
+
+    def __init__(self, funcs):
+        self.funcs = funcs
+        self.preds = {n: predecessors(items) for n, items in funcs.items()}
+        self.callsites = defaultdict(list)     # callee -> [(caller, position of the s_swappc_b64)]
+        self.rets = defaultdict(list)          # function -> positions of its returns (s_setpc_b64 without a label target)
+        self.unresolved = []
+        for n, items in funcs.items():
+            for i, it in enumerate(items):
+                if isinstance(it, tuple):
+                    continue
+                if it.mn == "s_swappc_b64":
+                    if it.callee in funcs:
+                        self.callsites[it.callee].append((n, i))
+                    else:
+                        self.unresolved.append((n, it))
+                elif it.mn == "s_setpc_b64" and it.target is None:
+                    self.rets[n].append(i)
+
+
+def walk_back(prog, fname, start, budget):
+    """Yields (inst, wait states between it and the consumer) for every instruction reachable backwards from position
+    `start` of function `fname` (exclusive) with fewer than `budget` wait states in between: across labels (fall-through,
+    branches, relaxed long branches), out of a function's entry into every call site, and from behind a call into the
+    callee's returns."""
+    stack = [(fname, start - 1, 0, False)]     # (function, position, distance, arrived at this s_swappc_b64 from its callee's entry)
     seen = set()
+
+    def push(fn, pos, dist, from_entry=False):
+        key = (fn, pos, dist, from_entry)
+        if key not in seen:
+            seen.add(key)
+            stack.append(key)
+
     while stack:
-        pos, dist, fall = stack.pop()
-        while pos >= 0 and dist < budget:
+        fn, pos, dist, from_entry = stack.pop()
+        items, preds = prog.funcs[fn], prog.preds[fn]
+        while dist < budget:
+            if pos < 0:    # function entry: the code in front of every call of this function ran before (kernels: nothing did)
+                for cf, cpos in prog.callsites.get(fn, ()):
+                    push(cf, cpos, dist, True)
+                break
             it = items[pos]
             if isinstance(it, tuple):
                 for b in preds.get(pos, ()):
-                    if (b, dist) not in seen:
-                        seen.add((b, dist))
-                        stack.append((b, dist, False))
+                    push(fn, b, dist)
                 pos -= 1
                 # fall-through into the label is impossible behind an unconditional transfer
                 if pos >= 0 and not isinstance(items[pos], tuple) and items[pos].mn in ("s_branch", "s_endpgm", "s_setpc_b64"):
                     break
                 continue
+            if it.mn == "s_swappc_b64" and it.callee in prog.funcs and not from_entry:
+                # coming from behind the call: what ran last is the callee -- its returns, its body, its entry, and through
+                # prog.callsites the s_swappc_b64 itself and the code in front of it
+                for r in prog.rets.get(it.callee, ()):
+                    push(it.callee, r, dist)
+                break
+            from_entry = False
             yield it, dist
             dist += it.ws
             pos -= 1
 
 
-def check_consumer(items, preds, i, found):
-    """Appends the violations whose CONSUMER is items[i]."""
+def check_consumer(prog, fname, i, found):
+    """Appends the violations whose CONSUMER is instruction i of function fname."""
+    items = prog.funcs[fname]
     c = items[i]
     if isinstance(c, tuple) or c.kind in ("salu", "other"):
         return
@@ -266,7 +333,7 @@ def check_consumer(items, preds, i, found):
     budget = max([r[1] for r in rules] + [MAXW if (vt or c.kind == "mfma") else 0])
     if budget == 0:
         return
-    for p, dist in walk_back(items, preds, i, budget):
+    for p, dist in walk_back(prog, fname, i, budget):
         for name, need, pred, regs in rules:
             if dist < need and regs and pred(p):
                 hit = p.wr & regs
@@ -290,11 +357,10 @@ def check_consumer(items, preds, i, found):
                     break
 
 
-def check_function(items):
-    preds = predecessors(items)
+def check_function(prog, fname):
     found = []
-    for i in range(len(items)):
-        check_consumer(items, preds, i, found)
+    for i in range(len(prog.funcs[fname])):
+        check_consumer(prog, fname, i, found)
     return found
 
 
@@ -307,8 +373,8 @@ def check_function(items):
 ELIDE_WINDOW = 24
 
 
-def elide_function(items):
-    preds = predecessors(items)
+def elide_function(prog, fname):
+    items = prog.funcs[fname]
     saved = removed = 0
     for i, it in enumerate(items):
         if isinstance(it, tuple) or it.mn != "s_nop" or not it.in_asm:
@@ -321,7 +387,7 @@ def elide_function(items):
             it.ws = w
             found = []
             for j in range(i + 1, min(len(items), i + 1 + ELIDE_WINDOW)):
-                check_consumer(items, preds, j, found)
+                check_consumer(prog, fname, j, found)
                 if found:
                     break
             if not found:
@@ -334,11 +400,12 @@ def elide_function(items):
 def elide(asm_in, asm_out, lower=True):
     """Writes asm_out = asm_in with the asm-side wait states minimised; returns statistics.  The result is audited again."""
     funcs = parse(asm_in)
+    prog = Program(funcs)
     new_ws = {}
     stats = {}
     for name, items in funcs.items():
         before = sum(it.ws for it in items if not isinstance(it, tuple) and it.mn == "s_nop" and it.in_asm)
-        saved, removed = elide_function(items) if lower else (0, 0)
+        saved, removed = elide_function(prog, name) if lower else (0, 0)
         stats[name] = dict(asm_wait_states=before, saved=saved, nops_removed=removed)
         for it in items:
             if not isinstance(it, tuple) and it.mn == "s_nop" and it.in_asm:
@@ -347,7 +414,7 @@ def elide(asm_in, asm_out, lower=True):
     # result three wait states later): pad the consumer rather than argue about which side is right
     pad = {}
     for name, items in funcs.items():
-        for f in check_function(items):
+        for f in check_function(prog, name):
             if not f["asm"]:
                 ln = f["cons"].line
                 pad[ln] = max(pad.get(ln, 0), f["need"] - f["have"])
@@ -377,9 +444,12 @@ def build_asm(out):
 
 def audit(asm_path):
     funcs = parse(asm_path)
+    prog = Program(funcs)
+    if prog.unresolved:
+        raise SystemExit("call targets not resolved (the audit cannot follow them): " + ", ".join(f"{n} L{it.line}" for n, it in prog.unresolved))
     summary = {}
     for name, items in funcs.items():
-        found = check_function(items)
+        found = check_function(prog, name)
         insts = [it for it in items if not isinstance(it, tuple)]
         summary[name] = dict(n_inst=len(insts), n_asm_inst=sum(1 for it in insts if it.in_asm),
                              asm=[f for f in found if f["asm"]], compiler=[f for f in found if not f["asm"]])

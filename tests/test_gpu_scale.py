@@ -41,21 +41,31 @@ def _check_f64(mpc, cfg, x0, ub, stuck, xref):
     return out
 
 
-def test_f64_persistent_loop_reference_vehicle(gpu_mpc_factory):
-    """<4,1> (n <= 256): N=15, 16 thrusters, two random faults (n = 210), B = 4096 = 8..16 instances per workgroup."""
+@pytest.mark.parametrize("sel", ["auto", "dense"])
+def test_f64_persistent_loop_reference_vehicle(gpu_mpc_factory, sel):
+    """N=15, 16 thrusters, two random faults (n = 210), B = 4096 = 8..16 instances per workgroup: the wrench-space float64
+    kernel <1> (auto) and the dense <4,1> (n <= 256)."""
     N, NT, B = 15, 16, 4096
-    mpc = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40)
+    mpc = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40, kernel_select=sel)
+    assert ("ws64" in mpc.kernel_name(6))
     x0, ub, stuck, xref = qo.make_batch(B, N, NT, 2, 5101)
     out = _check_f64(mpc, qo.QPConfig(N=N, NT=NT), x0, ub, stuck, xref)
     assert out["iters"].max() <= 40
 
 
-def test_f64_persistent_loop_config5_shard(gpu_mpc_factory):
-    """<10,3> (n <= 640): BASELINE configs[4] shard, N=40, 16 thrusters, two faults (n = 560), 2048 per GPU."""
-    N, NT, B = 40, 16, 2048
-    mpc = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40)
+@pytest.mark.parametrize("sel,B", [("auto", 2048), ("dense", 640)])
+def test_f64_persistent_loop_config5_shard(gpu_mpc_factory, sel, B):
+    """BASELINE configs[4] shard, N=40, 16 thrusters, two faults (n = 560), 2048 per GPU: the wrench-space float64 kernel <3>
+    (auto: K is 240 x 240); the dense <10,3> (n <= 640) on 640 instances (2.5 per resident workgroup)."""
+    N, NT = 40, 16
+    mpc = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40, kernel_select=sel)
     x0, ub, stuck, xref = qo.make_batch(B, N, NT, 2, 1005)
-    _check_f64(mpc, qo.QPConfig(N=N, NT=NT), x0, ub, stuck, xref)
+    out = _check_f64(mpc, qo.QPConfig(N=N, NT=NT), x0, ub, stuck, xref)
+    mpc.set_profiling(True)
+    mpc.solve(x0[:64], ub[:64], stuck[:64], xref.reshape(-1, order="F"))
+    ran = mpc.last_kernel_ms()
+    assert ("ftmpc_solve_ws64_kernel" in ran) == (sel == "auto") and ("ftmpc_solve_f64_kernel" in ran) == (sel == "dense"), ran
+    assert out["iters"].max() <= 40
 
 
 def test_f64_persistent_loop_beyond_640(gpu_mpc_factory):

@@ -73,7 +73,7 @@ def test_rule_table_on_hand_written_sequences(tmp_path):
     def run(body):
         p = tmp_path / "t.s"
         p.write_text("_Z1kv:\n" + "\n".join("\t" + l for l in body) + "\n.Lfunc_end0:\n")
-        return sorted({f["rule"] for f in ch.check_function(ch.parse(p)["_Z1kv"])})
+        return sorted({f["rule"] for f in ch.check_function(ch.Program(ch.parse(p)), "_Z1kv")})
     assert run(["v_rsq_f32_e32 v1, v2", "v_mul_f32_e32 v3, v1, v1"]) == ["trans_use"]
     assert run(["v_rsq_f32_e32 v1, v2", "s_nop 0", "v_mul_f32_e32 v3, v1, v1"]) == []
     assert run(["v_mov_b32_e32 v1, v2", "s_nop 0", "v_add_f32_dpp v3, v1, v1 row_ror:8 row_mask:0xf bank_mask:0xf"]) == ["dpp_vgpr"]
@@ -88,5 +88,34 @@ def test_rule_table_on_hand_written_sequences(tmp_path):
     # the sequence hipcc emitted in the workgroup kernel (wrong results on the GPU until padded)
     assert run(["v_mfma_f32_16x16x4_f32 a[0:3], v25, v7, a[0:3]", "v_mfma_f32_16x16x4_f32 a[4:7], v25, v15, a[4:7]", "s_cbranch_execnz .LBB0_8",
                 "s_branch .LBB0_9", ".LBB0_8:", "s_waitcnt vmcnt(1)", "v_accvgpr_read_b32 v7, a3", ".LBB0_9:"]) == ["mfma_use"]
+    # across a RELAXED LONG BRANCH (s_getpc / s_add / s_addc / s_setpc): four wait states of SALU between the MFMA and the read
+    assert run(["v_mfma_f32_16x16x4_f32 a[0:3], v25, v7, a[0:3]", "s_getpc_b64 s[4:5]", ".Lpost_getpc3:", "s_add_u32 s4, s4, (.LBB0_9-.Lpost_getpc3)&4294967295",
+                "s_addc_u32 s5, s5, (.LBB0_9-.Lpost_getpc3)>>32", "s_setpc_b64 s[4:5]", ".LBB0_8:", "s_nop 0", ".LBB0_9:", "v_accvgpr_read_b32 v7, a3"]) == ["mfma_use"]
     # across a branch edge: the producer sits before the branch, the consumer behind the label
     assert run(["v_mov_b32_e32 v1, v2", "s_cbranch_scc1 .LBB0_2", "s_nop 3", ".LBB0_2:", "v_add_f32_dpp v3, v1, v1 row_ror:8 row_mask:0xf bank_mask:0xf"]) == ["dpp_vgpr"]
+
+
+def test_walk_crosses_calls_and_returns(tmp_path):
+    """Producer in the caller / consumer at the callee's entry, and producer at the callee's end / consumer behind the call:
+    the audit follows s_swappc_b64 into the callee and s_setpc_b64 s[30:31] back (function boundaries were blind)."""
+    def run(caller, callee):
+        p = tmp_path / "c.s"
+        call = ["s_getpc_b64 s[0:1]", "s_add_u32 s0, s0, _Z1fv@rel32@lo+4", "s_addc_u32 s1, s1, _Z1fv@rel32@hi+12", "s_swappc_b64 s[30:31], s[0:1]"]
+        body = []
+        for l in caller:
+            body += call if l == "CALL" else [l]
+        p.write_text("_Z1kv:\n" + "\n".join("\t" + l for l in body) + "\n\ts_endpgm\n.Lfunc_end0:\n_Z1fv:\n" +
+                     "\n".join("\t" + l for l in callee) + "\n\ts_setpc_b64 s[30:31]\n.Lfunc_end1:\n")
+        prog = ch.Program(ch.parse(p))
+        assert not prog.unresolved and prog.callsites["_Z1fv"] and prog.rets["_Z1fv"]
+        return {n: sorted({f["rule"] for f in ch.check_function(prog, n)}) for n in ("_Z1kv", "_Z1fv")}
+    # MFMA result written in front of the call, read by the callee's first instruction (4 SALU wait states in between)
+    r = run(["v_mfma_f32_16x16x4_f32 v[0:3], v4, v5, v[0:3]", "CALL"], ["v_add_f32_e32 v9, v0, v0"])
+    assert r["_Z1fv"] == ["mfma_use"]
+    r = run(["v_mfma_f32_16x16x4_f32 v[0:3], v4, v5, v[0:3]", "s_nop 7", "CALL"], ["v_add_f32_e32 v9, v0, v0"])
+    assert r["_Z1fv"] == []
+    # transcendental at the callee's end, consumed right behind the call: only the return lies in between
+    r = run(["CALL", "v_add_f32_dpp v3, v1, v1 row_ror:8 row_mask:0xf bank_mask:0xf"], ["v_mov_b32_e32 v1, v2"])
+    assert r["_Z1kv"] == ["dpp_vgpr"]
+    r = run(["CALL", "s_nop 0", "v_add_f32_dpp v3, v1, v1 row_ror:8 row_mask:0xf bank_mask:0xf"], ["v_mov_b32_e32 v1, v2"])
+    assert r["_Z1kv"] == []

@@ -417,6 +417,11 @@ extern "C" {
 
 int32_t ftmpc_version(void) { return 400; }
 
+#ifndef FTMPC_BUILD_ID
+#define FTMPC_BUILD_ID "unknown"
+#endif
+const char* ftmpc_build_id(void) { return FTMPC_BUILD_ID; }
+
 int ftmpc_default_config(ftmpc_config* cfg, int32_t N, int32_t NT) {
     if (!cfg || N < 1 || N > 64 || NT < 1 || NT > FTMPC_MAX_NT) return FTMPC_ERR_ARG;
     std::memset(cfg, 0, sizeof(*cfg));
@@ -592,7 +597,7 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
             int per = 0;
             if (h->ws64_nvt == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_ws64_kernel<1>, ftmpc::ws64k::WG, 0);
             else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_ws64_kernel<3>, ftmpc::ws64k::WG, 0);
-            h->grid_ws64 = h->num_cu * std::max(1, std::min(per, 2));
+            h->grid_ws64 = h->num_cu * std::max(1, std::min(per, FTMPC_WS64_WPC));
             h->ws64_slot_doubles = ftmpc::ws64k::slot_doubles(cfg->N);
             bad = grow(h, &h->ws64_slot, (int64_t)h->grid_ws64 * h->ws64_slot_doubles) != FTMPC_OK;
         }

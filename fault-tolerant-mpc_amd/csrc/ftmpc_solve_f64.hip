@@ -109,6 +109,57 @@ __device__ __forceinline__ bool potrf_inv16_f64(const double* S, int li, double 
 
 __device__ __forceinline__ f64x4 ld4(const double* p) { return *reinterpret_cast<const f64x4*>(p); }
 
+// 16x16 Cholesky + inverse of a diagonal tile held in the float64 MFMA C/D layout (lane (lq, li): rows lq + 4 rr, rr < 4, of
+// column li) by ONE wave with all 64 lanes at work: right-looking elimination without scaling the pivot column (the float64
+// form of ftmpc_solve.hip's potrf_inv16: after step j column j holds sqrt(d_j) L[:, j]), the inverse built alongside from
+// E = I.  Per pivot the four lanes that hold column j publish it in LDS (colS, 16 doubles in v64pos order so that a lane
+// reads its four rows with one 32-byte load) and the sixteen lanes that hold row j of E publish that (rowE); every lane
+// reads the pivot, its rows, its column's entry and E[j][col], then eight FMAs.  The row-per-lane version above spends
+// ~900 cycles per pivot on ~32 v_readlane of double words; this one two LDS round trips (~300).
+// Out: w = W = L^-1 and l = L in the same layout (zero above the diagonal); returns false on a non-positive pivot.
+__device__ __forceinline__ bool potrf_inv16_lds(double (&c)[4], double* colS, double* rowE, int lq, int li, double (&w)[4], double (&l)[4]) {
+    double e[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        e[rr] = (lq + 4 * rr == li) ? 1.0 : 0.0;
+        w[rr] = 0.0;
+        l[rr] = 0.0;
+    }
+    bool ok = true;
+    const int pli = v64pos(li);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (li == j) *reinterpret_cast<f64x4*>(colS + 4 * lq) = f64x4{c[0], c[1], c[2], c[3]};
+        if (lq == (j & 3)) rowE[li] = e[j >> 2];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double d = colS[v64pos(j)];
+        const f64x4 sc = *reinterpret_cast<const f64x4*>(colS + 4 * lq);
+        const double sk = colS[pli], ek = rowE[li];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();     // the next pivot's stores stay behind these loads
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        ok = ok && (d > 0.0);
+        double inv = __builtin_amdgcn_rsq(d);
+        inv = inv * (1.5 - 0.5 * d * inv * inv);
+        inv = inv * (1.5 - 0.5 * d * inv * inv);
+        const double invd = inv * inv;
+        if (li == j) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) l[rr] = (lq + 4 * rr >= j) ? sc[rr] * inv : 0.0;
+        }
+        if (lq == (j & 3)) w[j >> 2] = ek * inv;
+        const double mk = sk * invd, me = ek * invd;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            c[rr] -= sc[rr] * mk;
+            e[rr] -= sc[rr] * me;
+        }
+    }
+    return ok;
+}
+
 }  // namespace f64k
 
 struct Solve64Params {
@@ -160,7 +211,7 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4 && MODE == 0) ? 2 :
     __shared__ double dv[NMAX];        // d (permuted per 16-block) for the gradient mat-vec
     __shared__ double xv[NMAX];        // rhs / solution of the KKT solves (permuted)
     __shared__ double part[NWAVE * 16];
-    __shared__ double Sbuf[16 * 17];
+    __shared__ __attribute__((aligned(32))) double Sbuf[32];     // pivot column | row of E (potrf_inv16_lds)
     __shared__ double red[NWAVE];
     __shared__ float s_Da[6 * MAX_NT];
     __shared__ double s_MR[MAX_NT * MAX_NT];
@@ -532,20 +583,13 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4 && MODE == 0) ? 2 :
                 hull_blocks(J, c);
                 const double sg = dv[16 * J + li];
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
+                for (int rr = 0; rr < 4; ++rr)
                     if (lq + 4 * rr == li) c[rr] += sg;
-                    Sbuf[(lq + 4 * rr) * 17 + li] = c[rr];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                double w[16];
-                const bool ok = potrf_inv16_f64(Sbuf, li, w);
+                double w[4], lunused[4];
+                const bool ok = potrf_inv16_lds(c, Sbuf, Sbuf + 16, lq, li, w, lunused);
                 if (!ok && lane == 0) s_flag = 0;
-                if (lq == 0) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) tjj[t64off(i, li)] = w[i];
-                }
+                for (int rr = 0; rr < 4; ++rr) tjj[t64off(lq + 4 * rr, li)] = w[rr];
             }
             S64(8);    // (diagnostic) wave 0: diagonal tile + potrf
             // off-diagonal tiles of this wave as ONE stream of (tile, batch of four block columns): the loads of the next

@@ -14,8 +14,9 @@
 //
 // One 4-wave workgroup per instance, two workgroups per CU.  Everything n x n lives as 16 x 16 float64 tiles in a
 // per-workgroup global slot (row-major "operand layout" f64k::t64off: a tile is the A operand of X Y' as it stands):
-//     Ks  H_w during the build, then K - I of every iteration     Fs  the factor of K (diagonal slot: inverse of the block)
-//     Lr  L by rows (tile (I,J) = L_IJ)                            Lt  L' (tile (I,J) = L_IJ')      Ps  P' = L' S
+//     Ks  H_w during the build, then K - I of every iteration, factorised IN PLACE (diagonal slot: inverse of the block)
+//     Lt  L' (tile (I,J) = L_IJ'), the only copy of the factor of H_w: L p reads its tiles by columns
+// (P' = L' S exists one block row at a time, in LDS).
 // Reference path replaced: ft_mpc/controllers/spiraling_mpc.py:87-238,319-354; oracle/qp_oracle.py:ipm_box is the mirror
 // (schur_newton_solver restates this form of the Newton step).
 #include <hip/hip_runtime.h>
@@ -43,42 +44,11 @@ constexpr int NTL = NBW * (NBW + 1) / 2;
 constexpr int NMAXST = NPADW / 6;            // stages
 // per-workgroup global slot, in doubles
 __host__ __device__ constexpr int64_t off_K() { return 0; }
-__host__ __device__ constexpr int64_t off_F() { return (int64_t)NTL * 256; }
-__host__ __device__ constexpr int64_t off_Lr() { return 2 * (int64_t)NTL * 256; }
-__host__ __device__ constexpr int64_t off_Lt() { return 3 * (int64_t)NTL * 256; }
-__host__ __device__ constexpr int64_t off_Ld() { return 4 * (int64_t)NTL * 256; }
-__host__ __device__ constexpr int64_t off_P() { return off_Ld() + (int64_t)NBW * 256; }
-__host__ __device__ constexpr int64_t off_E() { return off_P() + (int64_t)NBW * NBW * 256; }
+__host__ __device__ constexpr int64_t off_Lt() { return (int64_t)NTL * 256; }
+__host__ __device__ constexpr int64_t off_Ld() { return 2 * (int64_t)NTL * 256; }
+__host__ __device__ constexpr int64_t off_E() { return off_Ld() + (int64_t)NBW * 256; }
 __host__ __device__ constexpr int64_t slot_doubles(int N) { return off_E() + (int64_t)N * 9 * NPADW; }
 
-// 16x16 Cholesky + inverse in registers (f64k::potrf_inv16_f64), also returning the factor itself: lane li holds row li
-// of L in a[0..li] (the entries beyond the diagonal are not part of L)
-__device__ __forceinline__ bool potrf_inv16_keep(const double* S, int li, double (&w)[16], double (&a)[16]) {
-#pragma unroll
-    for (int k = 0; k < 16; ++k) a[k] = S[li * 17 + k];
-    double invs[16];
-    bool ok = true;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const double djj = f64k::readlane_d(a[j], j);
-        ok = ok && (djj > 0.0);
-        double inv = __builtin_amdgcn_rsq(djj);
-        inv = inv * (1.5 - 0.5 * djj * inv * inv);
-        inv = inv * (1.5 - 0.5 * djj * inv * inv);
-        invs[j] = inv;
-        a[j] *= inv;
-#pragma unroll
-        for (int k = j + 1; k < 16; ++k) a[k] -= a[j] * f64k::readlane_d(a[j], k);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        double s = (i == li) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < i; ++k) s -= f64k::readlane_d(a[k], i) * w[k];
-        w[i] = s * invs[i];
-    }
-    return ok;
-}
 }  // namespace ws64k
 
 struct SolveWs64Params {
@@ -87,8 +57,11 @@ struct SolveWs64Params {
     int64_t slot_doubles;
 };
 
+#ifndef FTMPC_WS64_WPC
+#define FTMPC_WS64_WPC 2      // resident workgroups per CU (register budget 512 / WPC per lane)
+#endif
 template <int NVT>   // thruster-space variables per thread: N * na <= 256 NVT
-__global__ void __launch_bounds__(ws64k::WG, 2) ftmpc_solve_ws64_kernel(const DeviceConsts C, const SolveWs64Params Q) {
+__global__ void __launch_bounds__(ws64k::WG, FTMPC_WS64_WPC) ftmpc_solve_ws64_kernel(const DeviceConsts C, const SolveWs64Params Q) {
     using namespace ws64k;
     constexpr int NTP = WG * NVT;
     const SolveParams& P = Q.base;
@@ -98,7 +71,7 @@ __global__ void __launch_bounds__(ws64k::WG, 2) ftmpc_solve_ws64_kernel(const De
     __shared__ double tw[NPADW], yv[NPADW], gwv[NPADW];
     __shared__ double rv[NTP], rdg[NTP];
     __shared__ double part[NWAVE * 16];
-    __shared__ double Sbuf[16 * 17];
+    __shared__ __attribute__((aligned(32))) double Sbuf[32];     // pivot column | row of E (f64k::potrf_inv16_lds)
     __shared__ double red[NWAVE];
     __shared__ double s_DaT[6 * MAX_NT];          // the healthy columns of D
     __shared__ double s_DD[21 * MAX_NT];          // D_a[g][a] D_a[h][a] for the 21 pairs g >= h
@@ -109,7 +82,8 @@ __global__ void __launch_bounds__(ws64k::WG, 2) ftmpc_solve_ws64_kernel(const De
     __shared__ int s_act[MAX_NT];
     __shared__ int s_flag;
     // finished tiles of the current block row J of the factor (K < J): see ftmpc_solve_f64.hip
-    __shared__ __attribute__((aligned(32))) double Pj[(NBW - 1) * 256];
+    // (also: block row I of P' = L' S while the tiles X_IJ of that row are formed, NBW tiles)
+    __shared__ __attribute__((aligned(32))) double Pj[NBW * 256];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -120,11 +94,9 @@ __global__ void __launch_bounds__(ws64k::WG, 2) ftmpc_solve_ws64_kernel(const De
 
     double* const slot = Q.slot + (int64_t)blockIdx.x * Q.slot_doubles;
     double* const Ks = slot + off_K();
-    double* const Fs = slot + off_F();
-    double* const Lr = slot + off_Lr();
+    double* const Fs = Ks;     // the factorisation runs in place: tile (I, J) of the matrix is read once, by the wave that writes tile (I, J) of the factor
     double* const Lt = slot + off_Lt();
     double* const Ld = slot + off_Ld();
-    double* const Ps = slot + off_P();
     double* const Eall = slot + off_E();
 
     for (int t = tid; t < NTL; t += WG) {
@@ -376,7 +348,8 @@ __global__ void __launch_bounds__(ws64k::WG, 2) ftmpc_solve_ws64_kernel(const De
         // ---- blocked left-looking Cholesky of (Hsrc + diag(dv)) into Fdst: ftmpc_solve_f64.hip's schedule (wave 0 owns the
         // diagonal tile and its potrf + inverse, the off-diagonal tiles of a column run as one prefetched stream per wave).
         // keep_l: the diagonal blocks of the factor itself go to Ld (the first factorisation: H_w = L L').
-        auto factor = [&](const double* Hsrc, double* Fdst, bool keep_l) {
+        auto factor = [&](const double* Hsrc, double* Fdst, auto KEEP) {
+            constexpr bool keep_l = decltype(KEEP)::value;
             if (tid == 0) s_flag = 1;
             for (int J = 0; J < nb; ++J) {
                 __syncthreads();
@@ -404,26 +377,20 @@ __global__ void __launch_bounds__(ws64k::WG, 2) ftmpc_solve_ws64_kernel(const De
                     double* tjj = Fdst + (int64_t)t64idx(J, J) * 256;
                     const double* hjj = Hsrc + (int64_t)t64idx(J, J) * 256;
                     const double sg = dv[16 * J + li];
+                    double c[4], w[4], l[4];
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
-                        double c = hjj[t64off(lq + 4 * rr, li)] - acc[rr];
-                        if (lq + 4 * rr == li) c += sg;
-                        Sbuf[(lq + 4 * rr) * 17 + li] = c;
+                        c[rr] = hjj[t64off(lq + 4 * rr, li)] - acc[rr];
+                        if (lq + 4 * rr == li) c[rr] += sg;
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    double w[16], a[16];
-                    const bool ok = potrf_inv16_keep(Sbuf, li, w, a);
+                    const bool ok = f64k::potrf_inv16_lds(c, Sbuf, Sbuf + 16, lq, li, w, l);
                     if (!ok && lane == 0) s_flag = 0;
-                    if (lq == 0) {
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) tjj[t64off(i, li)] = w[i];
-                        if (keep_l) {
-                            double* ldj = Ld + J * 256;
+                    for (int rr = 0; rr < 4; ++rr) tjj[t64off(lq + 4 * rr, li)] = w[rr];
+                    if constexpr (keep_l) {
+                        double* ldj = Ld + J * 256;
 #pragma unroll
-                            for (int i = 0; i < 16; ++i) ldj[t64off(li, i)] = (i <= li) ? a[i] : 0.0;   // lane li holds row li
-                        }
+                        for (int rr = 0; rr < 4; ++rr) ldj[t64off(lq + 4 * rr, li)] = l[rr];
                     }
                 }
                 S64(8);
@@ -663,27 +630,32 @@ __global__ void __launch_bounds__(ws64k::WG, 2) ftmpc_solve_ws64_kernel(const De
             }
             __syncthreads();
         };
-        // ---- out = L' in (tiles of Lt) or L in (tiles of Lr): row-major tile times permuted vector; output block rows dealt
-        // over the waves.  PERM_OUT: the result keeps the permuted layout (operand of the solve), else natural order ----
+        // ---- out = L' in (TRANS: tile of Lt times permuted vector, one 32-byte load per lane) or L in (the same tiles read by
+        // columns: L_IJ[r][c] = Lt tile[c][r], four 8-byte loads per lane); output block rows dealt over the waves.
+        // PERM_OUT: the result keeps the permuted layout (operand of the solve), else natural order ----
         auto tri_mv = [&](auto TRANS, auto PERM_OUT, const double* in, double* out) {
+            constexpr bool tr = decltype(TRANS)::value;
             for (int Bo = wave; Bo < nb; Bo += NWAVE) {
                 double a0 = 0.0, a1 = 0.0;
-                const int X0 = decltype(TRANS)::value ? Bo : 0, X1 = decltype(TRANS)::value ? nb : Bo + 1;
+                const int X0 = tr ? Bo : 0, X1 = tr ? nb : Bo + 1;
+                auto tile = [&](int X) -> f64x4 {
+                    if constexpr (tr) {
+                        return ld4(Lt + (int64_t)t64idx(X, Bo) * 256 + 16 * li + 4 * lq);      // L'_{Bo,X}[li][lq + 4 s]
+                    } else {
+                        const double* t = Lt + (int64_t)t64idx(Bo, X) * 256;                   // L_{Bo,X}[li][lq + 4 s] = L'_{X,Bo}[lq + 4 s][li]
+                        return f64x4{t[t64off(lq, li)], t[t64off(lq + 4, li)], t[t64off(lq + 8, li)], t[t64off(lq + 12, li)]};
+                    }
+                };
                 int X = X0;
                 for (; X + 1 < X1; X += 2) {
-                    const int i0 = decltype(TRANS)::value ? t64idx(X, Bo) : t64idx(Bo, X);
-                    const int i1 = decltype(TRANS)::value ? t64idx(X + 1, Bo) : t64idx(Bo, X + 1);
-                    const double* src = decltype(TRANS)::value ? Lt : Lr;
-                    const f64x4 t0 = ld4(src + (int64_t)i0 * 256 + 16 * li + 4 * lq), t1 = ld4(src + (int64_t)i1 * 256 + 16 * li + 4 * lq);
+                    const f64x4 t0 = tile(X), t1 = tile(X + 1);
                     const double* d0 = in + 16 * X + 4 * lq;
                     const double* d1 = d0 + 16;
                     a0 += t0.x * d0[0] + t0.y * d0[1] + t0.z * d0[2] + t0.w * d0[3];
                     a1 += t1.x * d1[0] + t1.y * d1[1] + t1.z * d1[2] + t1.w * d1[3];
                 }
                 if (X < X1) {
-                    const int i0 = decltype(TRANS)::value ? t64idx(X, Bo) : t64idx(Bo, X);
-                    const double* src = decltype(TRANS)::value ? Lt : Lr;
-                    const f64x4 t0 = ld4(src + (int64_t)i0 * 256 + 16 * li + 4 * lq);
+                    const f64x4 t0 = tile(X);
                     const double* d0 = in + 16 * X + 4 * lq;
                     a0 += t0.x * d0[0] + t0.y * d0[1] + t0.z * d0[2] + t0.w * d0[3];
                 }
@@ -698,9 +670,13 @@ __global__ void __launch_bounds__(ws64k::WG, 2) ftmpc_solve_ws64_kernel(const De
 #pragma unroll
             for (int v = 0; v < NVT; ++v) t[v] = r[v] * rdg[v * WG + tid];
             to_wrench(t, tw);
+            S64(4);
             tri_mv(std::true_type{}, std::true_type{}, tw, xv);
+            S64(6);     // (diagnostic) the two triangular products with L
             solve();
+            S64(5);     // (diagnostic) the solve with the factor of K
             tri_mv(std::false_type{}, std::false_type{}, xv, yv);
+            S64(6);
 #pragma unroll
             for (int v = 0; v < NVT; ++v) {
                 double s = 0.0;
@@ -753,24 +729,16 @@ __global__ void __launch_bounds__(ws64k::WG, 2) ftmpc_solve_ws64_kernel(const De
         __syncthreads();
         if (tid < npad) dv[tid] = 0.0;
         __syncthreads();
-        factor(Ks, Lr, true);
+        factor(Ks, Ks, std::true_type{});
         if (s_flag == 0) {     // H_w not positive definite: report the linearisation point, do not iterate
             write_flat(2, true, ubar, tvalid, tk, ta);
             continue;
         }
-        for (int t = wave; t < ntl; t += NWAVE) {
+        for (int t = wave; t < ntl; t += NWAVE) {     // Lt: the transposed tiles (the diagonal slot of the factor holds W, L_JJ came by Ld)
             const int I = tIJ[2 * t], J = tIJ[2 * t + 1];
-            const double* src = (I == J) ? Ld + I * 256 : Lr + (int64_t)t * 256;
-            double vals[4];
+            const double* src = (I == J) ? Ld + I * 256 : Ks + (int64_t)t * 256;
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) vals[rr] = src[t64off(lq + 4 * rr, li)];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                if (I == J) Lr[(int64_t)t * 256 + t64off(lq + 4 * rr, li)] = vals[rr];     // the diagonal slot held W, not L
-                Lt[(int64_t)t * 256 + t64off(li, lq + 4 * rr)] = vals[rr];
-            }
+            for (int rr = 0; rr < 4; ++rr) Lt[(int64_t)t * 256 + t64off(li, lq + 4 * rr)] = src[t64off(lq + 4 * rr, li)];
         }
         __syncthreads();
         if (tid < npad) dv[tid] = 1.0;       // the identity of K = I + L' S L
@@ -828,66 +796,87 @@ __global__ void __launch_bounds__(ws64k::WG, 2) ftmpc_solve_ws64_kernel(const De
                 Sblk[k * 36 + hh * 6 + g] = sacc;
             }
             __syncthreads();
-            S64(5);
-            // ---- P' = L' S: tile (J, M), M >= J - 1: sum_K L'_JK S_KM over K in {M-1, M, M+1}, K >= J.  A operand: the tile of
-            // Lt as it stands; B operand: rows of S_MK, read off the stage blocks (S is block diagonal: no tiles of it exist) ----
-            for (int t = wave; t < nb * nb; t += NWAVE) {
-                const int J = t / nb, M = t - J * nb;
-                if (M + 1 < J) continue;
-                const int e1 = 16 * M + li;
-                const int s1 = s_stg[e1], a1 = s_thr[e1];
-                f64x4 acc = zero4, acc2 = zero4;
-                const int K0 = (M - 1 > J) ? M - 1 : J, K1 = (M + 1 < nb - 1) ? M + 1 : nb - 1;
-                for (int K = K0; K <= K1; ++K) {
-                    const f64x4 a4 = ld4(Lt + (int64_t)t64idx(K, J) * 256 + 16 * li + 4 * lq);
-                    double b[4];
+            S64(4);
+            // ---- K - I = X = L' S L, one block row I at a time:
+            //   P'_IM = sum_K L'_IK S_KM  (M >= I - 1; K in {M-1, M, M+1}, K >= I) into LDS, each tile laid out as the A operand its
+            //           readers want (A operand of the product: the tile of Lt as it stands; B operand: rows of S_MK, read off the
+            //           stage blocks -- S is block diagonal, no tiles of it exist);
+            //   X_IJ  = sum_{M >= max(I-1, J)} P'_IM (L'_JM)'  (J <= I), A operand from LDS, B operand the tile of Lt, four block
+            //           columns per step with the next step's tiles requested before the products of the current one.
+            // P' never goes to global memory, and every tile of a row has the same number of products. ----
+            for (int I = 0; I < nb; ++I) {
+                const int Mlo = (I > 0) ? I - 1 : 0;
+                for (int M = Mlo + wave; M < nb; M += NWAVE) {
+                    const int e1 = 16 * M + li;
+                    const int s1 = s_stg[e1], a1 = s_thr[e1];
+                    f64x4 acc = zero4, acc2 = zero4;
+                    const int K0 = (M - 1 > I) ? M - 1 : I, K1 = (M + 1 < nb - 1) ? M + 1 : nb - 1;
+                    for (int K = K0; K <= K1; ++K) {
+                        const f64x4 a4 = ld4(Lt + (int64_t)t64idx(K, I) * 256 + 16 * li + 4 * lq);
+                        double b[4];
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const int e2 = 16 * K + 4 * s + lq;
-                        const int s2 = s_stg[e2];
-                        b[s] = (s1 != 255 && s1 == s2) ? Sblk[s1 * 36 + a1 * 6 + s_thr[e2]] : 0.0;
+                        for (int s = 0; s < 4; ++s) {
+                            const int e2 = 16 * K + 4 * s + lq;
+                            const int s2 = s_stg[e2];
+                            b[s] = (s1 != 255 && s1 == s2) ? Sblk[s1 * 36 + a1 * 6 + s_thr[e2]] : 0.0;
+                        }
+                        acc = mfma(a4.x, b[0], acc);
+                        acc2 = mfma(a4.y, b[1], acc2);
+                        acc = mfma(a4.z, b[2], acc);
+                        acc2 = mfma(a4.w, b[3], acc2);
                     }
-                    acc = mfma(a4.x, b[0], acc);
-                    acc2 = mfma(a4.y, b[1], acc2);
-                    acc = mfma(a4.z, b[2], acc);
-                    acc2 = mfma(a4.w, b[3], acc2);
-                }
-                acc += acc2;
-                double* pt = Ps + (int64_t)(J * NBW + M) * 256;
+                    acc += acc2;
+                    // element (row lq + 4 rr, column li) belongs to the reader lane (li & 3, lq + 4 rr), k-step li >> 2
+                    double* pt = Pj + (M - Mlo) * 256 + 4 * (16 * (li & 3) + lq) + (li >> 2);
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) pt[t64off(lq + 4 * rr, li)] = acc[rr];
-            }
-            __syncthreads();
-            S64(6);
-            // ---- X = P' L (lower triangle): X_IJ = sum_{M >= max(I-1, J)} P'_IM (L'_JM)', both operands row-major tiles ----
-            for (int t = wave; t < ntl; t += NWAVE) {
-                const int I = tIJ[2 * t], J = tIJ[2 * t + 1];
-                f64x4 acc = zero4, acc2 = zero4;
-                const double* prow = Ps + (int64_t)I * NBW * 256 + 16 * li + 4 * lq;
-                int M = (I - 1 > J) ? I - 1 : J;
-                for (; M + 1 < nb; M += 2) {
-                    const f64x4 a0 = ld4(prow + M * 256), a1 = ld4(prow + (M + 1) * 256);
-                    const f64x4 b0 = ld4(Lt + (int64_t)t64idx(M, J) * 256 + 16 * li + 4 * lq);
-                    const f64x4 b1 = ld4(Lt + (int64_t)t64idx(M + 1, J) * 256 + 16 * li + 4 * lq);
-                    acc = mfma(a0.x, b0.x, acc); acc2 = mfma(a1.x, b1.x, acc2);
-                    acc = mfma(a0.y, b0.y, acc); acc2 = mfma(a1.y, b1.y, acc2);
-                    acc = mfma(a0.z, b0.z, acc); acc2 = mfma(a1.z, b1.z, acc2);
-                    acc = mfma(a0.w, b0.w, acc); acc2 = mfma(a1.w, b1.w, acc2);
+                    for (int rr = 0; rr < 4; ++rr) pt[16 * rr] = acc[rr];
                 }
-                if (M < nb) {
-                    const f64x4 a0 = ld4(prow + M * 256);
-                    const f64x4 b0 = ld4(Lt + (int64_t)t64idx(M, J) * 256 + 16 * li + 4 * lq);
-                    acc = mfma(a0.x, b0.x, acc); acc = mfma(a0.y, b0.y, acc);
-                    acc = mfma(a0.z, b0.z, acc); acc = mfma(a0.w, b0.w, acc);
-                }
-                acc += acc2;
-                double* kt = Ks + (int64_t)t * 256;
+                __syncthreads();
+                for (int J = wave; J <= I; J += NWAVE) {
+                    const int M0 = (I - 1 > J) ? I - 1 : J;
+                    f64x4 acc = zero4, acc2 = zero4;
+                    f64x4 B0[4], B1[4];
+                    auto fetchB = [&](f64x4 (&Bq)[4], int Mb) {
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) kt[t64off(lq + 4 * rr, li)] = acc[rr];
+                        for (int i = 0; i < 4; ++i) {
+                            Bq[i] = zero4;
+                            if (Mb + i < nb) Bq[i] = ld4(Lt + (int64_t)t64idx(Mb + i, J) * 256 + 16 * li + 4 * lq);
+                        }
+                    };
+                    auto mm = [&](const f64x4 (&Bq)[4], int Mb) {
+                        f64x4 A[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            A[i] = zero4;
+                            if (Mb + i < nb) A[i] = ld4(Pj + (Mb + i - Mlo) * 256 + 4 * lane);
+                        }
+                        acc = mfma(A[0].x, Bq[0].x, acc); acc2 = mfma(A[1].x, Bq[1].x, acc2);
+                        acc = mfma(A[0].y, Bq[0].y, acc); acc2 = mfma(A[1].y, Bq[1].y, acc2);
+                        acc = mfma(A[0].z, Bq[0].z, acc); acc2 = mfma(A[1].z, Bq[1].z, acc2);
+                        acc = mfma(A[0].w, Bq[0].w, acc); acc2 = mfma(A[1].w, Bq[1].w, acc2);
+                        acc = mfma(A[2].x, Bq[2].x, acc); acc2 = mfma(A[3].x, Bq[3].x, acc2);
+                        acc = mfma(A[2].y, Bq[2].y, acc); acc2 = mfma(A[3].y, Bq[3].y, acc2);
+                        acc = mfma(A[2].z, Bq[2].z, acc); acc2 = mfma(A[3].z, Bq[3].z, acc2);
+                        acc = mfma(A[2].w, Bq[2].w, acc); acc2 = mfma(A[3].w, Bq[3].w, acc2);
+                    };
+                    fetchB(B0, M0);
+                    for (int Mb = M0; Mb < nb; Mb += 8) {
+                        if (Mb + 4 < nb) fetchB(B1, Mb + 4);
+                        mm(B0, Mb);
+                        if (Mb + 4 < nb) {
+                            if (Mb + 8 < nb) fetchB(B0, Mb + 8);
+                            mm(B1, Mb + 4);
+                        }
+                    }
+                    acc += acc2;
+                    double* kt = Ks + (int64_t)t64idx(I, J) * 256;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) kt[t64off(lq + 4 * rr, li)] = acc[rr];
+                }
+                __syncthreads();
             }
-            __syncthreads();
             S64(7);
-            factor(Ks, Fs, false);
+            factor(Ks, Fs, std::false_type{});
             if (s_flag == 0) {
                 status = 2;
                 break;

@@ -340,6 +340,9 @@ int ftmpc_multi_last_kernel_ms(ftmpc_multi* m, int32_t slot, float* ms, int32_t 
 
 /* Library/ABI version: major*10000 + minor*100 + patch. */
 int32_t ftmpc_version(void);
+/* Hash of the kernel and host sources this binary was built from (csrc/Makefile): two builds of the same sources -- the
+ * shipped one and the `plain` diagnostic build with the asm-side wait states as written -- report the same string. */
+const char* ftmpc_build_id(void);
 
 #ifdef __cplusplus
 }

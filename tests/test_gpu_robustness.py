@@ -82,6 +82,7 @@ for name, N, NT, nf, B, dtype, sel in cases:
     mpc.close()
     for k in ("u0", "U", "status", "iters"):
         out[name + "/" + k] = r[k]
+out["build_id"] = np.frombuffer(ft_mpc_amd._lib.load_library().ftmpc_build_id(), dtype=np.uint8)
 np.savez(sys.argv[2], **out)
 print(ft_mpc_amd._lib.library_path())
 """
@@ -104,6 +105,8 @@ def test_lowered_wait_states_give_the_bits_of_the_plain_build(tmp_path):
         assert p.stdout.strip().endswith("libftmpc_hip_plain.so" if so is not None else "libftmpc_hip.so"), p.stdout
         res[tag] = dict(np.load(npz))
     assert res["shipped"].keys() == res["plain"].keys()
+    ids = [bytes(res[t]["build_id"]).decode() for t in ("shipped", "plain")]
+    assert ids[0] == ids[1] and ids[0] != "unknown", f"the plain build is stale (sources {ids[1]}, shipped {ids[0]}): make -C fault-tolerant-mpc_amd/csrc plain"
     for k in res["shipped"]:
         assert np.array_equal(res["shipped"][k], res["plain"][k]), k
         if k.endswith("/status"):

@@ -79,26 +79,42 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+// The lane number, recomputed where it is needed (two v_mbcnt) and opaque to the optimiser.  Everything the hot regions
+// derive from the lane -- li, lq, the per-lane LDS addresses of the vector workspace -- used to be computed once per
+// kernel, kept live across the whole interior-point loop and SPILLED: every ds_write of a solution block then waited for a
+// scratch reload of its own address (an HBM round trip in place of one v_lshlrev).
+__device__ __forceinline__ int lane_now() {
+    int l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));
+    return l;
+}
 // The Hessian tiles (register order: word 4*lane + s of a 256-word tile) live in LDS for NB = 8; for the
 // larger instantiations they would cut the residency to 3 or 2 waves per CU, so there they sit in the
 // per-workgroup global slot (L2 / Infinity-Cache resident; every lane re-reads only what it wrote itself).
 typedef __attribute__((address_space(1))) float glb_f32;
 // NLDS = number of leading tiles (tile number I(I+1)/2 + J, i.e. whole block rows) kept in LDS; the
 // rest sits in the global slot.  Tile numbers are compile-time constants at every call site.
+// The global tiles are addressed through a BUFFER resource: the slot base sits in four SGPRs, the tile number is a scalar
+// offset and every lane contributes the same 16 * lane bytes -- one VGPR for all tiles.  As plain pointers the compiler
+// forms one 64-bit per-lane address per tile, hoists the lot out of the interior-point loop and spills it, so that every
+// tile load waited for a scratch reload of its own address first.
 template <int NLDS>
 struct TileStore {
-    float* p;        // LDS, tiles [0, NLDS)
-    glb_f32* g;      // global slot, tiles [NLDS, ..)
-    typedef __attribute__((address_space(1))) f32x4 glb_f32x4;
+    float* p;                    // LDS, tiles [0, NLDS)
+    __amdgpu_buffer_rsrc_t r;    // global slot, tiles [NLDS, ..)
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
     static constexpr bool is_global(int tile) { return tile >= NLDS; }
     static constexpr bool any_global(int ntiles) { return ntiles > NLDS; }
+    __device__ __forceinline__ void bind(float* slot_tiles) {
+        r = __builtin_amdgcn_make_buffer_rsrc(slot_tiles, 0, 0x7fffffff, 0x00020000);
+    }
     __device__ __forceinline__ f32x4 ld(int tile, int lane) const {
         if (tile < NLDS) return *reinterpret_cast<const f32x4*>(p + tile * 256 + 4 * lane);
-        return *reinterpret_cast<const glb_f32x4*>(g + (tile - NLDS) * 256 + 4 * lane);
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, 16 * lane, (tile - NLDS) * 1024, 0));
     }
     __device__ __forceinline__ void st(int tile, int lane, f32x4 v) const {
         if (tile < NLDS) *reinterpret_cast<f32x4*>(p + tile * 256 + 4 * lane) = v;
-        else *reinterpret_cast<glb_f32x4*>(g + (tile - NLDS) * 256 + 4 * lane) = v;
+        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), r, 16 * lane, (tile - NLDS) * 1024, 0);
     }
 };
 
@@ -382,22 +398,27 @@ __device__ __forceinline__ float row_sum16(float x) {
 // one block column of the register-resident factorisation (template recursion instead of a
 // `#pragma unroll` loop: the barrier inside would otherwise block the unroller and push the
 // tile arrays into scratch).  T[tidx(I,J)] = L_IJ' for I > J, T[tidx(J,J)] = W_J', Wd[J] = W_J.
-template <int NB, int J, class TilesT>
+// WL: nullptr, or LDS for the inverse diagonal blocks W_J (NB x 256 words, register order) instead of Wd -- the two-waves-per-SIMD
+// build of the NB = 8 instantiation keeps 28 tiles of the factor in registers and nothing else of it.
+// PREF: tiles of the global slot are requested a block column ahead (registers for a whole column) or where they are used
+// (a second resident wave covers the latency instead).
+template <int NB, int J, class TilesT, bool PREF = true, bool WLDS = false>
 __device__ __forceinline__ void chol_reg_col(const TilesT& tiles, const float* sigv, float* S, int nb, int lane, bool& ok,
-                                             f32x4 (&T)[NB * (NB + 1) / 2], f32x4 (&Wd)[NB], const f32x4 (&pre)[NB]) {
+                                             f32x4 (&T)[NB * (NB + 1) / 2], f32x4 (&Wd)[NB], const f32x4 (&pre)[NB], float* WL = nullptr) {
+    lane = lane_now();
     const int li = lane & 15, lq = lane >> 4;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     {
         // every accumulator starts from the stored tile (-H, register order) and collects  sum_K T_JK' T_IK  on top.
         // Tiles that live in the global slot were requested before the previous column's potrf (`pre`), and
         // the next column's are requested here, a potrf ahead of their use.
-        f32x4 a0 = TilesT::is_global(tidx(J, J)) ? pre[J] : tiles.ld(tidx(J, J), lane), a1 = zero;
+        f32x4 a0 = (PREF && TilesT::is_global(tidx(J, J))) ? pre[J] : tiles.ld(tidx(J, J), lane), a1 = zero;
         f32x4 bacc[NB];
 #pragma unroll
-        for (int I = 0; I < NB; ++I) bacc[I] = (I > J) ? (TilesT::is_global(tidx(I, J)) ? pre[I] : tiles.ld(tidx(I, J), lane)) : zero;
+        for (int I = 0; I < NB; ++I) bacc[I] = (I > J) ? ((PREF && TilesT::is_global(tidx(I, J))) ? pre[I] : tiles.ld(tidx(I, J), lane)) : zero;
         f32x4 nxt[NB];
 #pragma unroll
-        for (int I = 0; I < NB; ++I) nxt[I] = (J + 1 < NB && I > J && TilesT::is_global(tidx(I, J + 1))) ? tiles.ld(tidx(I, J + 1), lane) : zero;
+        for (int I = 0; I < NB; ++I) nxt[I] = (PREF && J + 1 < NB && I > J && TilesT::is_global(tidx(I, J + 1))) ? tiles.ld(tidx(I, J + 1), lane) : zero;
 #pragma unroll
         for (int K = 0; K < J; ++K) {
             if (K & 1) a1 = mm_tn(T[tidx(J, K)], T[tidx(J, K)], a1);
@@ -409,7 +430,8 @@ __device__ __forceinline__ void chol_reg_col(const TilesT& tiles, const float* s
         for (int rr = 0; rr < 4; ++rr) cd[rr] = ((4 * lq + rr == li) ? sg : 0.f) - (a0[rr] + a1[rr]);   // H + Sigma - sum
         const f32x4 w = potrf_inv16_call(cd, lane, SchurWork<NB, J>{T, bacc});
         ok = ok && (fabsf(w.w) <= 3.0e38f);   // NaN or inf in W[15][15]: non-positive pivot
-        Wd[J] = w;
+        if constexpr (WLDS) *reinterpret_cast<f32x4*>(WL + J * 256 + 4 * lane) = w;
+        else Wd[J] = w;
         // Wt = W' through a 16x17 LDS scratch
         wave_lds_fence();
 #pragma unroll
@@ -424,18 +446,18 @@ __device__ __forceinline__ void chol_reg_col(const TilesT& tiles, const float* s
         T[tidx(J, J)] = wt;
 #pragma unroll
         for (int I = J + 1; I < NB; ++I) T[tidx(I, J)] = mm_tn(wtn, bacc[I], zero);    // L_IJ' = W_J (H_IJ' - sum) = -W_J bacc
-        if constexpr (J + 1 < NB) chol_reg_col<NB, J + 1, TilesT>(tiles, sigv, S, nb, lane, ok, T, Wd, nxt);
+        if constexpr (J + 1 < NB) chol_reg_col<NB, J + 1, TilesT, PREF, WLDS>(tiles, sigv, S, nb, lane, ok, T, Wd, nxt, WL);
     }
 }
 
-template <int NB, class TilesT>
+template <int NB, class TilesT, bool PREF = true, bool WLDS = false>
 __device__ __forceinline__ bool chol_reg(const TilesT& tiles, const float* sigv, float* S, int nb, int lane,
-                                         f32x4 (&T)[NB * (NB + 1) / 2], f32x4 (&Wd)[NB]) {
+                                         f32x4 (&T)[NB * (NB + 1) / 2], f32x4 (&Wd)[NB], float* WL = nullptr) {
     bool ok = true;
     f32x4 pre[NB];
 #pragma unroll
-    for (int I = 0; I < NB; ++I) pre[I] = TilesT::is_global(tidx(I, 0)) ? tiles.ld(tidx(I, 0), lane) : f32x4{0.f, 0.f, 0.f, 0.f};
-    chol_reg_col<NB, 0, TilesT>(tiles, sigv, S, nb, lane, ok, T, Wd, pre);
+    for (int I = 0; I < NB; ++I) pre[I] = (PREF && TilesT::is_global(tidx(I, 0))) ? tiles.ld(tidx(I, 0), lane) : f32x4{0.f, 0.f, 0.f, 0.f};
+    chol_reg_col<NB, 0, TilesT, PREF, WLDS>(tiles, sigv, S, nb, lane, ok, T, Wd, pre, WL);
     return __all(ok);
 }
 
@@ -447,10 +469,16 @@ __device__ __forceinline__ bool chol_reg(const TilesT& tiles, const float* sigv,
 //     over the 4 row-groups (permlane swaps)              -> "row" vectors          v[col] in every row-group
 //   forward   r_J = b_J - sum_{K<J} L_JK y_K   (row vector:  sum_q sum_s T_JK[s] y_K[s]),   y_J = W_J r_J   (column tile)
 //   backward  r_J = y_J - sum_{I>J} L_IJ' x_I  (column tile: row sums of T_IJ[s] x_I[col]), x_J = W_J' r_J  (row vector)
-template <int NB>
-__device__ __forceinline__ void solve_reg(const f32x4 (&T)[NB * (NB + 1) / 2], const f32x4 (&Wd)[NB],
-                                          float* xv, int nb, int lane) {
+template <int NB, bool WLDS = false>
+__device__ __forceinline__ void solve_reg(const f32x4 (&T)[NB * (NB + 1) / 2], const f32x4 (&WdR)[NB],
+                                          float* xv, int nb, int lane, const float* WL = nullptr) {
+    lane = lane_now();
     const int li = lane & 15, lq = lane >> 4;
+    // the inverse diagonal blocks: registers, or (WL) one conflict-free b128 per block and sweep from LDS
+    auto Wof = [&](int J) -> f32x4 {
+        if constexpr (WLDS) return *reinterpret_cast<const f32x4*>(WL + J * 256 + 4 * lane);
+        else return WdR[J];
+    };
     // Right-looking order: as soon as a block of the solution is known its contribution goes to ALL
     // later right-hand sides.  These updates are independent of each other and fill the issue slots
     // of the one chain that is serial (reduce -> W -> reduce), which a single wave cannot hide otherwise.
@@ -463,7 +491,8 @@ __device__ __forceinline__ void solve_reg(const f32x4 (&T)[NB * (NB + 1) / 2], c
         float r = xv[16 * J + li];
         if (J > 0) r -= quad_sum(p[J].x + p[J].y);
         {
-            float y0 = Wd[J].x * r, y1 = Wd[J].y * r, y2 = Wd[J].z * r, y3 = Wd[J].w * r;
+            const f32x4 wj = Wof(J);
+            float y0 = wj.x * r, y1 = wj.y * r, y2 = wj.z * r, y3 = wj.w * r;
             row_sum16x4(y0, y1, y2, y3);
             Y[J] = f32x4{y0, y1, y2, y3};
         }
@@ -478,6 +507,8 @@ __device__ __forceinline__ void solve_reg(const f32x4 (&T)[NB * (NB + 1) / 2], c
     f32x2 a0[NB], a1[NB];
 #pragma unroll
     for (int J = 0; J < NB; ++J) a0[J] = a1[J] = f32x2{0.f, 0.f};
+    const int lb = lane_now();
+    const int li_b = lb & 15, lq_b = lb >> 4;
 #pragma unroll
     for (int J = NB - 1; J >= 0; --J) {
         f32x4 r = Y[J];
@@ -486,9 +517,10 @@ __device__ __forceinline__ void solve_reg(const f32x4 (&T)[NB * (NB + 1) / 2], c
             row_sum16x4(s0, s1, s2, s3);
             r -= f32x4{s0, s1, s2, s3};
         }
-        const f32x2 d2 = f32x2{Wd[J].x, Wd[J].y} * f32x2{r.x, r.y} + f32x2{Wd[J].z, Wd[J].w} * f32x2{r.z, r.w};
+        const f32x4 wb = Wof(J);
+        const f32x2 d2 = f32x2{wb.x, wb.y} * f32x2{r.x, r.y} + f32x2{wb.z, wb.w} * f32x2{r.z, r.w};
         const float xr = quad_sum(d2.x + d2.y);
-        if (lq == 0) xv[16 * J + li] = xr;
+        if (lq_b == 0) xv[16 * J + li_b] = xr;
         const f32x2 xx = {xr, xr};
 #pragma unroll
         for (int K = 0; K < J; ++K) {
@@ -831,14 +863,24 @@ static_assert(tile_row_ok(), "state-component permutation of the sensitivity til
 
 }  // namespace
 
+// Resident waves per SIMD of the NB = 8 instantiation (the headline shape: n <= 128).  2: 256 registers and <= 20 KiB of LDS per
+// wave -- Hessian tiles in the per-workgroup global slot, W_J in LDS, see OCC2 below; 1: the round-2 form (512 registers, all
+// tiles in LDS).  Measured, 65 536 double-fault instances: 17.5 ms at 1, 14.1-15.0 ms at 2.
+#ifndef FTMPC_F32_OCC
+#define FTMPC_F32_OCC 2
+#endif
 template <int NB>
-__global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceConsts C, const SolveParams P) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 8) ? FTMPC_F32_OCC : 1, (NB == 8) ? FTMPC_F32_OCC : 1))) ftmpc_solve_f32_kernel(const DeviceConsts C, const SolveParams P) {
     using SH = Shape<NB>;
     constexpr int NPAD = SH::NPAD, NV = SH::NV, NTILES = SH::NTILES;
     // Hessian tiles kept in LDS (whole block rows; see TileStore): all 36 for NB = 8; the first 8 block rows
     // (36 tiles) for NB = 9, whose ninth row comes from the global slot one tile per column; the first 35
     // of 55 for NB = 10.  Each choice leaves 4 resident waves per CU (one per SIMD).
-    constexpr int NLDS = (NB == 8) ? NTILES : (NB == 9 ? 36 : 35);
+    constexpr int NLDS = (NB == 8) ? ((FTMPC_F32_OCC > 1) ? 0 : NTILES) : (NB == 9 ? 36 : 35);
+    // NB = 8 built for TWO resident waves per SIMD (FTMPC_F32_OCC = 2): 256 registers and 20 KiB of LDS per wave.  The Hessian
+    // tiles go to the per-workgroup global slot (Infinity-Cache resident, read where they are used: the partner wave covers the
+    // latency), the inverse diagonal blocks W_J to LDS, and the build keeps no scaled copy of the sensitivity tiles.
+    constexpr bool OCC2 = (NB == 8) && (FTMPC_F32_OCC > 1);
     constexpr int BUILD_WORDS = 2 * DENSE_WORDS + 256;   // dense stage-matrix images of the build phase; later N*NT output words
     __shared__ __attribute__((aligned(16))) float tiles[(NLDS * 256 > BUILD_WORDS) ? NLDS * 256 : BUILD_WORDS];
     __shared__ __attribute__((aligned(16))) float recbuf[2 * REC_STRIDE + 8];   // two fp32 stage records | one fp64 record + {0,1,dt}
@@ -846,6 +888,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
     __shared__ __attribute__((aligned(16))) float s_Da[6 * MAX_NT];
     __shared__ unsigned char s_stg[NPAD], s_thr[NPAD];
     __shared__ int s_act[MAX_NT];
+    __shared__ __attribute__((aligned(16))) float wlds[OCC2 ? NB * 256 : 4];   // W_J of the current factorisation (OCC2)
     float* const dense = tiles;      // build phase only: 2 x (A 16x16 | B 16x8 | dump word), then LPt 16x16
     float* const xvp = work;         // rhs / solution of the KKT solves
     float* const dvp = work + NPAD;  // d, permuted layout (gradient mat-vec); with the tail: struct_grad stage storage
@@ -855,7 +898,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
     const int N = C.N, NT = C.NT;
     TileStore<NLDS> htiles;
     htiles.p = tiles;
-    htiles.g = (glb_f32*)(P.hscratch + (int64_t)blockIdx.x * P.tile_words + slot_tile_off_words(C.N));
+    htiles.bind(P.hscratch + (int64_t)blockIdx.x * P.tile_words + slot_tile_off_words(C.N));
     const float rho = (float)C.rho;
     const float mu_stop = (float)C.mu_stop;
     float Rf[6];
@@ -979,22 +1022,24 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
         }
         // the sensitivity G = d c_{k+1} / d U as accumulator tiles: G[X] reg s of lane (q, col) is row 4q+s
         // (tile_row order: the 9 costed components sit in registers 0..2 of row-groups 0..2) of column 16X+col
-        int kX[NB];
-        float DaB[NB][2];           // B operand of the new columns: Da[g = 4s+q][thruster of column 16X+col]
+        int kX[OCC2 ? 1 : NB];
+        float DaB[OCC2 ? 1 : NB][2];           // B operand of the new columns: Da[g = 4s+q][thruster of column 16X+col]
         f32x4 G[NB];
         float gpart[NB];
 #pragma unroll
         for (int X = 0; X < NB; ++X) {
-            kX[X] = s_stg[16 * X + li];
-            const int ax = s_thr[16 * X + li];
-            DaB[X][0] = (ax != 255) ? s_Da[lq * MAX_NT + ax] : 0.f;
-            DaB[X][1] = (ax != 255 && lq < 2) ? s_Da[(4 + lq) * MAX_NT + ax] : 0.f;
+            if constexpr (!OCC2) {
+                kX[X] = s_stg[16 * X + li];
+                const int ax = s_thr[16 * X + li];
+                DaB[X][0] = (ax != 255) ? s_Da[lq * MAX_NT + ax] : 0.f;
+                DaB[X][1] = (ax != 255 && lq < 2) ? s_Da[(4 + lq) * MAX_NT + ax] : 0.f;
+            }
             G[X] = (f32x4){0.f, 0.f, 0.f, 0.f};
             gpart[X] = 0.f;
         }
-        float esc[3];               // sqrt(2 Q) of this lane's costed rows (row-group 3 holds the quaternion: 0)
+        float esc[3];               // sqrt(2 Q) of this lane's costed rows (row-group 3 holds the quaternion: 0); OCC2: 2 Q
 #pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3) esc[s3] = (lq < 3) ? (float)C.sq2Q[3 * s3 + lq] : 0.f;
+        for (int s3 = 0; s3 < 3; ++s3) esc[s3] = (lq < 3) ? (OCC2 ? 2.f * (float)C.Q[3 * s3 + lq] : (float)C.sq2Q[3 * s3 + lq]) : 0.f;
         f32x4 acc[NTILES];
 #pragma unroll
         for (int t = 0; t < NTILES; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1028,6 +1073,8 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
         //   acc(I,J) += E_I' E_J,   g += G' W e_k
         auto stage = [&](int k, auto TERM) {
             constexpr bool terminal = decltype(TERM)::value;
+            const int lane = lane_now();
+            const int li = lane & 15, lq = lane >> 4;
             float* rb = recbuf + (k & 1) * REC_STRIDE;
             float* dd = dense + (k & 1) * DENSE_WORDS;
             if (lane < REC_STRIDE / 4) {
@@ -1055,8 +1102,17 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 if (X <= Imax) {
                     f32x4 o = zero4;
                     if (X >= Xnew) {
-                        const bool mine = (kX[X] == k);
-                        const float d0 = mine ? DaB[X][0] : 0.f, d1 = mine ? DaB[X][1] : 0.f;
+                        float d0, d1;
+                        if constexpr (OCC2) {     // the one or two tiles that hold the columns of stage k: read off the tables
+                            const int ax = *(volatile unsigned char*)&s_thr[16 * X + li];
+                            const bool mine = (*(volatile unsigned char*)&s_stg[16 * X + li] == k);
+                            d0 = mine ? s_Da[lq * MAX_NT + (ax & (MAX_NT - 1))] : 0.f;
+                            d1 = (mine && lq < 2) ? s_Da[(4 + lq) * MAX_NT + (ax & (MAX_NT - 1))] : 0.f;
+                        } else {
+                            const bool mine = (kX[X] == k);
+                            d0 = mine ? DaB[X][0] : 0.f;
+                            d1 = mine ? DaB[X][1] : 0.f;
+                        }
                         o = mfma4(b0, d0, o);
                         o = mfma4(b1, d1, o);
                         gpart[X] += d0 * rut0 + d1 * rut1;   // input-cost gradient of the new columns, Da[:, a]' (R .* ut_k): rows g = lq, 4+lq
@@ -1072,9 +1128,11 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
                 if (X <= Imax) {
                     gpart[X] += we[0] * G[X].x + we[1] * G[X].y + we[2] * G[X].z;
                     if (!terminal) {
-                        E[X][0] = esc[0] * G[X].x;
-                        E[X][1] = esc[1] * G[X].y;
-                        E[X][2] = esc[2] * G[X].z;
+                        if constexpr (!OCC2) {
+                            E[X][0] = esc[0] * G[X].x;
+                            E[X][1] = esc[1] * G[X].y;
+                            E[X][2] = esc[2] * G[X].z;
+                        }
                     } else {
                         f32x4 o = zero4;
                         o = mfma4(lp4.x, G[X].x, o);
@@ -1090,11 +1148,23 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
 #pragma unroll
             for (int I = 0; I < NB; ++I)
                 if (I <= Imax) {
+                    float eI[3] = {0.f, 0.f, 0.f};
+                    if constexpr (OCC2 && !terminal) {   // E_J' E_I = G_J' (2 Q) G_I: the weight on one operand, no scaled copy of G
+                        eI[0] = esc[0] * G[I].x;
+                        eI[1] = esc[1] * G[I].y;
+                        eI[2] = esc[2] * G[I].z;
+                    }
 #pragma unroll
                     for (int J = 0; J <= I; ++J) {
                         // tile (I,J) is kept TRANSPOSED, (H_IJ)' = E_J' E_I: the layout the factorisation consumes
+                        if constexpr (OCC2 && !terminal) {
+                            acc[(I * (I + 1)) / 2 + J] = mfma4(G[J].x, eI[0], acc[(I * (I + 1)) / 2 + J]);
+                            acc[(I * (I + 1)) / 2 + J] = mfma4(G[J].y, eI[1], acc[(I * (I + 1)) / 2 + J]);
+                            acc[(I * (I + 1)) / 2 + J] = mfma4(G[J].z, eI[2], acc[(I * (I + 1)) / 2 + J]);
+                        } else {
 #pragma unroll
                         for (int s3 = 0; s3 < 3; ++s3) acc[(I * (I + 1)) / 2 + J] = mfma4(E[J][s3], E[I][s3], acc[(I * (I + 1)) / 2 + J]);
+                        }
                         // last stage (peeled copy of the stage code): the tile is complete -- finish and store it right
                         // here, so that its accumulator dies now; finishing all 36 after the loop keeps them live across
                         // that code and costs ~50 scratch round trips
@@ -1204,6 +1274,9 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
         const float inv2n = 1.0f / (float)(2 * n);
         for (int it = 0; it <= C.max_iters; ++it) {
             wave_lds_fence();
+            const int lane = lane_now();
+            const int li = lane & 15, lq = lane >> 4;
+            (void)li; (void)lq;
             const bool do_ref = __builtin_amdgcn_readfirstlane(!refined && mu_last < (float)C.mu_refine);
             float dcur[NV];
             if (do_ref || it == 0) {
@@ -1343,7 +1416,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
             }
             wave_lds_fence();
             STAMP(7);
-            const bool ok = chol_reg<NB>(htiles, dvp, recbuf, nbr, lane, Tt, Wd);
+            const bool ok = chol_reg<NB, TileStore<NLDS>, true, OCC2>(htiles, dvp, recbuf, nbr, lane, Tt, Wd, wlds);
             STAMP(5);
             if (__builtin_amdgcn_readfirstlane(!ok)) {
                 status = 2;
@@ -1357,7 +1430,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
             }
             wave_lds_fence();
             STAMP(7);
-            solve_reg<NB>(Tt, Wd, xvp, nbr, lane);
+            solve_reg<NB, OCC2>(Tt, Wd, xvp, nbr, lane, wlds);
             STAMP(6);
             float da[NV], dzl_a[NV], dzu_a[NV];
             float ap = 1.f, ad = 1.f;
@@ -1401,7 +1474,7 @@ __global__ void __launch_bounds__(64, 1) ftmpc_solve_f32_kernel(const DeviceCons
             }
             wave_lds_fence();
             STAMP(7);
-            solve_reg<NB>(Tt, Wd, xvp, nbr, lane);
+            solve_reg<NB, OCC2>(Tt, Wd, xvp, nbr, lane, wlds);
             STAMP(6);
             float dd[NV], dzl[NV], dzu[NV];
             ap = 1e30f;

@@ -48,7 +48,51 @@ def algorithmic_flops(N, na, iters):
     return f_lin + f_cond + f_h + f_g + iters * f_it
 
 
-def batch_flops(N, ub, iters):
+def executed_flops_wrench(N, na, iters):
+    """Work the wrench-space kernels (ftmpc_solve_ws32_kernel, ftmpc_solve_ws64_kernel) EXECUTE for one instance with `na`
+    healthy thrusters: condensing in the six wrench components, one Cholesky of the 6N x 6N Hessian H_w, and per
+    interior-point iteration the assembly of K = I + L'SL (stage blocks, P' = L'S with S block diagonal, the lower triangle
+    of X = P'L), its Cholesky, and two Newton solves through wrench space (two triangular products with L and two
+    triangular sweeps each) plus the element-wise work over the N na thruster variables (kernels 8 / 9)."""
+    nx, nq, ng = 13, 9, 6
+    nw, nt = 6 * N, N * na
+    f_lin = N * (8 * nx ** 3 + 8 * nx ** 2 * ng + 2 * nx * ng * na)
+    f_cond = N * (N - 1) * nx ** 2 * ng
+    f_h = 2 * nq * ng ** 2 * N * (N + 1) * (N + 2) / 6
+    f_g = nq * ng * N * (N + 1)
+    f_once = nw ** 3 / 3 + 2 * nw ** 2 + 2 * ng * nt        # factor of H_w, start gradient
+    f_it = (42 * N * na) + 6 * nw ** 2 + nw ** 3 / 3 + nw ** 3 / 3 + 2 * (4 * nw ** 2 + 4 * ng * nt) + 30 * nt
+    return f_lin + f_cond + f_h + f_g + f_once + iters * f_it
+
+
+def batch_flops(N, ub, iters, model=algorithmic_flops):
+    if model is not algorithmic_flops:
+        na = (ub > 0).sum(axis=1)
+        tot = 0.0
+        for a in np.unique(na):
+            sel = na == a
+            tot += float(model(N, int(a), 0)) * int(sel.sum()) + float(model(N, int(a), 1) - model(N, int(a), 0)) * float(iters[sel].sum())
+        return tot
+    return _batch_flops_dense(N, ub, iters)
+
+
+def workload_name(args, B, N, NT, f64):
+    """What the arguments describe, and which BASELINE.json config that is (if any)."""
+    base = None
+    if (N, NT) == (20, 8) and not f64:
+        if args.faults == 1 and B == 4096:
+            base = "configs[1]"
+        elif args.faults == 2 and B == 65536:
+            base = "configs[2]"
+        elif args.faults == 2 and B == 32768:
+            base = "configs[3] shard (262144 / 8 GPUs)"
+    if (N, NT) == (40, 16) and f64 and args.faults == 2 and B == 2048:
+        base = "configs[4] shard (16384 / 8 GPUs)"
+    w = f"batch {B}/GPU, N={N}, {NT} thrusters, random {args.faults}-fault Monte-Carlo, cold start, hover reference"
+    return w + (f" (BASELINE {base})" if base else " (not a BASELINE config: see config.batch_per_gpu / horizon / thrusters)")
+
+
+def _batch_flops_dense(N, ub, iters):
     na = (ub > 0).sum(axis=1)
     tot = 0.0
     for a in np.unique(na):
@@ -135,23 +179,27 @@ def make_line(args, world, elapsed, B, N, NT, iters, status, ub, kernel_ms, para
     dom = max(kernel_ms, key=kernel_ms.get)
     sol_ms = kernel_ms[dom]
     flops = batch_flops(N, ub, iters)
-    f64 = args.dtype == "f64" or N * NT > 240
+    f64 = "f64" in dom or "ws64" in dom
     peak = F64_PEAK_TFLOPS if f64 else F32_PEAK_TFLOPS
     achieved = flops / (sol_ms * 1e-3) / 1e12
     traffic, traffic_src = traffic_for(dom, B, N, NT)
-    # the workgroup slot runs kernel 8 (Newton systems through the 6N-variable wrench-space form) when it applies: the flop model
-    # above is SURVEY.md 8(d)'s dense one, i.e. the work the QP step stands for, not what that kernel executes
+    # the wrench-space kernels (8: ws32, 9: ws64) solve the Newton systems through the 6N-variable form: `achieved` / `frac` above
+    # follow SURVEY.md 8(d)'s DENSE flop model -- the work the QP step stands for -- and `executed` what the kernel really does
     note = {}
-    if "ws32" in dom:
-        note = {"work_model_note": "algorithmic flops of the dense condensed IPM (SURVEY.md 8(d)); this kernel factorises 6N x 6N "
-                                   "matrices instead of (N na) x (N na) and executes fewer"}
+    if "ws32" in dom or "ws64" in dom:
+        ex = batch_flops(N, ub, iters, executed_flops_wrench)
+        note = {"executed": {"flops_per_launch": ex, "achieved": ex / (sol_ms * 1e-3) / 1e12, "frac": ex / (sol_ms * 1e-3) / 1e12 / peak,
+                             "model": "bench.py:executed_flops_wrench (condensing in 6 wrench components, one Cholesky of H_w, per iteration "
+                                      "the assembly and Cholesky of K = I + L'SL (6N x 6N) and two solves through wrench space)"},
+                "work_model_note": "achieved / frac: algorithmic flops of the dense condensed IPM (SURVEY.md 8(d)); executed.*: the work "
+                                   "this kernel performs (it factorises 6N x 6N matrices instead of (N na) x (N na))"}
+    default_shape = (B, N, NT, args.faults) == (65536, 20, 8, 2) and not f64
     return {
-        "metric": METRIC,
+        "metric": METRIC if default_shape else f"MPC QP steps/s (whole node) at N={N}, {NT} thrusters, batch {B}",
         "value": args.steps * B * world / elapsed, "unit": "QP-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64" if f64 else "f32", "data": "synthetic",
-        "config": {"workload": f"batch {B}/GPU, N={N}, {NT} thrusters, random {args.faults}-fault Monte-Carlo, "
-                               f"cold start, hover reference (BASELINE configs[2])",
+        "config": {"workload": workload_name(args, B, N, NT, f64),
                    "batch_per_gpu": B, "horizon": N, "thrusters": NT, "faults": args.faults,
                    "ipm_iters_mean": float(iters.mean()), "ipm_iters_max": int(iters.max()),
                    "not_converged": int((status != 0).sum()), "parallelism": parallelism},

@@ -434,3 +434,20 @@ def test_device_pointer_entry_matches_host_entry(gpu_mpc_factory):
     W = host["U"].copy()
     host2 = mpc.solve(x0, ub, stuck, xr, warmU=W, return_U=True)
     assert np.array_equal(d_U.cpu().numpy(), host2["U"]) and np.array_equal(W, host2["U"])
+
+
+@pytest.mark.parametrize("name,dtype,sel,tol", [("refvehicle_n15", "f32", "auto", 1e-4), ("refvehicle_n15", "f32", "dense", 1e-4),
+                                                ("refvehicle_n20", "f32", "auto", 1e-4), ("refvehicle_n15", "f64", "auto", 1e-7),
+                                                ("refvehicle_n20", "f64", "auto", 1e-7), ("refvehicle_n20", "f64", "dense", 1e-7),
+                                                ("cfg5_n40_nt16", "f64", "auto", 1e-7), ("cfg5_n40_nt16", "f64", "dense", 1e-7)])
+def test_sixteen_thruster_kernels_against_golden(gpu_mpc_factory, name, dtype, sel, tol):
+    """Committed exact (BVLS) solutions for the reference vehicle at N = 15 / 20 and BASELINE config 5 (tests/golden/, made by
+    oracle/gen_golden.py:qp_fixtures_large): kernels 8 / 7 (fp32), 9 and the dense float64 kernel."""
+    d = np.load(__import__("pathlib").Path(__file__).parent / "golden" / f"qp_{name}.npz")
+    N, NT = int(d["N"]), int(d["NT"])
+    assert d["x0"].shape[0] >= 16
+    mpc = gpu_mpc_factory(N=N, NT=NT, dtype=dtype, kernel_select=sel, max_iters=40)
+    out = mpc.solve(d["x0"], d["ub"], d["stuck"], d["xref"].reshape(-1, order="F"), return_U=True)
+    assert (out["status"] == 0).all(), out["status"]
+    assert np.abs(out["u0"] - d["u0"]).max() / F_MAX <= tol
+    assert np.abs(out["U"] - d["U"]).max() / F_MAX <= (2e-3 if dtype == "f32" else 1e-6)

@@ -193,3 +193,21 @@ def test_terminal_set_needs_the_float64_kernel():
     with pytest.raises(ft_mpc_amd.FtmpcError) as e:
         ft_mpc_amd.BatchedMPC(N=20, NT=8, dtype="f32", terminal_set=True)
     assert "F64" in str(e.value)
+
+
+def test_general_constraint_forms_against_golden(gpu_mpc_factory):
+    """The committed fixtures of the reference's own formulation (tests/golden/qp_wrench_hull_n15.npz: hull rows per stage;
+    qp_terminal_set_n20.npz: 72-row terminal set, reachable and unreachable instances) against the HIP path."""
+    from pathlib import Path
+    g = Path(__file__).parent / "golden"
+    d = np.load(g / "qp_wrench_hull_n15.npz")
+    mpc = gpu_mpc_factory(N=int(d["N"]), NT=int(d["NT"]), dtype="f64", max_iters=40)
+    out = mpc.solve_wrench(d["x0"], d["ub"], d["stuck"], d["xref"].reshape(-1, order="F"), return_G=True)
+    assert (out["status"] == 0).all() and d["x0"].shape[0] >= 16
+    assert np.abs(out["G"] - d["G"]).max() / F_MAX <= TOL and np.abs(out["tau0"] - d["tau0"]).max() / F_MAX <= TOL
+    t = np.load(g / "qp_terminal_set_n20.npz")
+    mt = gpu_mpc_factory(N=int(t["N"]), NT=int(t["NT"]), dtype="f64", max_iters=60, terminal_set=(t["term_A"], t["term_b"]))
+    o2 = mt.solve(t["x0"], t["ub"], t["stuck"], t["xref"].reshape(-1, order="F"), return_U=True)
+    ok = t["status"] == 0
+    assert ((o2["status"] == 0) == ok).all() and ok.sum() >= 6
+    assert np.abs(o2["U"][ok] - t["U"][ok]).max() / F_MAX <= TOL and np.isfinite(o2["U"]).all()

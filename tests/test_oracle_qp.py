@@ -19,14 +19,16 @@ def _load(name):
     return d, ur, W
 
 
-@pytest.mark.parametrize("name", ["cfg2_single_fault", "cfg3_double_fault", "cfg3_warm_uref", "nominal_nt8", "short_horizon"])
+@pytest.mark.parametrize("name", ["cfg2_single_fault", "cfg3_double_fault", "cfg3_warm_uref", "nominal_nt8", "short_horizon",
+                                  "refvehicle_n15", "refvehicle_n20", "cfg5_n40_nt16"])
 def test_c_oracle_reproduces_golden(name):
     d, ur, W = _load(name)
     cfg = qo.QPConfig(N=int(d["N"]), NT=int(d["NT"]))
     assert np.array_equal(cfg.D, d["D"]) and cfg.rho == float(d["rho"])
     out = co.solve_batch(cfg, d["x0"], d["ub"], d["stuck"], d["xref"], uref=ur, warmU=W, nthreads=4)
     assert (out["status"] == 0).all()
-    assert np.abs(out["U"] - d["U"]).max() < 5e-7     # BVLS (1e-15 tol) vs IPM at mu 1e-13
+    # BVLS (1e-15 tol) vs IPM at mu 1e-13; the 16-thruster shapes have weakly determined late-horizon thrusters (n up to 560)
+    assert np.abs(out["U"] - d["U"]).max() < (5e-7 if cfg.NT == 8 else 3e-6)
     assert np.abs(out["u0"] - d["u0"]).max() < 5e-7
     assert (out["U"][d["ub"][:, None, :].repeat(cfg.N, 1) == 0] == 0).all()
 
@@ -92,3 +94,29 @@ def test_plant_step_matches_numpy_restatement():
     u = rng.uniform(0, 3.4, 16)
     ref = rm.rk4(lambda s: rm.plant_dx_dt(s, u, cfg.D, fs.stuck, fs.ub), x)
     assert np.allclose(co.plant_step(cfg, x, u, fs.ub, fs.stuck), ref, atol=1e-13)
+
+
+def test_general_constraint_fixtures_are_reproduced_and_certified():
+    """tests/golden/qp_wrench_hull_n15.npz and qp_terminal_set_n20.npz (oracle/gen_golden.py:general_constraint_fixtures): the
+    NumPy general-constraint IPM reproduces the stored solutions, and each stored solution passes the solver-independent KKT
+    certificate on the QP rebuilt from the stored inputs (a subset here: the whole set runs on the GPU side)."""
+    d = np.load(GOLD / "qp_wrench_hull_n15.npz")
+    cfg = qo.QPConfig(N=int(d["N"]), NT=int(d["NT"]))
+    assert np.array_equal(cfg.D, d["D"]) and (d["status"] == 0).all() and d["x0"].shape[0] >= 16
+    for b in (0, 7, 15):
+        tau0, T, st, _, qp = qo.solve_wrench_instance(cfg, d["x0"][b], d["ub"][b], d["stuck"][b], d["xref"])
+        assert st == 0 and np.abs(T - d["G"][b]).max() < 1e-9 and np.abs(tau0 - d["tau0"][b]).max() < 1e-9
+        dd = (d["G"][b] - qp["Tbar"]).reshape(-1)
+        assert (qp["C"] @ dd <= qp["h"] + 1e-8).all()                          # the stored wrenches respect every hull row
+        assert max(qo.kkt_general(qp["H"], qp["g"], qp["C"], qp["h"], qp["d"], qp["z"])) < 1e-4
+    t = np.load(GOLD / "qp_terminal_set_n20.npz")
+    cfg = qo.QPConfig(N=int(t["N"]), NT=int(t["NT"]))
+    ok = np.flatnonzero(t["status"] == 0)
+    assert ok.size >= 6 and ok.size < t["x0"].shape[0] and t["x0"].shape[0] >= 16
+    with np.errstate(all="ignore"):
+        for b in list(ok[:2]) + [int(np.flatnonzero(t["status"] != 0)[0])]:
+            _, U, st, _, qp = qo.solve_box_terminal_instance(cfg, t["x0"][b], t["ub"][b], t["stuck"][b], t["xref"], (t["term_A"], t["term_b"]), iters=60)
+            assert (st == 0) == (t["status"][b] == 0)
+            if st == 0:
+                assert np.abs(U - t["U"][b]).max() < 1e-9
+                assert (t["term_A"] @ (qp["eN"] + qp["GN"] @ qp["d"]) <= t["term_b"] + 1e-7).all()

@@ -325,6 +325,32 @@ __device__ __forceinline__ void potrf_inv16(float (&c)[4], float (&w)[4], int la
 __device__ __forceinline__ void potrf_inv16(float (&c)[4], float (&w)[4], int lane) {
     potrf_inv16(c, w, lane, NoWork{});
 }
+// The same for a diagonal tile whose rows 8..15 are identity padding (the last block of n = 16 (NB - 1) + 8 .. : the headline
+// shape, n = 120): pivots 8..15 are 1 and their columns zero, so the elimination stops after eight steps and rows 8..15 of W
+// are the untouched rows of E.  A bad pivot among the first eight shows as NaN / inf in W[7][7] (lane 23, register 3).
+__device__ __forceinline__ void potrf_inv16_half(float (&c)[4], float (&w)[4], int lane) {
+    const int q = lane >> 4, col = lane & 15;
+    float e[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        e[rr] = (4 * q + rr == col) ? 1.f : 0.f;
+        w[rr] = 0.f;
+    }
+    const int bb = 4 * col;
+    const NoWork work{};
+#if FTMPC_POTRF_PRIO
+    __builtin_amdgcn_s_setprio(FTMPC_POTRF_PRIO);
+#endif
+    potrf_inv_step<0>(c, e, w, bb, work);   potrf_inv_step<1>(c, e, w, bb, work);
+    potrf_inv_step<2>(c, e, w, bb, work);   potrf_inv_step<3>(c, e, w, bb, work);
+    potrf_inv_step<4>(c, e, w, bb, work);   potrf_inv_step<5>(c, e, w, bb, work);
+    potrf_inv_step<6>(c, e, w, bb, work);   potrf_inv_step<7>(c, e, w, bb, work);
+#if FTMPC_POTRF_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) w[rr] = (q >= 2) ? e[rr] : w[rr];
+}
 
 // =============================================================================================
 // Register-resident factorisation (all instantiations).  The factor never touches LDS: every tile
@@ -437,8 +463,15 @@ __device__ __forceinline__ void chol_reg_col(const TilesT& tiles, const float* s
         f32x4 cd;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) cd[rr] = ((4 * lq + rr == li) ? sg : 0.f) - (a0[rr] + a1[rr]);   // H + Sigma - sum
-        const f32x4 w = potrf_inv16_call(cd, lane, SchurWork<NB, J>{T, bacc});
-        ok = ok && (fabsf(w.w) <= 3.0e38f);   // NaN or inf in W[15][15]: non-positive pivot
+        f32x4 w;
+        if (J == NB - 1 && nb <= 16 * (NB - 1) + 8) {      // (`nb` carries n here) last block half padding: eight pivots
+            float ch[4] = {cd.x, cd.y, cd.z, cd.w}, wh[4];
+            potrf_inv16_half(ch, wh, lane);
+            w = f32x4{wh[0], wh[1], wh[2], wh[3]};
+        } else {
+            w = potrf_inv16_call(cd, lane, SchurWork<NB, J>{T, bacc});
+        }
+        ok = ok && (fabsf(w.w) <= 3.0e38f);   // NaN or inf in W[15][15] (W[7][7] for the half block): non-positive pivot
         if constexpr (WLDS) *reinterpret_cast<f32x4*>(WL + J * 256 + 4 * lane) = w;
         else Wd[J] = w;
         // Wt = W' through a 16x17 LDS scratch
@@ -1425,7 +1458,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 
             }
             wave_lds_fence();
             STAMP(7);
-            const bool ok = chol_reg<NB, TileStore<NLDS>, true, OCC2>(htiles, dvp, recbuf, nbr, lane, Tt, Wd, wlds);
+            const bool ok = chol_reg<NB, TileStore<NLDS>, true, OCC2>(htiles, dvp, recbuf, n, lane, Tt, Wd, wlds);
             STAMP(5);
             if (__builtin_amdgcn_readfirstlane(!ok)) {
                 status = 2;

@@ -59,3 +59,19 @@ def test_gpus_flag_without_a_launcher_fans_out_in_process():
     assert set(j["strong_scaling"]) == {"65536", "262144"}
     for s in j["strong_scaling"].values():
         assert s["value"] > 1e5 and s["parallel_efficiency"] > 0
+
+
+def test_eight_slots_without_a_launcher_print_a_complete_line():
+    """`python bench.py --gpus 8` as the driver runs it on an 8-GPU node, rehearsed with all eight device slots on this
+    box's one GPU (eight host threads, handles and stream sets at once): the complete line, strong-scaling keys included."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["FTMPC_BENCH_SINGLE_DEVICE"] = "1"
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "4096"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _last_json(r.stdout)
+    assert j["n_gpus"] == 8 and j["scaling"] == "weak" and j["config"]["launcher"].startswith("in-process")
+    assert j["value"] > 1e5 and j["config"]["not_converged"] == 0 and 0 < j["roofline"]["frac"] < 1
+    assert set(j["strong_scaling"]) == {"65536", "262144"}
+    for s in j["strong_scaling"].values():
+        assert s["value"] > 1e5 and s["parallel_efficiency"] > 0

@@ -73,3 +73,32 @@ def test_one_call_helper_and_float64_path():
 def test_bad_device_is_refused():
     with pytest.raises(ft_mpc_amd.FtmpcError):
         MultiGPUMPC(ft_mpc_amd.MPCConfig(N=20, NT=8), devices=[0, 99])
+
+
+@pytest.mark.parametrize("N,NT,dtype,B,nfault,seed", [(20, 8, "f32", 262144, 2, 1004), (40, 16, "f64", 16384, 2, 1005)])
+def test_eight_device_slots_at_full_baseline_size_equal_the_serial_run(N, NT, dtype, B, nfault, seed):
+    """BASELINE configs[3] (262 144 instances, 32 768 per GPU) and configs[4] (N = 40, 16 thrusters, fp64, 16 384 instances,
+    2 048 per GPU) through the in-process driver with EIGHT device slots -- all on this box's one GPU: eight worker threads,
+    handles and stream sets at once -- bitwise equal to one handle solving the whole batch; the workers report how many
+    host cores they are bound to (the cores nearest their GPU, or 0 when the container grants none of them)."""
+    x0, ub, stuck, xref = ft_mpc_amd.make_synthetic_batch(B, N, NT, nfault, seed)
+    xr = np.ascontiguousarray(xref.reshape(-1, order="F"))
+    cfg = ft_mpc_amd.MPCConfig(N=N, NT=NT, dtype=dtype)
+    one = ft_mpc_amd.BatchedMPC(cfg)
+    serial = one.solve(x0, ub, stuck, xr)
+    one.close()
+    assert (serial["status"] == 0).all()
+    m = MultiGPUMPC(cfg, devices=[0] * 8)
+    try:
+        assert m.n_devices == 8 and [m.shard_bounds(B, g) for g in range(8)] == [shard_bounds(B, 8, g) for g in range(8)]
+        assert all(m.worker_cpus(g) >= 0 for g in range(8))
+        out = m.solve(x0, ub, stuck, xr)                                   # host buffers in / out
+        for k in ("u0", "status", "iters"):
+            assert np.array_equal(out[k], serial[k]), k
+        m.upload(x0, ub, stuck, xr)                                        # shards resident in HBM (pinned upload staging)
+        m.step(1)
+        res = m.download()
+        for k in ("u0", "status", "iters"):
+            assert np.array_equal(res[k], serial[k]), k
+    finally:
+        m.close()

@@ -492,13 +492,16 @@ __device__ __forceinline__ void chol_reg_col(const TilesT& tiles, const float* s
     }
 }
 
+// the tiles of block column 0 that live in the global slot, requested by the caller ahead of the factorisation
+template <int NB, class TilesT>
+__device__ __forceinline__ void chol_prefetch_col0(const TilesT& tiles, int lane, f32x4 (&pre)[NB]) {
+#pragma unroll
+    for (int I = 0; I < NB; ++I) pre[I] = TilesT::is_global(tidx(I, 0)) ? tiles.ld(tidx(I, 0), lane) : f32x4{0.f, 0.f, 0.f, 0.f};
+}
 template <int NB, class TilesT, bool PREF = true, bool WLDS = false>
 __device__ __forceinline__ bool chol_reg(const TilesT& tiles, const float* sigv, float* S, int nb, int lane,
-                                         f32x4 (&T)[NB * (NB + 1) / 2], f32x4 (&Wd)[NB], float* WL = nullptr) {
+                                         f32x4 (&T)[NB * (NB + 1) / 2], f32x4 (&Wd)[NB], const f32x4 (&pre)[NB], float* WL = nullptr) {
     bool ok = true;
-    f32x4 pre[NB];
-#pragma unroll
-    for (int I = 0; I < NB; ++I) pre[I] = (PREF && TilesT::is_global(tidx(I, 0))) ? tiles.ld(tidx(I, 0), lane) : f32x4{0.f, 0.f, 0.f, 0.f};
     chol_reg_col<NB, 0, TilesT, PREF, WLDS>(tiles, sigv, S, nb, lane, ok, T, Wd, pre, WL);
     return __all(ok);
 }
@@ -1445,6 +1448,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 
             }
             if (it == C.max_iters) break;
             ++nit;
+            // block column 0 of the Hessian from the global slot (NB > 8, and NB = 8 at two waves per SIMD): requested here, the
+            // barrier weights below cover part of the trip
+            f32x4 pre0[NB];
+            chol_prefetch_col0<NB>(htiles, lane, pre0);
             // KKT matrix: H + Sigma on the diagonal
             float Sig[NV], rsl[NV], rsu[NV];   // 1/s_l, 1/s_u by v_rcp_f32 (1 ulp; the IPM tolerates it)
             wave_lds_fence();   // dvp is dead: it becomes the Sigma vector
@@ -1458,7 +1465,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 
             }
             wave_lds_fence();
             STAMP(7);
-            const bool ok = chol_reg<NB, TileStore<NLDS>, true, OCC2>(htiles, dvp, recbuf, n, lane, Tt, Wd, wlds);
+            const bool ok = chol_reg<NB, TileStore<NLDS>, true, OCC2>(htiles, dvp, recbuf, n, lane, Tt, Wd, pre0, wlds);
             STAMP(5);
             if (__builtin_amdgcn_readfirstlane(!ok)) {
                 status = 2;

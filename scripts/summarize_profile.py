@@ -32,7 +32,8 @@ for d in sorted(p for p in src.iterdir() if p.is_dir()):
     except Exception:
         continue
     dom = bench["roofline"]["kernel"]
-    pm = out.get("ftmpc::" + dom.split(" |")[0], {})
+    key = "ftmpc::" + dom.split(" |")[0]
+    pm = out.get(key) or next((v for k, v in out.items() if k.startswith(key) and v.get("FETCH_SIZE", 0) > 1000), {})
     row = {"value": bench["value"], "kernel": dom, "kernel_ms": bench["roofline"]["kernel_ms"], "frac": bench["roofline"]["frac"]}
     if "executed" in bench["roofline"]:
         row["executed_frac"] = bench["roofline"]["executed"]["frac"]

@@ -27,6 +27,7 @@
 #include "ftmpc_solve_wg.hip"
 #include "ftmpc_solve_ws.hip"
 #include "ftmpc_solve_ws64.hip"
+#include "ftmpc_solve_wsw.hip"
 #include "ftmpc_sim.hip"
 #include "ftmpc_alloc.hip"
 
@@ -82,6 +83,11 @@ struct ftmpc_handle {
     int ws_nb = 8, grid_ws = 0;
     float* ws_slot = nullptr;
     int64_t ws_slot_words = 0;
+    // kernel 10: the wrench-space form on ONE wave per instance (takes kernel 8's list when it applies)
+    bool use_wsw = false;
+    int grid_wsw = 0;
+    float* wsw_slot = nullptr;
+    int64_t wsw_slot_words = 0;
     bool use_wg = false;
     float* wg_slot = nullptr;
     int grid_wg = 0;
@@ -385,7 +391,22 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
             h->ev_used[1 + v] = true;
         }
     }
-    if (h->use_wg && h->use_ws) {
+    if (h->use_wg && h->use_wsw) {     // kernel 10 on work list 3
+        sp.hscratch = h->wsw_slot;
+        sp.tile_words = h->wsw_slot_words;
+        sp.qlist = h->d_qlist + (int64_t)3 * B;
+        sp.qcount = h->d_qctl + 3;
+        sp.qhead = h->d_qctl + 7;
+        const int grid = (int)std::min<int64_t>(B, h->grid_wsw);
+        if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[10], s));
+        if (h->ws_nb == 6) hipLaunchKernelGGL(ftmpc::ftmpc_solve_wsw32_kernel<6>, dim3(grid), dim3(64), 0, s, h->dc, sp);
+        else hipLaunchKernelGGL(ftmpc::ftmpc_solve_wsw32_kernel<8>, dim3(grid), dim3(64), 0, s, h->dc, sp);
+        HIP_TRY(h, hipGetLastError());
+        if (h->profiling) {
+            HIP_TRY(h, hipEventRecord(h->ev[11], s));
+            h->ev_used[5] = true;
+        }
+    } else if (h->use_wg && h->use_ws) {
         const int rc = launch_ws(3, 5);
         if (rc != FTMPC_OK) return rc;
     } else if (h->use_wg) {
@@ -494,8 +515,8 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
         return fail(nullptr, FTMPC_ERR_NODEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
     if (cfg->dtype != FTMPC_DTYPE_F32 && cfg->dtype != FTMPC_DTYPE_F64)
         return fail(nullptr, FTMPC_ERR_ARG, "dtype must be FTMPC_DTYPE_F32 or FTMPC_DTYPE_F64");
-    if (cfg->kernel_select != FTMPC_KERNEL_AUTO && cfg->kernel_select != FTMPC_KERNEL_DENSE)
-        return fail(nullptr, FTMPC_ERR_ARG, "kernel_select must be FTMPC_KERNEL_AUTO or FTMPC_KERNEL_DENSE");
+    if (cfg->kernel_select != FTMPC_KERNEL_AUTO && cfg->kernel_select != FTMPC_KERNEL_DENSE && cfg->kernel_select != FTMPC_KERNEL_WORKGROUP)
+        return fail(nullptr, FTMPC_ERR_ARG, "kernel_select must be FTMPC_KERNEL_AUTO, FTMPC_KERNEL_DENSE or FTMPC_KERNEL_WORKGROUP");
     if (cfg->stage_chunks < 0 || cfg->stage_chunks > ftmpc_handle::MAX_CHUNKS)
         return fail(nullptr, FTMPC_ERR_ARG, "stage_chunks out of range 0..8");
     ftmpc_handle* h = new (std::nothrow) ftmpc_handle();
@@ -523,6 +544,9 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
     h->ws_nb = (6 * cfg->N <= 96) ? 6 : 8;
     h->use_ws = cfg->dtype != FTMPC_DTYPE_F64 && cfg->kernel_select != FTMPC_KERNEL_DENSE && h->nb_max > 10 && 6 * cfg->N <= 128 &&
                 cfg->N * cfg->NT <= ftmpc::wsk::WG * ftmpc::wsk::nvt_of(h->ws_nb);
+    // ... on one wave per instance (kernel 10) when the thruster variables fit four (N <= 16) / six (N <= 21) per lane;
+    // kernel_select = FTMPC_KERNEL_WORKGROUP keeps the workgroup-per-instance kernel 8
+    h->use_wsw = h->use_ws && cfg->kernel_select != FTMPC_KERNEL_WORKGROUP && cfg->N * cfg->NT <= 64 * ftmpc::wswk::nvt_of(h->ws_nb);
     h->use_f64 = (cfg->dtype == FTMPC_DTYPE_F64) || (h->nb_max > 15 && !h->use_ws);
     h->use_wg = !h->use_f64 && h->nb_max > 10;
     // float64: through the wrench-space form where the thrusters outnumber the wrench components by enough to pay for the
@@ -623,6 +647,14 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
             h->ws_slot_words = ftmpc::wsk::slot_words(h->ws_nb, cfg->N);
             bad = grow(h, &h->ws_slot, (int64_t)h->grid_ws * h->ws_slot_words) != FTMPC_OK;
         }
+        if (!bad && h->use_wsw) {
+            int per = 0;
+            if (h->ws_nb == 6) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_wsw32_kernel<6>, 64, 0);
+            else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_wsw32_kernel<8>, 64, 0);
+            h->grid_wsw = h->num_cu * (per > 0 ? per : 1);
+            h->wsw_slot_words = ftmpc::wswk::slot_words(h->ws_nb, cfg->N);
+            bad = grow(h, &h->wsw_slot, (int64_t)h->grid_wsw * h->wsw_slot_words) != FTMPC_OK;
+        }
         if (!bad && h->use_wg) {
             h->grid_wg = h->num_cu;      // ~150 KiB of LDS: one workgroup per CU
             h->wg_slot_words = ftmpc::wgk::slot_words(15, cfg->N);
@@ -669,7 +701,7 @@ int ftmpc_destroy(ftmpc_handle* h) {
     void* ptrs[] = {h->rec, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, h->d_uref, h->d_warm, h->d_u0, h->d_U,
                     h->d_status, h->d_iters, h->hs[0], h->hs[1], h->hs[2], h->d_dbgH, h->d_dbgv, h->Hs, h->Ls, h->Eall, h->d_dbgH64, h->d_dbgv64,
                     h->d_atau, h->d_aub, h->d_au, h->d_ast, h->d_ait, h->d_qlist, h->d_qctl, h->d_term, h->d_eN, h->gHs, h->gLs,
-                    h->gEall, h->wg_slot, h->ws_slot, h->ws64_slot, h->d_tcost, h->d_cost, h->d_hullA, h->d_hullb, h->d_warmG, h->d_tau0, h->d_G, h->d_taud, h->d_hullset, h->d_ast2};
+                    h->gEall, h->wg_slot, h->ws_slot, h->ws64_slot, h->wsw_slot, h->d_tcost, h->d_cost, h->d_hullA, h->d_hullb, h->d_warmG, h->d_tau0, h->d_G, h->d_taud, h->d_hullset, h->d_ast2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->pin_in.p) (void)hipHostFree(h->pin_in.p);
@@ -1114,7 +1146,7 @@ int ftmpc_last_kernel_ms(ftmpc_handle* h, float* ms, int32_t n_slots) {
 }
 
 static const char* const k_kernel_names[FTMPC_KERNEL_SLOTS] = {"ftmpc_linearize_kernel", "ftmpc_solve_f32_kernel<8>", "ftmpc_solve_f32_kernel<9>",
-                                                                "ftmpc_solve_f32_kernel<10>", "ftmpc_solve_f64_kernel", "ftmpc_solve_ws32_kernel | ftmpc_solve_wg32_kernel<15>",
+                                                                "ftmpc_solve_f32_kernel<10>", "ftmpc_solve_f64_kernel", "ftmpc_solve_wsw32_kernel | ftmpc_solve_ws32_kernel | ftmpc_solve_wg32_kernel<15>",
                                                                 "ftmpc_solve_ws64_kernel"};
 
 const char* ftmpc_kernel_name(int32_t slot) { return (slot >= 0 && slot < FTMPC_KERNEL_SLOTS) ? k_kernel_names[slot] : ""; }
@@ -1140,11 +1172,14 @@ int ftmpc_debug_build_qp(ftmpc_handle* h, int64_t B, const double* x0, const dou
         return fail(h, FTMPC_ERR_ARG, "the QP dump needs N * NT <= 240 on the fp32 path (create the handle with dtype FTMPC_DTYPE_F64 for larger shapes)");
     const bool ws64_was = h->use_ws64;
     h->use_ws64 = false;
+    const bool wsw_was = h->use_wsw;
+    h->use_wsw = false;
     const bool ws_was = h->use_ws;
     h->use_ws = false;     // the dump hook (the condensed thruster-space QP) lives in kernel 7; kernel 8 never forms that matrix
     rc = enqueue(h, B, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, xref_stride, uref ? h->d_uref : nullptr, uref_stride,
                  warmU ? h->d_warm : nullptr, h->d_u0, nullptr, h->d_status, h->d_iters, s, inst);
     h->use_ws = ws_was;
+    h->use_wsw = wsw_was;
     h->use_ws64 = ws64_was;
     if (rc != FTMPC_OK) return rc;
     if (h->use_f64) {

@@ -92,6 +92,9 @@ __device__ __forceinline__ int lane_now() {
 // larger instantiations they would cut the residency to 3 or 2 waves per CU, so there they sit in the
 // per-workgroup global slot (L2 / Infinity-Cache resident; every lane re-reads only what it wrote itself).
 typedef __attribute__((address_space(1))) float glb_f32;
+// volatile read of an LDS byte table, typed with its address space (through a generic pointer the backend trips over the
+// aperture test of the cast: "Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base")
+typedef __attribute__((address_space(3))) volatile unsigned char lds_vu8;
 // NLDS = number of leading tiles (tile number I(I+1)/2 + J, i.e. whole block rows) kept in LDS; the
 // rest sits in the global slot.  Tile numbers are compile-time constants at every call site.
 // The global tiles are addressed through a BUFFER resource: the slot base sits in four SGPRs, the tile number is a scalar
@@ -437,7 +440,9 @@ __device__ __forceinline__ float row_sum16(float x) {
 // build of the NB = 8 instantiation keeps 28 tiles of the factor in registers and nothing else of it.
 // PREF: tiles of the global slot are requested a block column ahead (registers for a whole column) or where they are used
 // (a second resident wave covers the latency instead).
-template <int NB, int J, class TilesT, bool PREF = true, bool WLDS = false>
+// LOUT: the tiles of the factor itself, L_JJ = C_JJ W_J' and L_IJ = C_IJ W_J', are written over the matrix tiles of the column
+// just consumed (kernel 10 keeps L of the wrench-space Hessian in LDS this way).
+template <int NB, int J, class TilesT, bool PREF = true, bool WLDS = false, bool LOUT = false>
 __device__ __forceinline__ void chol_reg_col(const TilesT& tiles, const float* sigv, float* S, int nb, int lane, bool& ok,
                                              f32x4 (&T)[NB * (NB + 1) / 2], f32x4 (&Wd)[NB], const f32x4 (&pre)[NB], float* WL = nullptr) {
     lane = lane_now();
@@ -488,7 +493,12 @@ __device__ __forceinline__ void chol_reg_col(const TilesT& tiles, const float* s
         T[tidx(J, J)] = wt;
 #pragma unroll
         for (int I = J + 1; I < NB; ++I) T[tidx(I, J)] = mm_tn(wtn, bacc[I], zero);    // L_IJ' = W_J (H_IJ' - sum) = -W_J bacc
-        if constexpr (J + 1 < NB) chol_reg_col<NB, J + 1, TilesT, PREF, WLDS>(tiles, sigv, S, nb, lane, ok, T, Wd, nxt, WL);
+        if constexpr (LOUT) {
+            tiles.st(tidx(J, J), lane, mm_tn(cd, wt, zero));                             // C W' = L L' L^-T = L_JJ  (C symmetric)
+#pragma unroll
+            for (int I = J + 1; I < NB; ++I) tiles.st(tidx(I, J), lane, mm_tn(bacc[I], wtn, zero));   // (-C_IJ')' (-W_J') = C_IJ W_J' = L_IJ
+        }
+        if constexpr (J + 1 < NB) chol_reg_col<NB, J + 1, TilesT, PREF, WLDS, LOUT>(tiles, sigv, S, nb, lane, ok, T, Wd, nxt, WL);
     }
 }
 
@@ -498,11 +508,11 @@ __device__ __forceinline__ void chol_prefetch_col0(const TilesT& tiles, int lane
 #pragma unroll
     for (int I = 0; I < NB; ++I) pre[I] = TilesT::is_global(tidx(I, 0)) ? tiles.ld(tidx(I, 0), lane) : f32x4{0.f, 0.f, 0.f, 0.f};
 }
-template <int NB, class TilesT, bool PREF = true, bool WLDS = false>
+template <int NB, class TilesT, bool PREF = true, bool WLDS = false, bool LOUT = false>
 __device__ __forceinline__ bool chol_reg(const TilesT& tiles, const float* sigv, float* S, int nb, int lane,
                                          f32x4 (&T)[NB * (NB + 1) / 2], f32x4 (&Wd)[NB], const f32x4 (&pre)[NB], float* WL = nullptr) {
     bool ok = true;
-    chol_reg_col<NB, 0, TilesT, PREF, WLDS>(tiles, sigv, S, nb, lane, ok, T, Wd, pre, WL);
+    chol_reg_col<NB, 0, TilesT, PREF, WLDS, LOUT>(tiles, sigv, S, nb, lane, ok, T, Wd, pre, WL);
     return __all(ok);
 }
 
@@ -1149,8 +1159,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 
                     if (X >= Xnew) {
                         float d0, d1;
                         if constexpr (OCC2) {     // the one or two tiles that hold the columns of stage k: read off the tables
-                            const int ax = *(volatile unsigned char*)&s_thr[16 * X + li];
-                            const bool mine = (*(volatile unsigned char*)&s_stg[16 * X + li] == k);
+                            const int ax = *(lds_vu8*)&s_thr[16 * X + li];
+                            const bool mine = (*(lds_vu8*)&s_stg[16 * X + li] == k);
                             d0 = mine ? s_Da[lq * MAX_NT + (ax & (MAX_NT - 1))] : 0.f;
                             d1 = (mine && lq < 2) ? s_Da[(4 + lq) * MAX_NT + (ax & (MAX_NT - 1))] : 0.f;
                         } else {

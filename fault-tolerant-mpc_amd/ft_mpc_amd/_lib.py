@@ -20,7 +20,7 @@ MAX_TERM_ROWS = 80
 MAX_HULL_ROWS = 32
 MAX_TCOST = 24
 KERNEL_SLOTS = 7
-KERNEL_AUTO, KERNEL_DENSE = 0, 1
+KERNEL_AUTO, KERNEL_DENSE, KERNEL_WORKGROUP = 0, 1, 2
 
 # every symbol include/ftmpc.h declares (tests check the list against the header)
 SYMBOLS = (

@@ -44,7 +44,8 @@ class MPCConfig:
     # gradient at the linearisation point and eval_cost includes it (see BatchedMPC.solve_sqp).
     terminal_cost: object = None
     # implementation switches (include/ftmpc.h ftmpc_config; diagnostics and A/B runs): "auto" | "dense" (Newton systems
-    # always in the thruster variables, never through the wrench-space form), the batch size up to which the linearisation
+    # always in the thruster variables, never through the wrench-space form) | "workgroup" (the wrench-space form on a
+    # workgroup per instance, kernel 8, where "auto" gives the instance one wave, kernel 10), the batch size up to which the linearisation
     # is split by tangent direction (0: library default, < 0: never) and the staging ranges of the host-buffer entry
     kernel_select: str = "auto"
     lin_split_max: int = 0
@@ -78,9 +79,9 @@ class BatchedMPC:
         if cfg.dtype not in ("f32", "f64"):
             raise ValueError("dtype must be 'f32' or 'f64'")
         c.dtype = 1 if cfg.dtype == "f64" else 0
-        if cfg.kernel_select not in ("auto", "dense"):
-            raise ValueError("kernel_select must be 'auto' or 'dense'")
-        c.kernel_select = _lib.KERNEL_DENSE if cfg.kernel_select == "dense" else _lib.KERNEL_AUTO
+        if cfg.kernel_select not in ("auto", "dense", "workgroup"):
+            raise ValueError("kernel_select must be 'auto', 'dense' or 'workgroup'")
+        c.kernel_select = {"auto": _lib.KERNEL_AUTO, "dense": _lib.KERNEL_DENSE, "workgroup": _lib.KERNEL_WORKGROUP}[cfg.kernel_select]
         c.lin_split_max, c.stage_chunks = int(cfg.lin_split_max), int(cfg.stage_chunks)
         c.J[:] = list(_f64(cfg.J, 9))
         D = cfg.D

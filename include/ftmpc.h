@@ -116,7 +116,7 @@ typedef struct ftmpc_config {
     /*
      * Implementation switches (diagnostics and A/B runs; 0 = the library's choice everywhere).  They live here, per handle:
      * the library reads no environment variable and keeps no process-global state.
-     *   kernel_select   FTMPC_KERNEL_AUTO | FTMPC_KERNEL_DENSE: with DENSE the Newton systems are always factorised in the
+     *   kernel_select   FTMPC_KERNEL_AUTO | FTMPC_KERNEL_DENSE | FTMPC_KERNEL_WORKGROUP: with DENSE the Newton systems are always factorised in the
      *                   thruster variables (kernel 7 / the dense float64 kernel) even where the library would go through
      *                   the 6N-variable wrench-space form (kernel 8 / its float64 sibling)
      *   lin_split_max   batch size up to which the linearisation is split by tangent direction (0: library default 8192;
@@ -130,6 +130,8 @@ typedef struct ftmpc_config {
 
 #define FTMPC_KERNEL_AUTO 0
 #define FTMPC_KERNEL_DENSE 1
+#define FTMPC_KERNEL_WORKGROUP 2   /* the wrench-space form on a 4-wave workgroup per instance (kernel 8) where the library would
+                                      give the instance one wave (kernel 10) */
 
 typedef struct ftmpc_handle ftmpc_handle;
 
@@ -275,9 +277,10 @@ int ftmpc_simulate_batch(ftmpc_handle* h, int64_t B, int32_t T, double* x, const
  * not launched), for slot < min(n_slots, FTMPC_KERNEL_SLOTS); ftmpc_kernel_name(slot) is the kernel's name as it appears
  * in rocprofv3 traces:  0 linearise, 1..3 condense+IPM fp32 (one wave per instance) for n <= 128 / 144 / 160,
  * 4 condense+IPM fp64, dense (workgroup per instance, general n), 5 condense+IPM fp32, workgroup per instance, for
- * 160 < N*NT: ftmpc_solve_ws32_kernel (Newton systems through the 6N-variable wrench-space form, N <= 21 and N*NT <= 512)
- * or, with kernel_select = FTMPC_KERNEL_DENSE and N*NT <= 240, the dense ftmpc_solve_wg32_kernel<15> (the slot reports
- * both names), 6 condense+IPM fp64 through the wrench-space form (ftmpc_solve_ws64_kernel, 6 N <= 256). */
+ * 160 < N*NT: ftmpc_solve_wsw32_kernel (Newton systems through the 6N-variable wrench-space form, one wave per instance:
+ * N <= 16 with N*NT <= 256, N <= 21 with N*NT <= 384), ftmpc_solve_ws32_kernel (the same form on a workgroup per instance:
+ * kernel_select = FTMPC_KERNEL_WORKGROUP) or, with kernel_select = FTMPC_KERNEL_DENSE and N*NT <= 240, the dense
+ * ftmpc_solve_wg32_kernel<15> (the slot reports all three names), 6 condense+IPM fp64 through the wrench-space form (ftmpc_solve_ws64_kernel, 6 N <= 256). */
 #define FTMPC_KERNEL_SLOTS 7
 int ftmpc_set_profiling(ftmpc_handle* h, int32_t enabled);
 int ftmpc_last_kernel_ms(ftmpc_handle* h, float* ms, int32_t n_slots);

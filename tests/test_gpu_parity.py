@@ -120,11 +120,12 @@ def test_wg_kernel_build_matches_oracle(gpu_mpc_factory, nfault):
         assert np.allclose(lo, -qp["Ubar"], atol=1e-6) and np.allclose(hi, qp["ub"] - qp["Ubar"], atol=1e-6)
 
 
-@pytest.mark.parametrize("sel", ["auto", "dense"])
+@pytest.mark.parametrize("sel", ["auto", "workgroup", "dense"])
 @pytest.mark.parametrize("N,nfault,B", [(15, 2, 64), (15, 0, 32), (15, 1, 32), (12, 0, 32), (13, 2, 32)])
 def test_wg_kernel_u0_against_the_c_oracle(gpu_mpc_factory, N, nfault, B, sel):
     """n = 210 (reactive.yaml's horizon, two faults), 240 (nominal), 225, 192 and 182: block counts 12..15.
-    auto: kernel 8 (the same QP through wrench space, the default for these shapes); dense: kernel 7."""
+    auto: kernel 10 (the QP through wrench space on one wave per instance, the default for these shapes); workgroup: kernel 8
+    (the same form on a 4-wave workgroup); dense: kernel 7."""
     NT = 16
     mpc = gpu_mpc_factory(N=N, NT=NT, kernel_select=sel)
     x0, ub, stuck, xref = qo.make_batch(B, N, NT, nfault, 3400 + N + nfault)
@@ -137,10 +138,11 @@ def test_wg_kernel_u0_against_the_c_oracle(gpu_mpc_factory, N, nfault, B, sel):
     assert (out["u0"][ub == 0] == 0).all() and out["iters"].max() <= 30
 
 
+@pytest.mark.parametrize("sel", ["auto", "workgroup"])
 @pytest.mark.parametrize("N,NT,seed", [(11, 16, 1), (16, 16, 2), (14, 13, 3), (16, 12, 4), (21, 11, 5), (20, 11, 6), (13, 15, 7),
                                        (20, 16, 8), (21, 16, 9), (18, 14, 10)])
-def test_wrench_space_kernel_other_vehicles_and_horizons(gpu_mpc_factory, N, NT, seed):
-    """Kernel 8 away from the reference shape: 11..16 thrusters (a random allocation matrix of full row rank), horizons
+def test_wrench_space_kernel_other_vehicles_and_horizons(gpu_mpc_factory, N, NT, seed, sel):
+    """Kernels 10 (auto: one wave per instance) and 8 (workgroup per instance) away from the reference shape: 11..16 thrusters (a random allocation matrix of full row rank), horizons
     11..21 (both instantiations: six and eight tiles a side; N * NT up to 336: two thruster variables per thread), mixed
     fault counts, warm start; against a reference for EVERY instance (C oracle, BVLS for what it does not finish).
     All of them within the 1e-4 f_max of the specification: the eight-tile instantiation takes the float64 reference
@@ -151,7 +153,7 @@ def test_wrench_space_kernel_other_vehicles_and_horizons(gpu_mpc_factory, N, NT,
     if NT != 16:
         D = rng.standard_normal((6, NT)) * np.array([1, 1, 1, 0.3, 0.3, 0.3])[:, None]
     cfg = _cfg(N, NT) if D is None else qo.QPConfig(N=N, NT=NT, D=D)
-    mpc = gpu_mpc_factory(N=N, NT=NT) if D is None else gpu_mpc_factory(N=N, NT=NT, D=D)
+    mpc = gpu_mpc_factory(N=N, NT=NT, kernel_select=sel) if D is None else gpu_mpc_factory(N=N, NT=NT, D=D, kernel_select=sel)
     x0, ub, stuck, xref = qo.make_batch(B, N, NT, 1, 4100 + seed)
     for b in range(B):
         k = int(rng.integers(0, 3))
@@ -182,12 +184,13 @@ def test_wrench_space_kernel_agrees_with_the_dense_workgroup_kernel(gpu_mpc_fact
         idx = np.random.default_rng(b).choice(NT, 8, replace=False)
         ub[b, idx] = 0.0
     xr = xref.reshape(-1, order="F")
-    a = gpu_mpc_factory(N=N, NT=NT).solve(x0, ub, stuck, xr, return_U=True)
     b = gpu_mpc_factory(N=N, NT=NT, kernel_select="dense").solve(x0, ub, stuck, xr, return_U=True)
-    assert (a["status"] == 0).all() and (b["status"] == 0).all()
-    assert np.abs(a["U"] - b["U"]).max() / F_MAX <= 2e-5
-    assert np.abs(a["u0"] - b["u0"]).max() / F_MAX <= 5e-6
-    assert (np.abs(a["iters"].astype(int) - b["iters"]) <= 1).all() and (a["iters"] == b["iters"]).mean() > 0.97
+    for sel in ("auto", "workgroup"):      # kernel 10 (one wave per instance) and kernel 8 (workgroup per instance)
+        a = gpu_mpc_factory(N=N, NT=NT, kernel_select=sel).solve(x0, ub, stuck, xr, return_U=True)
+        assert (a["status"] == 0).all() and (b["status"] == 0).all()
+        assert np.abs(a["U"] - b["U"]).max() / F_MAX <= 2e-5, sel
+        assert np.abs(a["u0"] - b["u0"]).max() / F_MAX <= 5e-6, sel
+        assert (np.abs(a["iters"].astype(int) - b["iters"]) <= 1).all() and (a["iters"] == b["iters"]).mean() > 0.97, sel
 
 
 @pytest.mark.parametrize("N,NT,dtype", [(15, 16, "f32"), (15, 16, "f64"), (20, 8, "f32")])
@@ -230,7 +233,7 @@ def test_direction_split_linearisation_gives_the_same_bits(gpu_mpc_factory, N, N
             assert np.array_equal(a[k], b[k]), k
 
 
-@pytest.mark.parametrize("sel", ["auto", "dense"])
+@pytest.mark.parametrize("sel", ["auto", "workgroup", "dense"])
 def test_wg_kernel_whole_batch_mixed_fault_counts_warm_start_and_uref(gpu_mpc_factory, sel):
     """4096 instances (16 per workgroup), fault counts 0..10 mixed in one batch (routed between the one-wave kernels
     NB = 8 / 9 / 10 and the workgroup kernel 8 or 7), then a warm-started step with a circle reference window."""
@@ -437,6 +440,7 @@ def test_device_pointer_entry_matches_host_entry(gpu_mpc_factory):
 
 
 @pytest.mark.parametrize("name,dtype,sel,tol", [("refvehicle_n15", "f32", "auto", 1e-4), ("refvehicle_n15", "f32", "dense", 1e-4),
+                                                ("refvehicle_n15", "f32", "workgroup", 1e-4), ("refvehicle_n20", "f32", "workgroup", 1e-4),
                                                 ("refvehicle_n20", "f32", "auto", 1e-4), ("refvehicle_n15", "f64", "auto", 1e-7),
                                                 ("refvehicle_n20", "f64", "auto", 1e-7), ("refvehicle_n20", "f64", "dense", 1e-7),
                                                 ("cfg5_n40_nt16", "f64", "auto", 1e-7), ("cfg5_n40_nt16", "f64", "dense", 1e-7)])

@@ -61,9 +61,11 @@ def test_wrench_entry_refuses_a_hull_table_number_out_of_range(gpu_mpc_factory):
 _AB_CASES = [  # (name, N, NT, faults, B, dtype, kernel_select): one batch per kernel family of the library
     ("headline_f32_nb8", 20, 8, 2, 2048, "f32", "auto"),
     ("f32_nb9_nb10", 20, 8, 0, 1024, "f32", "auto"),
-    ("refvehicle_ws32_6", 15, 16, 2, 1024, "f32", "auto"),
+    ("refvehicle_wsw32_6", 15, 16, 2, 1024, "f32", "auto"),
+    ("refvehicle_ws32_6", 15, 16, 2, 1024, "f32", "workgroup"),
+    ("ws32_8_two_per_thread", 20, 16, 2, 256, "f32", "workgroup"),
     ("refvehicle_wg32", 15, 16, 2, 512, "f32", "dense"),
-    ("ws32_8_two_per_thread", 20, 16, 2, 256, "f32", "auto"),
+    ("wsw32_8", 20, 16, 2, 512, "f32", "auto"),
     ("config5_ws64", 40, 16, 2, 128, "f64", "auto"),
     ("config5_f64_dense", 40, 16, 2, 64, "f64", "dense"),
     ("refvehicle_f64", 15, 16, 2, 256, "f64", "dense"),

@@ -51,13 +51,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     __shared__ __attribute__((aligned(16))) float Ltl[NTW * 256];       // -H_w' tiles (build) -> tiles of L (H_w = L L')
     __shared__ __attribute__((aligned(16))) float recbuf[2 * REC_STRIDE + 8];
     __shared__ __attribute__((aligned(16))) float xvp[NPADW], dvp[NPADW], twv[NPADW], yvv[NPADW];
-    __shared__ __attribute__((aligned(16))) float rv[NTP], rdg[NTP];
+    __shared__ __attribute__((aligned(16))) float rv[NTP];
+    __shared__ __attribute__((aligned(16))) float rdg[NSTG * MAX_NT];   // 1 / Dg of thruster a of stage k at k * 16 + a, zero beyond the healthy ones
+    __shared__ __attribute__((aligned(16))) float rv16[NSTG * MAX_NT];  // operand of the wrench images, same layout
     __shared__ __attribute__((aligned(16))) double sSl[9 * (NSTG + 2)];
     __shared__ __attribute__((aligned(16))) float Sblk[NSTG * 36];
     __shared__ __attribute__((aligned(16))) float s_DD[21 * MAX_NT];
     __shared__ __attribute__((aligned(16))) float s_DaT[6 * MAX_NT];
     __shared__ __attribute__((aligned(16))) float mtab[MAX_NT * MAX_NT];
     __shared__ unsigned char s_stg[NPADW], s_thr[NPADW];
+    __shared__ unsigned char s_pg[24], s_ph[24];     // pair p = g (g + 1) / 2 + h of the symmetric 6 x 6 stage blocks -> (g, h)
     __shared__ int s_act[MAX_NT];
     float* const dense = Ltl;
 
@@ -76,6 +79,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         if (lane0 == 0) i = atomicAdd(P.qhead, 1);
         return i;
     };
+    if (lane0 < 21) {
+        int g = 0;
+        while ((g + 1) * (g + 2) / 2 <= lane0) ++g;
+        s_pg[lane0] = (unsigned char)g;
+        s_ph[lane0] = (unsigned char)(lane0 - g * (g + 1) / 2);
+    }
     const int qn = *P.qcount;
     int qnext = pull();
     for (;;) {
@@ -172,6 +181,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         bool tvalid[NVT];
         int tk[NVT], ta[NVT];
         float ubar[NVT], ubv[NVT];
+        for (int i = lane; i < NSTG * MAX_NT; i += 64) {
+            rdg[i] = 0.f;
+            rv16[i] = 0.f;
+        }
 #pragma unroll
         for (int v = 0; v < NVT; ++v) {
             const int e = v * 64 + lane;
@@ -331,7 +344,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         auto to_wrench = [&](const float (&x)[NVT], float* out) {
             const int lane = lane_now();
 #pragma unroll
-            for (int v = 0; v < NVT; ++v) rv[v * 64 + lane] = tvalid[v] ? x[v] : 0.f;
+            for (int v = 0; v < NVT; ++v)
+                if (tvalid[v]) rv16[tk[v] * MAX_NT + ta[v]] = x[v];
             wave_lds_fence();
 #pragma unroll
             for (int v = 0; v < NVW; ++v) {
@@ -339,8 +353,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 if (e < NPADW) {
                     float s = 0.f;
                     if (e < n) {
-                        const int k = e / 6, g = e - 6 * k;
-                        for (int a = 0; a < nat; ++a) s += s_DaT[g * MAX_NT + a] * rv[k * nat + a];
+                        const int k = (e * 10923) >> 16, g = e - 6 * k;      // e / 6 for e < 4096
+                        const f32x4* d4 = reinterpret_cast<const f32x4*>(s_DaT + g * MAX_NT);     // zero beyond the healthy thrusters
+                        const f32x4* r4 = reinterpret_cast<const f32x4*>(rv16 + k * MAX_NT);
+#pragma unroll
+                        for (int a4 = 0; a4 < MAX_NT / 4; ++a4) {
+                            const f32x4 d = d4[a4], r = r4[a4];
+                            s += (d.x * r.x + d.y * r.y) + (d.z * r.z + d.w * r.w);
+                        }
                     }
                     out[e] = s;
                 }
@@ -491,7 +511,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             const int lane = lane_now();
             float t[NVT];
 #pragma unroll
-            for (int v = 0; v < NVT; ++v) t[v] = r[v] * rdg[v * 64 + lane];
+            for (int v = 0; v < NVT; ++v) t[v] = r[v] * rdg[tk[v] * MAX_NT + ta[v]];
             to_wrench(t, twv);
             tri_mv(std::true_type{}, twv, xvp);
             solve_reg<NBW>(Tt, Wd, xvp, NBW, lane);
@@ -501,7 +521,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 float s = 0.f;
 #pragma unroll
                 for (int g = 0; g < 6; ++g) s += s_DaT[g * MAX_NT + ta[v]] * yvv[tk[v] * 6 + g];
-                x[v] = tvalid[v] ? (r[v] - s) * rdg[v * 64 + lane] : 0.f;
+                x[v] = tvalid[v] ? (r[v] - s) * rdg[tk[v] * MAX_NT + ta[v]] : 0.f;
             }
         };
 
@@ -568,16 +588,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 rsl[v] = __builtin_amdgcn_rcpf(sl[v]);
                 rsu[v] = __builtin_amdgcn_rcpf(su[v]);
                 Sig[v] = tvalid[v] ? zl[v] * rsl[v] + zu[v] * rsu[v] : 0.f;
-                rdg[v * 64 + lane] = tvalid[v] ? 1.0f / (2.f * rho + Sig[v]) : 0.f;
+                if (tvalid[v]) rdg[tk[v] * MAX_NT + ta[v]] = 1.0f / (2.f * rho + Sig[v]);
             }
             wave_lds_fence();
             for (int idx = lane; idx < N * 21; idx += 64) {          // stage blocks S_k = D_a diag(1 / Dg) D_a'
-                const int k = idx / 21, p = idx - 21 * k;
-                int g = 0;
-                while ((g + 1) * (g + 2) / 2 <= p) ++g;
-                const int hh = p - g * (g + 1) / 2;
+                const int k = (idx * 3121) >> 16, p = idx - 21 * k;      // idx / 21 for idx < 5000
+                const int g = s_pg[p], hh = s_ph[p];
+                // all sixteen products at once (s_DD is zero beyond the healthy thrusters, the index stays inside rdg): a loop
+                // over the healthy ones alone is a chain of dependent LDS round trips
+                const f32x4* dd4 = reinterpret_cast<const f32x4*>(s_DD + p * MAX_NT);
+                const f32x4* r4 = reinterpret_cast<const f32x4*>(rdg + k * MAX_NT);
                 float sacc = 0.f;
-                for (int a = 0; a < nat; ++a) sacc += s_DD[p * MAX_NT + a] * rdg[k * nat + a];
+#pragma unroll
+                for (int a4 = 0; a4 < MAX_NT / 4; ++a4) {
+                    const f32x4 d = dd4[a4], r = r4[a4];
+                    sacc += (d.x * r.x + d.y * r.y) + (d.z * r.z + d.w * r.w);
+                }
                 Sblk[k * 36 + g * 6 + hh] = sacc;
                 Sblk[k * 36 + hh * 6 + g] = sacc;
             }

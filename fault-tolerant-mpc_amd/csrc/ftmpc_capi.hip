@@ -117,6 +117,10 @@ struct ftmpc_handle {
     TermCost* d_tcost = nullptr;       // non-quadratic terminal-cost terms (terminal_cost_terms != 0)
     double* d_cost = nullptr;
     int64_t cap_cost = 0;
+    // on-device SQP (ftmpc_solve_sqp_batch): iterate, QP solution, trial point | J, Jt, J0, alpha | flags and counters
+    double *d_sqU = nullptr, *d_sqQ = nullptr, *d_sqT = nullptr, *d_sqJ = nullptr;
+    int32_t* d_sqF = nullptr;
+    int64_t cap_sqp = 0;
     int64_t cap_hullA = 0, cap_wrench = 0;
     // debug
     float *d_dbgH = nullptr, *d_dbgv = nullptr;
@@ -701,7 +705,7 @@ int ftmpc_destroy(ftmpc_handle* h) {
     void* ptrs[] = {h->rec, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, h->d_uref, h->d_warm, h->d_u0, h->d_U,
                     h->d_status, h->d_iters, h->hs[0], h->hs[1], h->hs[2], h->d_dbgH, h->d_dbgv, h->Hs, h->Ls, h->Eall, h->d_dbgH64, h->d_dbgv64,
                     h->d_atau, h->d_aub, h->d_au, h->d_ast, h->d_ait, h->d_qlist, h->d_qctl, h->d_term, h->d_eN, h->gHs, h->gLs,
-                    h->gEall, h->wg_slot, h->ws_slot, h->ws64_slot, h->wsw_slot, h->d_tcost, h->d_cost, h->d_hullA, h->d_hullb, h->d_warmG, h->d_tau0, h->d_G, h->d_taud, h->d_hullset, h->d_ast2};
+                    h->gEall, h->wg_slot, h->ws_slot, h->ws64_slot, h->wsw_slot, h->d_tcost, h->d_cost, h->d_sqU, h->d_sqQ, h->d_sqT, h->d_sqJ, h->d_sqF, h->d_hullA, h->d_hullb, h->d_warmG, h->d_tau0, h->d_G, h->d_taud, h->d_hullset, h->d_ast2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->pin_in.p) (void)hipHostFree(h->pin_in.p);
@@ -924,6 +928,87 @@ int ftmpc_eval_cost_batch(ftmpc_handle* h, int64_t B, const double* x0, const do
     hipLaunchKernelGGL(ftmpc::ftmpc_cost_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, h->dc, cp);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(out_cost, h->d_cost, B * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return FTMPC_OK;
+}
+
+int ftmpc_solve_sqp_batch(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, const double* stuck, const double* xref,
+                          int64_t xref_stride, const double* uref, int64_t uref_stride, const double* warmU, int32_t sqp_iters,
+                          int32_t backtracks, double tol, double* out_u0, double* out_U, double* out_cost, double* out_cost0,
+                          int32_t* out_sqp_iters, int32_t* out_iters, int32_t* status) {
+    if (!h) return FTMPC_ERR_ARG;
+    if (B < 0 || !x0 || !ub || !stuck || !xref || !out_u0 || sqp_iters < 0 || backtracks < 1 || !(tol >= 0))
+        return fail(h, FTMPC_ERR_ARG, "null buffer, negative batch or bad iteration counts");
+    if (B == 0) return FTMPC_OK;
+    int rc = check_strides(h, xref_stride, uref_stride, uref);
+    if (rc != FTMPC_OK) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if ((rc = ftmpc_reserve(h, B)) != FTMPC_OK) return rc;
+    const int N = h->cfg.N, NT = h->cfg.NT;
+    const int64_t nw = (int64_t)N * NT;
+    if (B > h->cap_sqp) {
+        h->cap_sqp = 0;
+        if ((rc = grow(h, &h->d_sqU, B * nw)) != FTMPC_OK || (rc = grow(h, &h->d_sqQ, B * nw)) != FTMPC_OK ||
+            (rc = grow(h, &h->d_sqT, B * nw)) != FTMPC_OK || (rc = grow(h, &h->d_sqJ, 4 * B)) != FTMPC_OK ||
+            (rc = grow(h, &h->d_sqF, 6 * B)) != FTMPC_OK)
+            return rc;
+        h->cap_sqp = B;
+    }
+    hipStream_t s = h->stream;
+    HIP_TRY(h, hipMemcpyAsync(h->d_x0, x0, B * 13 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_ub, ub, B * NT * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_stuck, stuck, B * NT * sizeof(double), hipMemcpyHostToDevice, s));
+    if ((rc = stage_refs(h, B, xref, xref_stride, uref, uref_stride)) != FTMPC_OK) return rc;
+    if (warmU) HIP_TRY(h, hipMemcpyAsync(h->d_warm, warmU, B * nw * sizeof(double), hipMemcpyHostToDevice, s));
+    double *J = h->d_sqJ, *Jt = h->d_sqJ + B, *J0 = h->d_sqJ + 2 * B, *alpha = h->d_sqJ + 3 * B;
+    ftmpc::SqpState S;
+    S.B = B; S.N = N; S.NT = NT;
+    S.ub = h->d_ub;
+    S.U = h->d_sqU; S.Uq = h->d_sqQ; S.Ut = h->d_sqT;
+    S.J = J; S.Jt = Jt; S.alpha = alpha;
+    S.active = h->d_sqF; S.todo = h->d_sqF + B; S.improved = h->d_sqF + 2 * B; S.nmajor = h->d_sqF + 3 * B; S.ipm = h->d_sqF + 4 * B;
+    S.status = h->d_sqF + 5 * B;
+    S.qstatus = h->d_status; S.qiters = h->d_iters;
+    S.tol = tol;
+    const unsigned gE = (unsigned)((B * nw + 255) / 256), gB = (unsigned)((B + 255) / 256);
+    ftmpc::CostParams cp;
+    cp.B = B;
+    cp.x0 = h->d_x0; cp.ub = h->d_ub; cp.stuck = h->d_stuck;
+    cp.xref = h->d_xref; cp.xref_stride = xref_stride;
+    cp.uref = uref ? h->d_uref : nullptr; cp.uref_stride = uref_stride;
+    cp.tcost = h->d_tcost;
+    auto cost = [&](const double* U, double* out) {
+        cp.U = U;
+        cp.out = out;
+        hipLaunchKernelGGL(ftmpc::ftmpc_cost_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, h->dc, cp);
+    };
+    hipLaunchKernelGGL(ftmpc::ftmpc_sqp_init_kernel, dim3(gE > gB ? gE : gB), dim3(256), 0, s, S, warmU ? (const double*)h->d_warm : nullptr);
+    cost(S.U, J);
+    HIP_TRY(h, hipMemcpyAsync(J0, J, B * sizeof(double), hipMemcpyDeviceToDevice, s));
+    for (int it = 0; it < sqp_iters; ++it) {
+        // the QP linearised about the current iterate (every instance: a stopped one costs a solve but changes nothing)
+        rc = enqueue(h, B, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, xref_stride, uref ? h->d_uref : nullptr, uref_stride, S.U, h->d_u0, h->d_sqQ,
+                     h->d_status, h->d_iters, s, -1);
+        if (rc != FTMPC_OK) return rc;
+        hipLaunchKernelGGL(ftmpc::ftmpc_sqp_open_kernel, dim3(gB), dim3(256), 0, s, S);
+        for (int bt = 0; bt < backtracks; ++bt) {
+            hipLaunchKernelGGL(ftmpc::ftmpc_sqp_trial_kernel, dim3(gE), dim3(256), 0, s, S);
+            cost(S.Ut, Jt);
+            hipLaunchKernelGGL(ftmpc::ftmpc_sqp_decide_kernel, dim3(gB), dim3(256), 0, s, S);
+        }
+        hipLaunchKernelGGL(ftmpc::ftmpc_sqp_close_kernel, dim3(gE), dim3(256), 0, s, S);     // new iterate -> Ut
+        hipLaunchKernelGGL(ftmpc::ftmpc_sqp_count_kernel, dim3(gB), dim3(256), 0, s, S);
+        std::swap(S.U, S.Ut);
+        HIP_TRY(h, hipGetLastError());
+    }
+    // u0 = stage 0 of the final sequences
+    HIP_TRY(h, hipMemcpy2DAsync(out_u0, NT * sizeof(double), S.U, nw * sizeof(double), NT * sizeof(double), (size_t)B, hipMemcpyDeviceToHost, s));
+    if (out_U) HIP_TRY(h, hipMemcpyAsync(out_U, S.U, B * nw * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (out_cost) HIP_TRY(h, hipMemcpyAsync(out_cost, J, B * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (out_cost0) HIP_TRY(h, hipMemcpyAsync(out_cost0, J0, B * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (out_sqp_iters) HIP_TRY(h, hipMemcpyAsync(out_sqp_iters, S.nmajor, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (out_iters) HIP_TRY(h, hipMemcpyAsync(out_iters, S.ipm, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (status) HIP_TRY(h, hipMemcpyAsync(status, S.status, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
     return FTMPC_OK;
 }

@@ -103,4 +103,112 @@ __global__ void __launch_bounds__(256) ftmpc_shift_warm_kernel(int64_t B, int N,
     warm[i] = (r < per - NT) ? U[i + NT] : 0.0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Line-search SQP towards the reference's nonlinear program, on the device (reference
+// spiraling_mpc.py:87-238 solved by IPOPT :346).  ft_mpc_amd.BatchedMPC.solve_sqp is the host mirror of exactly this
+// bookkeeping; here nothing crosses PCIe between the first upload and the last download.
+//   per instance:  J (cost at U), Jt (cost at the trial point), alpha, flags {active, todo, improved}, counters
+// ---------------------------------------------------------------------------------------------------------
+struct SqpState {
+    int64_t B;
+    int32_t N, NT;
+    const double* ub;       // [B*NT]
+    double* U;              // [B*N*NT] current iterate
+    const double* Uq;       // [B*N*NT] solution of the QP linearised about U
+    double* Ut;             // [B*N*NT] trial point U + alpha (clip(Uq) - U)
+    double* J;              // [B]
+    const double* Jt;       // [B]
+    double* alpha;          // [B] current trial step; after a success: the accepted step
+    int32_t* active;        // [B]
+    int32_t* todo;          // [B]
+    int32_t* improved;      // [B]
+    int32_t* nmajor;        // [B]
+    int32_t* ipm;           // [B]
+    int32_t* status;        // [B]
+    const int32_t* qstatus; // [B] of the last QP
+    const int32_t* qiters;  // [B]
+    double tol;
+};
+
+// U = clip(warm, 0, ub) (or 0); active = 1; counters = 0
+__global__ void ftmpc_sqp_init_kernel(const SqpState S, const double* warm) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nw = (int64_t)S.N * S.NT;
+    if (i < S.B * nw) {
+        const int64_t b = i / nw;
+        const int t = (int)(i % S.NT);
+        const double ub = S.ub[b * S.NT + t];
+        S.U[i] = warm ? fmin(fmax(warm[i], 0.0), ub) : 0.0;
+    }
+    if (i < S.B) {
+        S.active[i] = 1;
+        S.todo[i] = 0;
+        S.improved[i] = 0;
+        S.nmajor[i] = 0;
+        S.ipm[i] = 0;
+        S.status[i] = 0;
+        S.alpha[i] = 1.0;
+    }
+}
+// after the QP of a major iteration: account for it, open the line search
+__global__ void ftmpc_sqp_open_kernel(const SqpState S) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= S.B) return;
+    const int act = S.active[b];
+    if (act) {
+        S.ipm[b] += S.qiters[b];
+        S.status[b] = S.qstatus[b];
+    }
+    S.todo[b] = act && S.qstatus[b] != 2;
+    S.improved[b] = 0;
+    S.alpha[b] = 1.0;
+}
+// trial point Ut = U + alpha (clip(Uq, 0, ub) - U)   (the fp32 kernels return ub rounded to float32: hence the clip)
+__global__ void ftmpc_sqp_trial_kernel(const SqpState S) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nw = (int64_t)S.N * S.NT;
+    if (i >= S.B * nw) return;
+    const int64_t b = i / nw;
+    const int t = (int)(i % S.NT);
+    const double ub = S.ub[b * S.NT + t];
+    const double step = fmin(fmax(S.Uq[i], 0.0), ub) - S.U[i];
+    S.Ut[i] = S.U[i] + S.alpha[b] * step;
+}
+// accept the trial point where the TRUE cost decreased enough, else halve the step
+__global__ void ftmpc_sqp_decide_kernel(const SqpState S) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= S.B || !S.todo[b]) return;
+    const double J = S.J[b], Jt = S.Jt[b];
+    if (Jt < J - S.tol * (1.0 + fabs(J))) {
+        S.J[b] = Jt;
+        S.improved[b] = 1;
+        S.todo[b] = 0;       // alpha keeps the accepted step
+    } else {
+        S.alpha[b] *= 0.5;
+    }
+}
+// close the line search: U += alpha step where a trial point was accepted; an instance without progress stops
+__global__ void ftmpc_sqp_close_kernel(const SqpState S) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nw = (int64_t)S.N * S.NT;
+    if (i < S.B * nw) {
+        const int64_t b = i / nw;
+        if (S.improved[b]) {
+            const int t = (int)(i % S.NT);
+            const double ub = S.ub[b * S.NT + t];
+            const double step = fmin(fmax(S.Uq[i], 0.0), ub) - S.U[i];
+            S.Ut[i] = S.U[i] + S.alpha[b] * step;      // (U is read by the other threads of this launch: the new iterate goes to Ut)
+        } else {
+            S.Ut[i] = S.U[i];
+        }
+    }
+}
+__global__ void ftmpc_sqp_count_kernel(const SqpState S) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= S.B) return;
+    S.nmajor[b] += S.improved[b];
+    S.active[b] = S.active[b] && S.improved[b];
+}
+
 }  // namespace ftmpc

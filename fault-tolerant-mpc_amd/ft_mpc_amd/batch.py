@@ -287,6 +287,25 @@ class BatchedMPC:
             active &= improved
         return dict(u0=U[:, 0, :].copy(), U=U, cost=J, cost0=J0, sqp_iters=n_major, iters=ipm, status=status)
 
+    def solve_sqp_device(self, x0, ub, stuck, xref, uref=None, warmU=None, sqp_iters=10, tol=1e-9, backtracks=8):
+        """The same line-search SQP with the whole loop on the device (include/ftmpc.h ftmpc_solve_sqp_batch): inputs go up
+        once, results come down once; every instance runs `sqp_iters` QP steps and `backtracks` cost evaluations per step
+        (a stopped instance's are discarded).  Same return dict as solve_sqp."""
+        N, NT = self.cfg.N, self.cfg.NT
+        x0 = _f64(x0).reshape(-1, 13)
+        B = x0.shape[0]
+        ub = _f64(ub, (B, NT))
+        stuck = _f64(stuck, (B, NT))
+        xref, xs, uref, us = self._refs(B, xref, uref)
+        W = None if warmU is None else _f64(warmU, (B, N, NT))
+        u0, U = np.empty((B, NT)), np.empty((B, N, NT))
+        J, J0 = np.empty(B), np.empty(B)
+        nmaj, ipm, st = np.empty(B, np.int32), np.empty(B, np.int32), np.empty(B, np.int32)
+        self._check(self.lib.ftmpc_solve_sqp_batch(self._h, B, _ptr(x0), _ptr(ub), _ptr(stuck), _ptr(xref), xs, _ptr(uref), us, _ptr(W),
+                                                   int(sqp_iters), int(backtracks), float(tol), _ptr(u0), _ptr(U), _ptr(J), _ptr(J0),
+                                                   _ptr(nmaj, C.c_int32), _ptr(ipm, C.c_int32), _ptr(st, C.c_int32)))
+        return dict(u0=u0, U=U, cost=J, cost0=J0, sqp_iters=nmaj, iters=ipm, status=st)
+
     # -- the reference's two-stage structure: 6-D generalized-force QP with the input hull, then allocation ----
     def solve_wrench(self, x0, ub, stuck, xref, uref=None, warmG=None, return_G=False, hull=None):
         """One MPC step in generalized-force space (reference: spiraling_mpc.py:87-238 with the per-stage hull rows

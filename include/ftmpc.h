@@ -192,6 +192,25 @@ int ftmpc_eval_cost_batch(ftmpc_handle* h, int64_t B,
                           const double* uref, int64_t uref_stride,
                           const double* U, double* out_cost);
 
+/*
+ * Line-search sequential QP towards the reference's NONLINEAR program (nonlinear RK4 dynamics, full terminal cost when
+ * terminal_cost_terms != 0; spiraling_mpc.py:87-238 as IPOPT solves it, :346), entirely on the device: per major iteration
+ * one QP step linearised about the current thruster sequences U (ftmpc_solve_batch's QP; Hessian 2 (B'QB + R + rho I) with
+ * the quadratic terminal weight, gradient exact), then backtracking alpha = 1, 1/2, ... (`backtracks` trial points) along
+ * clip(U_qp) - U on the TRUE cost (ftmpc_eval_cost_batch's kernel) until it decreases by more than tol (1 + |J|); an
+ * instance without such a step stops.  Nothing crosses PCIe between the upload of the inputs and the download of the results.
+ *   warmU         NULL (start from thrusters off) or [B*N*NT] start sequences (clipped to the bounds)
+ *   out_cost / out_cost0   [B] cost of the returned sequences / of the start point;  out_sqp_iters [B] major iterations that
+ *   made progress;  out_iters [B] interior-point iterations summed;  status [B] of the last QP.   HOST buffers.
+ */
+int ftmpc_solve_sqp_batch(ftmpc_handle* h, int64_t B,
+                          const double* x0, const double* ub, const double* stuck,
+                          const double* xref, int64_t xref_stride,
+                          const double* uref, int64_t uref_stride,
+                          const double* warmU, int32_t sqp_iters, int32_t backtracks, double tol,
+                          double* out_u0, double* out_U, double* out_cost, double* out_cost0,
+                          int32_t* out_sqp_iters, int32_t* out_iters, int32_t* status);
+
 /* Same contract with DEVICE pointers (HBM-resident inputs/outputs) enqueued on `stream`
  * (a hipStream_t passed as void*; NULL = the default stream).  Asynchronous: returns after
  * enqueue.  warmU is read only; pass the same buffer as out_U to update it in place. */

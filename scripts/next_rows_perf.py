@@ -43,4 +43,8 @@ print(f"nonlinear cost kernel (full terminal cost) N={N} NT={NT} B={B2}: {dt*1e3
 t0 = time.perf_counter(); out = mq.solve_sqp(x0[:16384], ub[:16384], stuck[:16384], xr, sqp_iters=10); dt = time.perf_counter() - t0
 print(f"line-search SQP, 10 major iterations max, B=16384: {dt*1e3:8.1f} ms  {16384/dt:9.0f} NLP solves/s  major iterations {out['sqp_iters'].mean():.2f}  "
       f"IPM iterations {out['iters'].mean():.1f}  cost {np.median(out['cost0']):.0f} -> {np.median(out['cost']):.1f} (median)", flush=True)
+t0 = time.perf_counter(); outd = mq.solve_sqp_device(x0, ub, stuck, xr, sqp_iters=10); dtd = time.perf_counter() - t0
+t0 = time.perf_counter(); outd = mq.solve_sqp_device(x0, ub, stuck, xr, sqp_iters=10); dtd = min(dtd, time.perf_counter() - t0)
+print(f"line-search SQP ON THE DEVICE (ftmpc_solve_sqp_batch), 10 major iterations, B={B2}: {dtd*1e3:8.1f} ms  {B2/dtd:9.0f} NLP solves/s  "
+      f"major iterations {outd['sqp_iters'].mean():.2f}  IPM iterations {outd['iters'].mean():.1f}  cost {np.median(outd['cost0']):.0f} -> {np.median(outd['cost']):.1f} (median)", flush=True)
 mq.close()

@@ -71,3 +71,23 @@ def test_line_search_sqp_against_the_oracle(gpu_mpc_factory):
     rel = mpc.solve(x0, ub, stuck, xref.reshape(-1, order="F"), return_U=True, relinearize=11)
     Jrel = mpc.eval_cost(x0, ub, stuck, xref.reshape(-1, order="F"), rel["U"])
     assert np.median(Jrel / out["cost"]) > 3.0
+
+
+@pytest.mark.parametrize("N,NT,dtype,warm", [(20, 8, "f32", False), (20, 8, "f32", True), (15, 16, "f32", False), (15, 16, "f64", True)])
+def test_on_device_sqp_equals_the_host_loop_bit_for_bit(gpu_mpc_factory, N, NT, dtype, warm):
+    """ftmpc_solve_sqp_batch keeps the whole line-search SQP on the device (QP step, trial points, cost evaluations, accept /
+    halve decisions per instance); BatchedMPC.solve_sqp is the same bookkeeping as a host loop over the same kernels.  Same
+    iterates, costs, counters -- bit for bit -- with and without a start sequence, on the one-wave, wrench-space and float64 kernels."""
+    T = load_terminal()
+    mpc = gpu_mpc_factory(N=N, NT=NT, dtype=dtype, terminal_cost=T)
+    B = 96
+    x0, ub, stuck, xref = qo.make_batch(B, N, NT, 2, 8300 + N)
+    xr = xref.reshape(-1, order="F")
+    W = None
+    if warm:
+        W = np.random.default_rng(5).uniform(-0.2, 1.2 * rm.F_MAX, (B, N, NT))      # beyond the bounds on purpose: both clip
+    host = mpc.solve_sqp(x0, ub, stuck, xr, warmU=None if W is None else W.copy(), sqp_iters=6)
+    dev = mpc.solve_sqp_device(x0, ub, stuck, xr, warmU=W, sqp_iters=6)
+    for k in ("U", "u0", "cost", "cost0", "sqp_iters", "iters", "status"):
+        assert np.array_equal(host[k], dev[k]), k
+    assert (dev["cost"] < dev["cost0"]).all() and (dev["sqp_iters"] >= 2).all()

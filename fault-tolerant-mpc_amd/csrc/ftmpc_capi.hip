@@ -932,6 +932,66 @@ int ftmpc_eval_cost_batch(ftmpc_handle* h, int64_t B, const double* x0, const do
     return FTMPC_OK;
 }
 
+// The line-search SQP over DEVICE buffers (h->d_x0 / d_ub / d_stuck and the given reference windows), enqueued on h->stream:
+// on return S describes where the results are (S.U the final sequences, S.J their cost, J0 the cost of the start point).
+static int sqp_enqueue(ftmpc_handle* h, int64_t B, const double* d_xref, int64_t xref_stride, const double* d_uref, int64_t uref_stride,
+                       const double* d_warm, int32_t sqp_iters, int32_t backtracks, double tol, ftmpc::SqpState& S, double** J0_out) {
+    const int N = h->cfg.N, NT = h->cfg.NT;
+    const int64_t nw = (int64_t)N * NT;
+    int rc;
+    if (B > h->cap_sqp) {
+        h->cap_sqp = 0;
+        if ((rc = grow(h, &h->d_sqU, B * nw)) != FTMPC_OK || (rc = grow(h, &h->d_sqQ, B * nw)) != FTMPC_OK ||
+            (rc = grow(h, &h->d_sqT, B * nw)) != FTMPC_OK || (rc = grow(h, &h->d_sqJ, 4 * B)) != FTMPC_OK ||
+            (rc = grow(h, &h->d_sqF, 6 * B)) != FTMPC_OK)
+            return rc;
+        h->cap_sqp = B;
+    }
+    hipStream_t s = h->stream;
+    double *J = h->d_sqJ, *Jt = h->d_sqJ + B, *J0 = h->d_sqJ + 2 * B, *alpha = h->d_sqJ + 3 * B;
+    S.B = B; S.N = N; S.NT = NT;
+    S.ub = h->d_ub;
+    S.U = h->d_sqU; S.Uq = h->d_sqQ; S.Ut = h->d_sqT;
+    S.J = J; S.Jt = Jt; S.alpha = alpha;
+    S.active = h->d_sqF; S.todo = h->d_sqF + B; S.improved = h->d_sqF + 2 * B; S.nmajor = h->d_sqF + 3 * B; S.ipm = h->d_sqF + 4 * B;
+    S.status = h->d_sqF + 5 * B;
+    S.qstatus = h->d_status; S.qiters = h->d_iters;
+    S.tol = tol;
+    const unsigned gE = (unsigned)((B * nw + 255) / 256), gB = (unsigned)((B + 255) / 256);
+    ftmpc::CostParams cp;
+    cp.B = B;
+    cp.x0 = h->d_x0; cp.ub = h->d_ub; cp.stuck = h->d_stuck;
+    cp.xref = d_xref; cp.xref_stride = xref_stride;
+    cp.uref = d_uref; cp.uref_stride = uref_stride;
+    cp.tcost = h->d_tcost;
+    auto cost = [&](const double* U, double* out) {
+        cp.U = U;
+        cp.out = out;
+        hipLaunchKernelGGL(ftmpc::ftmpc_cost_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, h->dc, cp);
+    };
+    hipLaunchKernelGGL(ftmpc::ftmpc_sqp_init_kernel, dim3(gE > gB ? gE : gB), dim3(256), 0, s, S, d_warm);
+    cost(S.U, J);
+    HIP_TRY(h, hipMemcpyAsync(J0, J, B * sizeof(double), hipMemcpyDeviceToDevice, s));
+    for (int it = 0; it < sqp_iters; ++it) {
+        // the QP linearised about the current iterate (every instance: a stopped one costs a solve but changes nothing)
+        rc = enqueue(h, B, h->d_x0, h->d_ub, h->d_stuck, d_xref, xref_stride, d_uref, uref_stride, S.U, h->d_u0, h->d_sqQ, h->d_status,
+                     h->d_iters, s, -1);
+        if (rc != FTMPC_OK) return rc;
+        hipLaunchKernelGGL(ftmpc::ftmpc_sqp_open_kernel, dim3(gB), dim3(256), 0, s, S);
+        for (int bt = 0; bt < backtracks; ++bt) {
+            hipLaunchKernelGGL(ftmpc::ftmpc_sqp_trial_kernel, dim3(gE), dim3(256), 0, s, S);
+            cost(S.Ut, Jt);
+            hipLaunchKernelGGL(ftmpc::ftmpc_sqp_decide_kernel, dim3(gB), dim3(256), 0, s, S);
+        }
+        hipLaunchKernelGGL(ftmpc::ftmpc_sqp_close_kernel, dim3(gE), dim3(256), 0, s, S);     // new iterate -> Ut
+        hipLaunchKernelGGL(ftmpc::ftmpc_sqp_count_kernel, dim3(gB), dim3(256), 0, s, S);
+        std::swap(S.U, S.Ut);
+        HIP_TRY(h, hipGetLastError());
+    }
+    *J0_out = J0;
+    return FTMPC_OK;
+}
+
 int ftmpc_solve_sqp_batch(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, const double* stuck, const double* xref,
                           int64_t xref_stride, const double* uref, int64_t uref_stride, const double* warmU, int32_t sqp_iters,
                           int32_t backtracks, double tol, double* out_u0, double* out_U, double* out_cost, double* out_cost0,
@@ -946,65 +1006,21 @@ int ftmpc_solve_sqp_batch(ftmpc_handle* h, int64_t B, const double* x0, const do
     if ((rc = ftmpc_reserve(h, B)) != FTMPC_OK) return rc;
     const int N = h->cfg.N, NT = h->cfg.NT;
     const int64_t nw = (int64_t)N * NT;
-    if (B > h->cap_sqp) {
-        h->cap_sqp = 0;
-        if ((rc = grow(h, &h->d_sqU, B * nw)) != FTMPC_OK || (rc = grow(h, &h->d_sqQ, B * nw)) != FTMPC_OK ||
-            (rc = grow(h, &h->d_sqT, B * nw)) != FTMPC_OK || (rc = grow(h, &h->d_sqJ, 4 * B)) != FTMPC_OK ||
-            (rc = grow(h, &h->d_sqF, 6 * B)) != FTMPC_OK)
-            return rc;
-        h->cap_sqp = B;
-    }
     hipStream_t s = h->stream;
     HIP_TRY(h, hipMemcpyAsync(h->d_x0, x0, B * 13 * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(h, hipMemcpyAsync(h->d_ub, ub, B * NT * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(h, hipMemcpyAsync(h->d_stuck, stuck, B * NT * sizeof(double), hipMemcpyHostToDevice, s));
     if ((rc = stage_refs(h, B, xref, xref_stride, uref, uref_stride)) != FTMPC_OK) return rc;
     if (warmU) HIP_TRY(h, hipMemcpyAsync(h->d_warm, warmU, B * nw * sizeof(double), hipMemcpyHostToDevice, s));
-    double *J = h->d_sqJ, *Jt = h->d_sqJ + B, *J0 = h->d_sqJ + 2 * B, *alpha = h->d_sqJ + 3 * B;
     ftmpc::SqpState S;
-    S.B = B; S.N = N; S.NT = NT;
-    S.ub = h->d_ub;
-    S.U = h->d_sqU; S.Uq = h->d_sqQ; S.Ut = h->d_sqT;
-    S.J = J; S.Jt = Jt; S.alpha = alpha;
-    S.active = h->d_sqF; S.todo = h->d_sqF + B; S.improved = h->d_sqF + 2 * B; S.nmajor = h->d_sqF + 3 * B; S.ipm = h->d_sqF + 4 * B;
-    S.status = h->d_sqF + 5 * B;
-    S.qstatus = h->d_status; S.qiters = h->d_iters;
-    S.tol = tol;
-    const unsigned gE = (unsigned)((B * nw + 255) / 256), gB = (unsigned)((B + 255) / 256);
-    ftmpc::CostParams cp;
-    cp.B = B;
-    cp.x0 = h->d_x0; cp.ub = h->d_ub; cp.stuck = h->d_stuck;
-    cp.xref = h->d_xref; cp.xref_stride = xref_stride;
-    cp.uref = uref ? h->d_uref : nullptr; cp.uref_stride = uref_stride;
-    cp.tcost = h->d_tcost;
-    auto cost = [&](const double* U, double* out) {
-        cp.U = U;
-        cp.out = out;
-        hipLaunchKernelGGL(ftmpc::ftmpc_cost_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, h->dc, cp);
-    };
-    hipLaunchKernelGGL(ftmpc::ftmpc_sqp_init_kernel, dim3(gE > gB ? gE : gB), dim3(256), 0, s, S, warmU ? (const double*)h->d_warm : nullptr);
-    cost(S.U, J);
-    HIP_TRY(h, hipMemcpyAsync(J0, J, B * sizeof(double), hipMemcpyDeviceToDevice, s));
-    for (int it = 0; it < sqp_iters; ++it) {
-        // the QP linearised about the current iterate (every instance: a stopped one costs a solve but changes nothing)
-        rc = enqueue(h, B, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, xref_stride, uref ? h->d_uref : nullptr, uref_stride, S.U, h->d_u0, h->d_sqQ,
-                     h->d_status, h->d_iters, s, -1);
-        if (rc != FTMPC_OK) return rc;
-        hipLaunchKernelGGL(ftmpc::ftmpc_sqp_open_kernel, dim3(gB), dim3(256), 0, s, S);
-        for (int bt = 0; bt < backtracks; ++bt) {
-            hipLaunchKernelGGL(ftmpc::ftmpc_sqp_trial_kernel, dim3(gE), dim3(256), 0, s, S);
-            cost(S.Ut, Jt);
-            hipLaunchKernelGGL(ftmpc::ftmpc_sqp_decide_kernel, dim3(gB), dim3(256), 0, s, S);
-        }
-        hipLaunchKernelGGL(ftmpc::ftmpc_sqp_close_kernel, dim3(gE), dim3(256), 0, s, S);     // new iterate -> Ut
-        hipLaunchKernelGGL(ftmpc::ftmpc_sqp_count_kernel, dim3(gB), dim3(256), 0, s, S);
-        std::swap(S.U, S.Ut);
-        HIP_TRY(h, hipGetLastError());
-    }
+    double* J0 = nullptr;
+    if ((rc = sqp_enqueue(h, B, h->d_xref, xref_stride, uref ? h->d_uref : nullptr, uref_stride, warmU ? h->d_warm : nullptr, sqp_iters,
+                          backtracks, tol, S, &J0)) != FTMPC_OK)
+        return rc;
     // u0 = stage 0 of the final sequences
     HIP_TRY(h, hipMemcpy2DAsync(out_u0, NT * sizeof(double), S.U, nw * sizeof(double), NT * sizeof(double), (size_t)B, hipMemcpyDeviceToHost, s));
     if (out_U) HIP_TRY(h, hipMemcpyAsync(out_U, S.U, B * nw * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (out_cost) HIP_TRY(h, hipMemcpyAsync(out_cost, J, B * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (out_cost) HIP_TRY(h, hipMemcpyAsync(out_cost, S.J, B * sizeof(double), hipMemcpyDeviceToHost, s));
     if (out_cost0) HIP_TRY(h, hipMemcpyAsync(out_cost0, J0, B * sizeof(double), hipMemcpyDeviceToHost, s));
     if (out_sqp_iters) HIP_TRY(h, hipMemcpyAsync(out_sqp_iters, S.nmajor, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     if (out_iters) HIP_TRY(h, hipMemcpyAsync(out_iters, S.ipm, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -1307,7 +1323,14 @@ int ftmpc_debug_build_qp(ftmpc_handle* h, int64_t B, const double* x0, const dou
 int ftmpc_simulate_batch(ftmpc_handle* h, int64_t B, int32_t T, double* x, const double* ub, const double* stuck,
                          const double* xref_traj, const double* uref_traj, const double noise[4], uint64_t seed,
                          double* u_hist, int32_t* not_converged) {
+    return ftmpc_simulate_batch_ex(h, B, T, x, ub, stuck, xref_traj, uref_traj, noise, seed, 0, 0, 0.0, u_hist, not_converged);
+}
+
+int ftmpc_simulate_batch_ex(ftmpc_handle* h, int64_t B, int32_t T, double* x, const double* ub, const double* stuck,
+                            const double* xref_traj, const double* uref_traj, const double noise[4], uint64_t seed,
+                            int32_t sqp_iters, int32_t backtracks, double tol, double* u_hist, int32_t* not_converged) {
     if (!h) return FTMPC_ERR_ARG;
+    if (sqp_iters < 0 || (sqp_iters > 0 && (backtracks < 1 || !(tol >= 0)))) return fail(h, FTMPC_ERR_ARG, "bad SQP iteration counts");
     if (B < 0 || T < 0 || !x || !ub || !stuck || !xref_traj || !noise) return fail(h, FTMPC_ERR_ARG, "null buffer or negative size");
     if (B == 0 || T == 0) return FTMPC_OK;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1358,16 +1381,29 @@ int ftmpc_simulate_batch(ftmpc_handle* h, int64_t B, int32_t T, double* x, const
     const int64_t nw = B * (int64_t)N * NT;
     for (int t = 0; t < T; ++t) {
         // window t..t+N of the reference (column-major, so a plain pointer offset); warm start from step 1 on
-        rc = enqueue(h, B, h->d_x0, h->d_ub, h->d_stuck, d_xr + (int64_t)9 * t, 0, uref_traj ? d_ur + (int64_t)6 * t : nullptr, 0,
-                     t > 0 ? d_warmB : nullptr, h->d_u0, h->d_U, h->d_status, h->d_iters, s, -1);
+        const double* Ufin = h->d_U;
+        if (sqp_iters > 0) {     // the nonlinear program of this step by the line-search SQP, started from the shifted previous solution
+            ftmpc::SqpState S;
+            double* J0 = nullptr;
+            rc = sqp_enqueue(h, B, d_xr + (int64_t)9 * t, 0, uref_traj ? d_ur + (int64_t)6 * t : nullptr, 0, t > 0 ? d_warmB : nullptr, sqp_iters,
+                             backtracks, tol, S, &J0);
+            if (rc == FTMPC_OK) {
+                Ufin = S.U;
+                sp.status = S.status;
+                SIM_TRY(hipMemcpy2DAsync(h->d_u0, NT * sizeof(double), S.U, (size_t)N * NT * sizeof(double), NT * sizeof(double), (size_t)B,
+                                         hipMemcpyDeviceToDevice, s));
+            }
+        } else {
+            rc = enqueue(h, B, h->d_x0, h->d_ub, h->d_stuck, d_xr + (int64_t)9 * t, 0, uref_traj ? d_ur + (int64_t)6 * t : nullptr, 0,
+                         t > 0 ? d_warmB : nullptr, h->d_u0, h->d_U, h->d_status, h->d_iters, s, -1);
+        }
         if (rc != FTMPC_OK) {
             cleanup();
             return rc;
         }
         sp.step = t;
         hipLaunchKernelGGL(ftmpc::ftmpc_plant_step_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, h->dc, sp);
-        hipLaunchKernelGGL(ftmpc::ftmpc_shift_warm_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, B, N, NT,
-                           (const double*)h->d_U, d_warmB);
+        hipLaunchKernelGGL(ftmpc::ftmpc_shift_warm_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, B, N, NT, Ufin, d_warmB);
         SIM_TRY(hipGetLastError());
     }
     SIM_TRY(hipMemcpyAsync(x, h->d_x0, (size_t)B * 13 * sizeof(double), hipMemcpyDeviceToHost, s));

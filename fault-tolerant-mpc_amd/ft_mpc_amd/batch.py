@@ -364,8 +364,10 @@ class BatchedMPC:
 
     # -- closed loop on the device (SimulationEnvironment.run_simulation, batched) ------------
     def simulate(self, x0, ub, stuck, xref_traj, T, uref_traj=None, noise=(1e-3, 1e-3, 1e-3, 1e-3), seed=0,
-                 return_inputs=False):
+                 return_inputs=False, sqp_iters=0, backtracks=8, tol=1e-9):
         """T closed-loop steps (MPC step -> plant RK4 -> noise -> renormalise) without host round trips.
+        sqp_iters > 0: every step solves the nonlinear program by that many major iterations of the line-search SQP
+        (solve_sqp_device) instead of one QP step.
         xref_traj: 9 x (T+N) (column t..t+N is the window of step t), uref_traj: 6 x (T+N) or None.
         Returns dict(x [B,13] final states, u [T,B,NT]|None, not_converged [T])."""
         N, NT = self.cfg.N, self.cfg.NT
@@ -386,8 +388,9 @@ class BatchedMPC:
         nz = _f64(noise, 4)
         uh = np.empty((T, B, NT)) if return_inputs else None
         bad = np.zeros(T, np.int32)
-        self._check(self.lib.ftmpc_simulate_batch(self._h, B, int(T), _ptr(x), _ptr(ub), _ptr(stuck), _ptr(xr), _ptr(ur),
-                                                  _ptr(nz), C.c_uint64(int(seed)), _ptr(uh), _ptr(bad, C.c_int32)))
+        self._check(self.lib.ftmpc_simulate_batch_ex(self._h, B, int(T), _ptr(x), _ptr(ub), _ptr(stuck), _ptr(xr), _ptr(ur),
+                                                     _ptr(nz), C.c_uint64(int(seed)), int(sqp_iters), int(backtracks), float(tol),
+                                                     _ptr(uh), _ptr(bad, C.c_int32)))
         return dict(x=x, u=uh, not_converged=bad)
 
     # -- standalone thruster allocation (ControlAllocator.get_physical_input, batched) ---------

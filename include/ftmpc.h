@@ -291,6 +291,12 @@ int ftmpc_simulate_batch(ftmpc_handle* h, int64_t B, int32_t T, double* x, const
                          const double* xref_traj, const double* uref_traj, const double noise[4], uint64_t seed,
                          double* u_hist, int32_t* not_converged);
 
+/* The same closed loop with the NONLINEAR program solved at every step (sqp_iters > 0: that many major iterations of the
+ * line-search SQP of ftmpc_solve_sqp_batch, started from the shifted previous solution; sqp_iters = 0: ftmpc_simulate_batch). */
+int ftmpc_simulate_batch_ex(ftmpc_handle* h, int64_t B, int32_t T, double* x, const double* ub, const double* stuck,
+                            const double* xref_traj, const double* uref_traj, const double noise[4], uint64_t seed,
+                            int32_t sqp_iters, int32_t backtracks, double tol, double* u_hist, int32_t* not_converged);
+
 /* Per-kernel device timing of the LAST solve call, measured with hipEvents on the launch
  * stream when enabled.  ms[slot] is the duration of kernel slot `slot` (0 when that kernel was
  * not launched), for slot < min(n_slots, FTMPC_KERNEL_SLOTS); ftmpc_kernel_name(slot) is the kernel's name as it appears

@@ -91,3 +91,34 @@ def test_on_device_sqp_equals_the_host_loop_bit_for_bit(gpu_mpc_factory, N, NT, 
     for k in ("U", "u0", "cost", "cost0", "sqp_iters", "iters", "status"):
         assert np.array_equal(host[k], dev[k]), k
     assert (dev["cost"] < dev["cost0"]).all() and (dev["sqp_iters"] >= 2).all()
+
+
+def test_closed_loop_with_the_sqp_at_every_step_equals_the_step_by_step_loop(gpu_mpc_factory):
+    """ftmpc_simulate_batch_ex with sqp_iters > 0: plant, noise, warm-start shift and the line-search SQP of every step on the
+    device.  Against the same loop driven from the host step by step (solve_sqp_device per step, the oracle's plant and its
+    counter-based noise): the SQP results are the same bits, the plants agree to rounding."""
+    from oracle import c_oracle as co
+    from oracle import closed_loop as cl
+    N, NT, B, Tn = 15, 16, 6, 5
+    Tm = load_terminal()
+    mpc = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40, terminal_cost=Tm)
+    cfg = qo.QPConfig(N=N, NT=NT)
+    x0, ub, stuck, _ = qo.make_batch(B, N, NT, 2, 8400)
+    xr = np.zeros((9, Tn + N))
+    xr[8] = 0.6
+    out = mpc.simulate(x0, ub, stuck, xr, Tn, seed=21, return_inputs=True, sqp_iters=3)
+    x = x0.copy()
+    amp = np.repeat(np.full(4, 1e-3), [3, 3, 4, 3])
+    warm = None
+    for t in range(Tn):
+        step = mpc.solve_sqp_device(x, ub, stuck, np.ascontiguousarray(xr[:, t:t + N + 1]).reshape(-1, order="F"), warmU=warm, sqp_iters=3)
+        assert np.abs(step["u0"] - out["u"][t]).max() < 1e-8, t
+        warm = np.concatenate([step["U"][:, 1:], np.zeros((B, 1, NT))], axis=1)
+        for b in range(B):
+            x[b] = co.plant_step(cfg, x[b], step["u0"][b], ub[b], stuck[b])
+        idx = (np.uint64(t) * np.uint64(B) + np.arange(B, dtype=np.uint64))[:, None] * np.uint64(13) + np.arange(13, dtype=np.uint64)[None, :]
+        x = x + amp[None, :] * cl.u01(21, idx)
+        x[:, 6:10] /= np.linalg.norm(x[:, 6:10], axis=1, keepdims=True)
+    assert np.abs(out["x"] - x).max() < 1e-8
+    plain = mpc.simulate(x0, ub, stuck, xr, Tn, seed=21, return_inputs=True)
+    assert np.abs(plain["u"] - out["u"]).max() > 1e-4        # the nonlinear program is not the one-step QP

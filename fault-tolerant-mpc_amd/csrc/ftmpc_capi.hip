@@ -1048,15 +1048,10 @@ int ftmpc_solve_batch_device(ftmpc_handle* h, int64_t B, const double* x0, const
                    reinterpret_cast<hipStream_t>(stream), -1);
 }
 
-int ftmpc_solve_wrench_batch(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, const double* stuck,
-                             const double* hull_A, int32_t n_sets, const int32_t* hull_set, const double* hull_b, int32_t hull_rows,
-                             const double* xref, int64_t xref_stride, const double* uref, int64_t uref_stride, double* warmG,
-                             double* out_u0, double* out_tau0, double* out_G, int32_t* status, int32_t* iters, int32_t* alloc_status) {
-    if (!h) return FTMPC_ERR_ARG;
-    if (B < 0 || !x0 || !ub || !stuck || !xref || !out_u0 || !hull_A || !hull_b)
-        return fail(h, FTMPC_ERR_ARG, "null buffer or negative batch");
-    if (B == 0) return FTMPC_OK;
-    const int N = h->cfg.N, NT = h->cfg.NT;
+// Validation, workspace and hull tables of the generalized-force formulation (shared by the one-step entry and the closed loop).
+static int wrench_prepare(ftmpc_handle* h, int64_t B, const double* hull_A, int32_t n_sets, const int32_t* hull_set, const double* hull_b,
+                          int32_t hull_rows) {
+    const int N = h->cfg.N;
     if (6 * N > 256) return fail(h, FTMPC_ERR_ARG, "the generalized-force formulation needs 6 N <= 256");
     if (hull_rows < 1 || hull_rows > FTMPC_MAX_HULL_ROWS || (int64_t)N * hull_rows > 1024 || n_sets < 1)
         return fail(h, FTMPC_ERR_ARG, "hull_rows out of range (1..32, N * hull_rows <= 1024) or no hull table");
@@ -1065,8 +1060,7 @@ int ftmpc_solve_wrench_batch(ftmpc_handle* h, int64_t B, const double* x0, const
         for (int64_t b = 0; b < B; ++b)
             if (hull_set[b] < 0 || hull_set[b] >= n_sets)
                 return fail(h, FTMPC_ERR_ARG, "hull_set[" + std::to_string(b) + "] = " + std::to_string(hull_set[b]) + " is not a table number in [0, n_sets)");
-    int rc = check_strides(h, xref_stride, uref_stride, uref);
-    if (rc != FTMPC_OK) return rc;
+    int rc;
     HIP_TRY(h, hipSetDevice(h->device));
     if ((rc = ftmpc_reserve(h, B)) != FTMPC_OK) return rc;
     // per-workgroup slots of the 6N-variable problem (separate from the thruster-space slots of this handle)
@@ -1102,23 +1096,26 @@ int ftmpc_solve_wrench_batch(ftmpc_handle* h, int64_t B, const double* x0, const
         h->cap_wrench = B;
     }
     hipStream_t s = h->stream;
-    HIP_TRY(h, hipMemcpyAsync(h->d_x0, x0, B * 13 * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(h, hipMemcpyAsync(h->d_ub, ub, B * NT * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(h, hipMemcpyAsync(h->d_stuck, stuck, B * NT * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(h, hipMemcpyAsync(h->d_hullA, hull_A, nA * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(h, hipMemcpyAsync(h->d_hullb, hull_b, B * hull_rows * sizeof(double), hipMemcpyHostToDevice, s));
     if (hull_set) HIP_TRY(h, hipMemcpyAsync(h->d_hullset, hull_set, B * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    if ((rc = stage_refs(h, B, xref, xref_stride, uref, uref_stride)) != FTMPC_OK) return rc;
-    if (warmG) HIP_TRY(h, hipMemcpyAsync(h->d_warmG, warmG, B * N * 6 * sizeof(double), hipMemcpyHostToDevice, s));
+    return FTMPC_OK;
+}
+
+// One two-stage step over DEVICE buffers (h->d_x0 / d_ub / d_stuck, the staged hull tables, the given reference windows):
+// linearise, the 6N-variable QP with the hull rows, allocation.  Leaves u0 in h->d_u0, tau_0 in h->d_tau0, the wrenches in h->d_G.
+static int wrench_enqueue(ftmpc_handle* h, int64_t B, int32_t hull_rows, bool has_set, const double* d_xref, int64_t xref_stride,
+                          const double* d_uref, int64_t uref_stride, const double* d_warmG) {
+    hipStream_t s = h->stream;
     LinParams lp;
     lp.B = B;
     lp.x0 = h->d_x0; lp.ub = h->d_ub; lp.stuck = h->d_stuck;
-    lp.xref = h->d_xref; lp.xref_stride = xref_stride;
-    lp.uref = uref ? h->d_uref : nullptr; lp.uref_stride = uref_stride;
+    lp.xref = d_xref; lp.xref_stride = xref_stride;
+    lp.uref = d_uref; lp.uref_stride = uref_stride;
     lp.warmU = nullptr;
     lp.rec = h->rec;
     lp.qlist = nullptr; lp.qcount = nullptr; lp.qvmax = -1;
-    lp.warmG = warmG ? h->d_warmG : nullptr;
+    lp.warmG = d_warmG;
     lp.out_eN = h->d_eN;
     lp.tcost = h->d_tcost;
     launch_linearize(h, B, (int)((B + 63) / 64), s, lp);
@@ -1135,9 +1132,9 @@ int ftmpc_solve_wrench_batch(ftmpc_handle* h, int64_t B, const double* x0, const
     q.tile_doubles = h->tile_doubles_gen;
     q.e_doubles = h->e_doubles_gen;
     q.npad_max = h->npad_gen;
-    q.warmG = warmG ? h->d_warmG : nullptr;
+    q.warmG = d_warmG;
     q.hullA = h->d_hullA;
-    q.hull_set = hull_set ? h->d_hullset : nullptr;
+    q.hull_set = has_set ? h->d_hullset : nullptr;
     q.hullb = h->d_hullb;
     q.hull_rows = hull_rows;
     q.termA = h->cfg.terminal_set ? h->d_term : nullptr;
@@ -1169,6 +1166,30 @@ int ftmpc_solve_wrench_batch(ftmpc_handle* h, int64_t B, const double* x0, const
     ap.tol = 1e-8;
     hipLaunchKernelGGL(ftmpc::ftmpc_allocate_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, h->dc, ap);
     HIP_TRY(h, hipGetLastError());
+    return FTMPC_OK;
+}
+
+int ftmpc_solve_wrench_batch(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, const double* stuck,
+                             const double* hull_A, int32_t n_sets, const int32_t* hull_set, const double* hull_b, int32_t hull_rows,
+                             const double* xref, int64_t xref_stride, const double* uref, int64_t uref_stride, double* warmG,
+                             double* out_u0, double* out_tau0, double* out_G, int32_t* status, int32_t* iters, int32_t* alloc_status) {
+    if (!h) return FTMPC_ERR_ARG;
+    if (B < 0 || !x0 || !ub || !stuck || !xref || !out_u0 || !hull_A || !hull_b)
+        return fail(h, FTMPC_ERR_ARG, "null buffer or negative batch");
+    if (B == 0) return FTMPC_OK;
+    const int N = h->cfg.N, NT = h->cfg.NT;
+    int rc = check_strides(h, xref_stride, uref_stride, uref);
+    if (rc != FTMPC_OK) return rc;
+    if ((rc = wrench_prepare(h, B, hull_A, n_sets, hull_set, hull_b, hull_rows)) != FTMPC_OK) return rc;
+    hipStream_t s = h->stream;
+    HIP_TRY(h, hipMemcpyAsync(h->d_x0, x0, B * 13 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_ub, ub, B * NT * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_stuck, stuck, B * NT * sizeof(double), hipMemcpyHostToDevice, s));
+    if ((rc = stage_refs(h, B, xref, xref_stride, uref, uref_stride)) != FTMPC_OK) return rc;
+    if (warmG) HIP_TRY(h, hipMemcpyAsync(h->d_warmG, warmG, B * N * 6 * sizeof(double), hipMemcpyHostToDevice, s));
+    if ((rc = wrench_enqueue(h, B, hull_rows, hull_set != nullptr, h->d_xref, xref_stride, uref ? h->d_uref : nullptr, uref_stride,
+                             warmG ? h->d_warmG : nullptr)) != FTMPC_OK)
+        return rc;
     HIP_TRY(h, hipMemcpyAsync(out_u0, h->d_u0, B * NT * sizeof(double), hipMemcpyDeviceToHost, s));
     if (out_tau0) HIP_TRY(h, hipMemcpyAsync(out_tau0, h->d_tau0, B * 6 * sizeof(double), hipMemcpyDeviceToHost, s));
     if (out_G) HIP_TRY(h, hipMemcpyAsync(out_G, h->d_G, B * N * 6 * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1326,6 +1347,16 @@ int ftmpc_simulate_batch(ftmpc_handle* h, int64_t B, int32_t T, double* x, const
     return ftmpc_simulate_batch_ex(h, B, T, x, ub, stuck, xref_traj, uref_traj, noise, seed, 0, 0, 0.0, u_hist, not_converged);
 }
 
+struct WrenchLoop {      // the two-stage structure inside the closed loop: hull tables staged once, constant over the run
+    int32_t hull_rows;
+    bool has_set;
+    int32_t* alloc_failed;   // host [T] or null
+};
+
+static int simulate_core(ftmpc_handle* h, int64_t B, int32_t T, double* x, const double* ub, const double* stuck, const double* xref_traj,
+                         const double* uref_traj, const double noise[4], uint64_t seed, int32_t sqp_iters, int32_t backtracks, double tol,
+                         const WrenchLoop* wl, double* u_hist, int32_t* not_converged);
+
 int ftmpc_simulate_batch_ex(ftmpc_handle* h, int64_t B, int32_t T, double* x, const double* ub, const double* stuck,
                             const double* xref_traj, const double* uref_traj, const double noise[4], uint64_t seed,
                             int32_t sqp_iters, int32_t backtracks, double tol, double* u_hist, int32_t* not_converged) {
@@ -1336,12 +1367,33 @@ int ftmpc_simulate_batch_ex(ftmpc_handle* h, int64_t B, int32_t T, double* x, co
     HIP_TRY(h, hipSetDevice(h->device));
     int rc = ftmpc_reserve(h, B);
     if (rc != FTMPC_OK) return rc;
+    return simulate_core(h, B, T, x, ub, stuck, xref_traj, uref_traj, noise, seed, sqp_iters, backtracks, tol, nullptr, u_hist, not_converged);
+}
+
+int ftmpc_simulate_wrench_batch(ftmpc_handle* h, int64_t B, int32_t T, double* x, const double* ub, const double* stuck,
+                                const double* hull_A, int32_t n_sets, const int32_t* hull_set, const double* hull_b, int32_t hull_rows,
+                                const double* xref_traj, const double* uref_traj, const double noise[4], uint64_t seed,
+                                double* u_hist, int32_t* not_converged, int32_t* alloc_failed) {
+    if (!h) return FTMPC_ERR_ARG;
+    if (B < 0 || T < 0 || !x || !ub || !stuck || !xref_traj || !noise || !hull_A || !hull_b) return fail(h, FTMPC_ERR_ARG, "null buffer or negative size");
+    if (B == 0 || T == 0) return FTMPC_OK;
+    int rc = wrench_prepare(h, B, hull_A, n_sets, hull_set, hull_b, hull_rows);
+    if (rc != FTMPC_OK) return rc;
+    WrenchLoop wl{hull_rows, hull_set != nullptr, alloc_failed};
+    return simulate_core(h, B, T, x, ub, stuck, xref_traj, uref_traj, noise, seed, 0, 0, 0.0, &wl, u_hist, not_converged);
+}
+
+static int simulate_core(ftmpc_handle* h, int64_t B, int32_t T, double* x, const double* ub, const double* stuck, const double* xref_traj,
+                         const double* uref_traj, const double noise[4], uint64_t seed, int32_t sqp_iters, int32_t backtracks, double tol,
+                         const WrenchLoop* wl, double* u_hist, int32_t* not_converged) {
+    int rc;
     const int N = h->cfg.N, NT = h->cfg.NT;
     hipStream_t s = h->stream;
     const int64_t ncol = (int64_t)T + N;   // windows t .. t+N for t < T
     double *d_xr = nullptr, *d_ur = nullptr, *d_warmB = nullptr, *d_hist = nullptr;
-    int32_t* d_bad = nullptr;
+    int32_t *d_bad = nullptr, *d_abad = nullptr;
     auto cleanup = [&]() {
+        if (d_abad) (void)hipFree(d_abad);
         if (d_xr) (void)hipFree(d_xr);
         if (d_ur) (void)hipFree(d_ur);
         if (d_warmB) (void)hipFree(d_warmB);
@@ -1358,7 +1410,11 @@ int ftmpc_simulate_batch_ex(ftmpc_handle* h, int64_t B, int32_t T, double* x, co
     } while (0)
     SIM_TRY(hipMalloc(&d_xr, (size_t)ncol * 9 * sizeof(double)));
     if (uref_traj) SIM_TRY(hipMalloc(&d_ur, (size_t)ncol * 6 * sizeof(double)));
-    SIM_TRY(hipMalloc(&d_warmB, (size_t)B * N * NT * sizeof(double)));
+    if (!wl) SIM_TRY(hipMalloc(&d_warmB, (size_t)B * N * NT * sizeof(double)));
+    if (wl && wl->alloc_failed) {
+        SIM_TRY(hipMalloc(&d_abad, (size_t)T * sizeof(int32_t)));
+        SIM_TRY(hipMemsetAsync(d_abad, 0, (size_t)T * sizeof(int32_t), s));
+    }
     if (u_hist) SIM_TRY(hipMalloc(&d_hist, (size_t)T * B * NT * sizeof(double)));
     SIM_TRY(hipMalloc(&d_bad, (size_t)T * sizeof(int32_t)));
     SIM_TRY(hipMemsetAsync(d_bad, 0, (size_t)T * sizeof(int32_t), s));
@@ -1393,6 +1449,12 @@ int ftmpc_simulate_batch_ex(ftmpc_handle* h, int64_t B, int32_t T, double* x, co
                 SIM_TRY(hipMemcpy2DAsync(h->d_u0, NT * sizeof(double), S.U, (size_t)N * NT * sizeof(double), NT * sizeof(double), (size_t)B,
                                          hipMemcpyDeviceToDevice, s));
             }
+        } else if (wl) {         // the reference's two-stage structure: wrench MPC with the hull rows, then allocation
+            rc = wrench_enqueue(h, B, wl->hull_rows, wl->has_set, d_xr + (int64_t)9 * t, 0, uref_traj ? d_ur + (int64_t)6 * t : nullptr, 0,
+                                t > 0 ? h->d_warmG : nullptr);
+            if (rc == FTMPC_OK && d_abad)
+                hipLaunchKernelGGL(ftmpc::ftmpc_count_nonzero_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, B, (const int32_t*)h->d_ast2,
+                                   d_abad + t);
         } else {
             rc = enqueue(h, B, h->d_x0, h->d_ub, h->d_stuck, d_xr + (int64_t)9 * t, 0, uref_traj ? d_ur + (int64_t)6 * t : nullptr, 0,
                          t > 0 ? d_warmB : nullptr, h->d_u0, h->d_U, h->d_status, h->d_iters, s, -1);
@@ -1403,12 +1465,17 @@ int ftmpc_simulate_batch_ex(ftmpc_handle* h, int64_t B, int32_t T, double* x, co
         }
         sp.step = t;
         hipLaunchKernelGGL(ftmpc::ftmpc_plant_step_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, h->dc, sp);
-        hipLaunchKernelGGL(ftmpc::ftmpc_shift_warm_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, B, N, NT, Ufin, d_warmB);
+        if (wl)     // wrench warm start: shifted by one stage, the last stage repeats
+            hipLaunchKernelGGL(ftmpc::ftmpc_shift_warm_kernel, dim3((unsigned)((B * N * 6 + 255) / 256)), dim3(256), 0, s, B, N, 6,
+                               (const double*)h->d_G, h->d_warmG, 1);
+        else
+            hipLaunchKernelGGL(ftmpc::ftmpc_shift_warm_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, B, N, NT, Ufin, d_warmB, 0);
         SIM_TRY(hipGetLastError());
     }
     SIM_TRY(hipMemcpyAsync(x, h->d_x0, (size_t)B * 13 * sizeof(double), hipMemcpyDeviceToHost, s));
     if (u_hist) SIM_TRY(hipMemcpyAsync(u_hist, d_hist, (size_t)T * B * NT * sizeof(double), hipMemcpyDeviceToHost, s));
     if (not_converged) SIM_TRY(hipMemcpyAsync(not_converged, d_bad, (size_t)T * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (d_abad) SIM_TRY(hipMemcpyAsync(wl->alloc_failed, d_abad, (size_t)T * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     SIM_TRY(hipStreamSynchronize(s));
 #undef SIM_TRY
     cleanup();

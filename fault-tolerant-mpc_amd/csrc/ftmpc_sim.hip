@@ -95,12 +95,21 @@ __global__ void __launch_bounds__(64) ftmpc_plant_step_kernel(const DeviceConsts
 }
 
 // warm[b][k] = U[b][k+1] (k < N-1), warm[b][N-1] = 0     (spiraling_mpc.py:327-329)
-__global__ void __launch_bounds__(256) ftmpc_shift_warm_kernel(int64_t B, int N, int NT, const double* U, double* warm) {
+// last stage: zero (the thruster sequences, spiraling_mpc.py:327-329) or, repeat_last != 0, the previous last stage again
+// (the wrench sequences of the two-stage structure)
+__global__ void __launch_bounds__(256) ftmpc_shift_warm_kernel(int64_t B, int N, int NT, const double* U, double* warm, int repeat_last) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t per = (int64_t)N * NT;
     if (i >= B * per) return;
     const int64_t r = i % per;
-    warm[i] = (r < per - NT) ? U[i + NT] : 0.0;
+    warm[i] = (r < per - NT) ? U[i + NT] : (repeat_last ? U[i] : 0.0);
+}
+
+__global__ void __launch_bounds__(256) ftmpc_count_nonzero_kernel(int64_t B, const int32_t* flags, int32_t* count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool bad = i < B && flags[i] != 0;
+    const unsigned long long m = __ballot(bad);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (int32_t)__popcll(m));
 }
 
 

@@ -364,10 +364,11 @@ class BatchedMPC:
 
     # -- closed loop on the device (SimulationEnvironment.run_simulation, batched) ------------
     def simulate(self, x0, ub, stuck, xref_traj, T, uref_traj=None, noise=(1e-3, 1e-3, 1e-3, 1e-3), seed=0,
-                 return_inputs=False, sqp_iters=0, backtracks=8, tol=1e-9):
+                 return_inputs=False, sqp_iters=0, backtracks=8, tol=1e-9, formulation="thruster", hull=None):
         """T closed-loop steps (MPC step -> plant RK4 -> noise -> renormalise) without host round trips.
         sqp_iters > 0: every step solves the nonlinear program by that many major iterations of the line-search SQP
-        (solve_sqp_device) instead of one QP step.
+        (solve_sqp_device) instead of one QP step.  formulation="wrench": every step is the reference's two-stage structure
+        (solve_wrench: generalized-force MPC with the input hull, then allocation); every vehicle's healthy thrusters must span R^6.
         xref_traj: 9 x (T+N) (column t..t+N is the window of step t), uref_traj: 6 x (T+N) or None.
         Returns dict(x [B,13] final states, u [T,B,NT]|None, not_converged [T])."""
         N, NT = self.cfg.N, self.cfg.NT
@@ -388,6 +389,24 @@ class BatchedMPC:
         nz = _f64(noise, 4)
         uh = np.empty((T, B, NT)) if return_inputs else None
         bad = np.zeros(T, np.int32)
+        if formulation == "wrench":
+            if sqp_iters:
+                raise ValueError("the two-stage loop solves one QP per step (sqp_iters must be 0)")
+            from .controllers.tools.input_bounds import hull_tables
+            if hull is None:
+                hull = hull_tables(self.D, ub, stuck)
+            if np.asarray(hull["degenerate"], bool).any():
+                raise ValueError("a vehicle's healthy thrusters do not span R^6: no input hull (use the thruster formulation)")
+            A = np.ascontiguousarray(hull["A"], dtype=np.float64)
+            hs = np.ascontiguousarray(hull["set"], dtype=np.int32)
+            hb = np.ascontiguousarray(hull["b"], dtype=np.float64)
+            abad = np.zeros(T, np.int32)
+            self._check(self.lib.ftmpc_simulate_wrench_batch(self._h, B, int(T), _ptr(x), _ptr(ub), _ptr(stuck), _ptr(A), A.shape[0],
+                                                             _ptr(hs, C.c_int32), _ptr(hb), int(hull["rows"]), _ptr(xr), _ptr(ur), _ptr(nz),
+                                                             C.c_uint64(int(seed)), _ptr(uh), _ptr(bad, C.c_int32), _ptr(abad, C.c_int32)))
+            return dict(x=x, u=uh, not_converged=bad, alloc_failed=abad)
+        if formulation != "thruster":
+            raise ValueError("formulation must be 'thruster' or 'wrench'")
         self._check(self.lib.ftmpc_simulate_batch_ex(self._h, B, int(T), _ptr(x), _ptr(ub), _ptr(stuck), _ptr(xr), _ptr(ur),
                                                      _ptr(nz), C.c_uint64(int(seed)), int(sqp_iters), int(backtracks), float(tol),
                                                      _ptr(uh), _ptr(bad, C.c_int32)))

@@ -297,6 +297,16 @@ int ftmpc_simulate_batch_ex(ftmpc_handle* h, int64_t B, int32_t T, double* x, co
                             const double* xref_traj, const double* uref_traj, const double noise[4], uint64_t seed,
                             int32_t sqp_iters, int32_t backtracks, double tol, double* u_hist, int32_t* not_converged);
 
+/* The same closed loop in the reference's TWO-STAGE structure (ftmpc_solve_wrench_batch at every step: generalized-force MPC with
+ * the input hull -- and the terminal set when the handle's config has one -- then the min-norm allocation): the wrench warm start
+ * is the previous solution shifted by one stage with its last stage repeated.  The hull tables are those of
+ * ftmpc_solve_wrench_batch and stay fixed over the run (the fault pattern does not change inside a run).
+ *   alloc_failed  NULL or [T]: number of instances whose allocation status was not 0 at each step */
+int ftmpc_simulate_wrench_batch(ftmpc_handle* h, int64_t B, int32_t T, double* x, const double* ub, const double* stuck,
+                                const double* hull_A, int32_t n_sets, const int32_t* hull_set, const double* hull_b, int32_t hull_rows,
+                                const double* xref_traj, const double* uref_traj, const double noise[4], uint64_t seed,
+                                double* u_hist, int32_t* not_converged, int32_t* alloc_failed);
+
 /* Per-kernel device timing of the LAST solve call, measured with hipEvents on the launch
  * stream when enabled.  ms[slot] is the duration of kernel slot `slot` (0 when that kernel was
  * not launched), for slot < min(n_slots, FTMPC_KERNEL_SLOTS); ftmpc_kernel_name(slot) is the kernel's name as it appears

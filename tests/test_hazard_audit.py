@@ -66,7 +66,9 @@ def test_checker_sees_deleted_wait_states(device_asm, tmp_path):
     mut = tmp_path / "mut.s"
     mut.write_text("\n".join(out))
     rules = {f["rule"] for s in ch.audit(mut).values() for f in s["asm"]}
-    assert {"permlane_swap", "dpp_vgpr", "trans_use"} <= rules
+    # (whether a v_rsq lands right in front of an asm body depends on the compiler's schedule of the day: the
+    # transcendental rule is pinned by the hand-written sequence below instead)
+    assert {"permlane_swap", "dpp_vgpr"} <= rules
 
 
 def test_rule_table_on_hand_written_sequences(tmp_path):

@@ -55,7 +55,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     __shared__ __attribute__((aligned(16))) float rdg[NSTG * MAX_NT];   // 1 / Dg of thruster a of stage k at k * 16 + a, zero beyond the healthy ones
     __shared__ __attribute__((aligned(16))) float rv16[NSTG * MAX_NT];  // operand of the wrench images, same layout
     __shared__ __attribute__((aligned(16))) double sSl[9 * (NSTG + 2)];
-    __shared__ __attribute__((aligned(16))) float Sblk[NSTG * 36];
+    // stage blocks S_k, rows padded to eight words behind eight zero words: Sblk[8 + 48 k + 8 g + h], words 6 and 7 of a row stay zero
+    __shared__ __attribute__((aligned(16))) float Sblk[8 + NSTG * 48];
     __shared__ __attribute__((aligned(16))) float s_DD[21 * MAX_NT];
     __shared__ __attribute__((aligned(16))) float s_DaT[6 * MAX_NT];
     __shared__ __attribute__((aligned(16))) float mtab[MAX_NT * MAX_NT];
@@ -85,6 +86,32 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         s_pg[lane0] = (unsigned char)g;
         s_ph[lane0] = (unsigned char)(lane0 - g * (g + 1) / 2);
     }
+    // Operand tiles of S for P = S L: lane (q, col) of pair (M, K) holds S[16 K + 4 q + r][16 M + col], r < 4 -- four consecutive
+    // words of one padded block row (S_k is symmetric), or of two when the four rows straddle a stage boundary (then the column's
+    // stage picks the half, the other half reads the zero padding), or the zero words in front.  Word offsets, fixed per launch.
+    constexpr int NPAIR = 3 * NBW - 2;
+    int skoff[NPAIR];
+    {
+        const int li0 = lane0 & 15, lq0 = lane0 >> 4, n0 = 6 * N;
+        int pi = 0;
+#pragma unroll
+        for (int M = 0; M < NBW; ++M) {
+#pragma unroll
+            for (int dk = -1; dk <= 1; ++dk) {
+                const int K = M + dk;
+                if (K < 0 || K >= NBW) continue;
+                const int e1 = 16 * K + 4 * lq0, s1 = (e1 * 43) >> 8, j4 = e1 - 6 * s1;       // e / 6 for e < 128
+                const int e2 = 16 * M + li0, s2 = (e2 * 43) >> 8, a2 = e2 - 6 * s2;
+                int off = 0;
+                if (e2 < n0) {
+                    if (s1 == s2) off = 8 + 48 * s1 + 8 * a2 + j4;
+                    else if (j4 == 4 && s2 == s1 + 1) off = 8 + 48 * s2 + 8 * a2 - 2;
+                }
+                skoff[pi++] = off;
+            }
+        }
+    }
+    for (int i = lane0; i < 8 + NSTG * 48; i += 64) Sblk[i] = 0.f;
     const int qn = *P.qcount;
     int qnext = pull();
     for (;;) {
@@ -604,8 +631,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                     const f32x4 d = dd4[a4], r = r4[a4];
                     sacc += (d.x * r.x + d.y * r.y) + (d.z * r.z + d.w * r.w);
                 }
-                Sblk[k * 36 + g * 6 + hh] = sacc;
-                Sblk[k * 36 + hh * 6 + g] = sacc;
+                Sblk[8 + k * 48 + g * 8 + hh] = sacc;
+                Sblk[8 + k * 48 + hh * 8 + g] = sacc;
             }
             wave_lds_fence();
             STAMP(7);
@@ -616,24 +643,26 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 f32x4 Pt[NTW];
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) Pt[t] = zero4;
+                f32x4 skv[NPAIR];
 #pragma unroll
-                for (int M = 0; M < NBW; ++M) {
-                    const int e2 = 16 * M + li;
-                    const int s2 = s_stg[e2], a2 = s_thr[e2];
+                for (int pi = 0; pi < NPAIR; ++pi) {
+                    const f32x2 lo2 = *reinterpret_cast<const f32x2*>(Sblk + skoff[pi]);
+                    const f32x2 hi2 = *reinterpret_cast<const f32x2*>(Sblk + skoff[pi] + 2);
+                    skv[pi] = f32x4{lo2.x, lo2.y, hi2.x, hi2.y};
+                }
+                {
+                    int pi = 0;
 #pragma unroll
-                    for (int dk = -1; dk <= 1; ++dk) {
-                        const int K = M + dk;
-                        if (K < 0 || K >= NBW) continue;
-                        f32x4 sk;
+                    for (int M = 0; M < NBW; ++M) {
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) {
-                            const int e1 = 16 * K + 4 * lq + rr;
-                            const int s1 = s_stg[e1];
-                            sk[rr] = (s1 != 255 && s1 == s2) ? Sblk[s1 * 36 + s_thr[e1] * 6 + a2] : 0.f;
+                        for (int dk = -1; dk <= 1; ++dk) {
+                            const int K = M + dk;
+                            if (K < 0 || K >= NBW) continue;
+                            const f32x4 sk = skv[pi++];
+#pragma unroll
+                            for (int J = 0; J < NBW; ++J)
+                                if (J <= K && J <= M) Pt[tidx(M, J)] = mm_tn(sk, ltiles.ld(tidx(K, J), lane), Pt[tidx(M, J)]);
                         }
-#pragma unroll
-                        for (int J = 0; J < NBW; ++J)
-                            if (J <= K && J <= M) Pt[tidx(M, J)] = mm_tn(sk, ltiles.ld(tidx(K, J), lane), Pt[tidx(M, J)]);
                     }
                 }
                 STAMP(5);

@@ -2,7 +2,9 @@
 import sys, time
 sys.path.insert(0,'/root/repo/fault-tolerant-mpc_amd'); sys.path.insert(0,'/root/repo')
 import numpy as np, torch, ft_mpc_amd
+ONLY=sys.argv[1:]     # substrings of the names to run (default: all)
 def run(name,B,N,NT,nf,dtype,seed,reps=3,sel="auto"):
+    if ONLY and not any(o in name for o in ONLY): return
     mpc=ft_mpc_amd.BatchedMPC(N=N,NT=NT,dtype=dtype,kernel_select=sel)
     x0,ub,stuck,xref=ft_mpc_amd.make_synthetic_batch(B,N,NT,nf,seed)
     dev=torch.device('cuda:0'); t=lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)

@@ -28,6 +28,7 @@
 #include "ftmpc_solve_ws.hip"
 #include "ftmpc_solve_ws64.hip"
 #include "ftmpc_solve_wsw.hip"
+#include "ftmpc_solve_hull.hip"
 #include "ftmpc_sim.hip"
 #include "ftmpc_alloc.hip"
 
@@ -88,6 +89,10 @@ struct ftmpc_handle {
     int grid_wsw = 0;
     float* wsw_slot = nullptr;
     int64_t wsw_slot_words = 0;
+    // kernel 11 (the generalized-force formulation with hull rows, one wave per instance, fp32): float64 scratch of its reference gradient
+    float* hull_slot = nullptr;
+    int64_t hull_slot_words = 0;
+    int grid_hull = 0;
     bool use_wg = false;
     float* wg_slot = nullptr;
     int grid_wg = 0;
@@ -705,7 +710,7 @@ int ftmpc_destroy(ftmpc_handle* h) {
     void* ptrs[] = {h->rec, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, h->d_uref, h->d_warm, h->d_u0, h->d_U,
                     h->d_status, h->d_iters, h->hs[0], h->hs[1], h->hs[2], h->d_dbgH, h->d_dbgv, h->Hs, h->Ls, h->Eall, h->d_dbgH64, h->d_dbgv64,
                     h->d_atau, h->d_aub, h->d_au, h->d_ast, h->d_ait, h->d_qlist, h->d_qctl, h->d_term, h->d_eN, h->gHs, h->gLs,
-                    h->gEall, h->wg_slot, h->ws_slot, h->ws64_slot, h->wsw_slot, h->d_tcost, h->d_cost, h->d_sqU, h->d_sqQ, h->d_sqT, h->d_sqJ, h->d_sqF, h->d_hullA, h->d_hullb, h->d_warmG, h->d_tau0, h->d_G, h->d_taud, h->d_hullset, h->d_ast2};
+                    h->gEall, h->wg_slot, h->ws_slot, h->ws64_slot, h->wsw_slot, h->hull_slot, h->d_tcost, h->d_cost, h->d_sqU, h->d_sqQ, h->d_sqT, h->d_sqJ, h->d_sqF, h->d_hullA, h->d_hullb, h->d_warmG, h->d_tau0, h->d_G, h->d_taud, h->d_hullset, h->d_ast2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->pin_in.p) (void)hipHostFree(h->pin_in.p);
@@ -1048,6 +1053,14 @@ int ftmpc_solve_batch_device(ftmpc_handle* h, int64_t B, const double* x0, const
                    reinterpret_cast<hipStream_t>(stream), -1);
 }
 
+// The generalized-force formulation runs on kernel 11 (fp32, one wave per instance) when the handle computes in fp32, the problem
+// fits six tiles a side (N <= 16) and eight row slots per lane, and no terminal set is asked for; else on the float64 kernel
+// (dtype FTMPC_DTYPE_F64, kernel_select = FTMPC_KERNEL_DENSE, longer horizons, the terminal set).
+static bool hull_fp32(const ftmpc_handle* h, int32_t hull_rows) {
+    return h->cfg.dtype != FTMPC_DTYPE_F64 && h->cfg.kernel_select != FTMPC_KERNEL_DENSE && !h->cfg.terminal_set && 6 * h->cfg.N <= 96 &&
+           hull_rows <= 32 && (int64_t)h->cfg.N * 32 <= 64 * ftmpc::hullk::nvc_of(6);
+}
+
 // Validation, workspace and hull tables of the generalized-force formulation (shared by the one-step entry and the closed loop).
 static int wrench_prepare(ftmpc_handle* h, int64_t B, const double* hull_A, int32_t n_sets, const int32_t* hull_set, const double* hull_b,
                           int32_t hull_rows) {
@@ -1063,8 +1076,15 @@ static int wrench_prepare(ftmpc_handle* h, int64_t B, const double* hull_A, int3
     int rc;
     HIP_TRY(h, hipSetDevice(h->device));
     if ((rc = ftmpc_reserve(h, B)) != FTMPC_OK) return rc;
-    // per-workgroup slots of the 6N-variable problem (separate from the thruster-space slots of this handle)
-    if (!h->gHs) {
+    if (hull_fp32(h, hull_rows)) {     // kernel 11: one wave per instance, H_w tiles in LDS; only the float64 gradient scratch is global
+        if (!h->hull_slot) {
+            int per = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_hull32_kernel<6>, 64, 0);
+            h->grid_hull = h->num_cu * (per > 0 ? per : 1);
+            h->hull_slot_words = ftmpc::wswk::slot_words(6, N);
+            if ((rc = grow(h, &h->hull_slot, (int64_t)h->grid_hull * h->hull_slot_words)) != FTMPC_OK) return rc;
+        }
+    } else if (!h->gHs) {   // per-workgroup slots of the 6N-variable problem (separate from the thruster-space slots of this handle)
         const int nbg = (6 * N + 15) / 16;
         h->npad_gen = 16 * nbg;
         h->grid_gen = h->num_cu;
@@ -1120,6 +1140,34 @@ static int wrench_enqueue(ftmpc_handle* h, int64_t B, int32_t hull_rows, bool ha
     lp.tcost = h->d_tcost;
     launch_linearize(h, B, (int)((B + 63) / 64), s, lp);
     HIP_TRY(h, hipGetLastError());
+    // the wrench problem stops at mu 1e-10 unless the caller asked otherwise (general rows: see ftmpc_config.mu_stop)
+    DeviceConsts dcg = h->dc;
+    if (!(h->cfg.mu_stop > 0)) dcg.mu_stop = 1e-10;
+    if (hull_fp32(h, hull_rows)) {
+        HIP_TRY(h, hipMemsetAsync(h->d_qctl, 0, 8 * sizeof(int32_t), s));
+        ftmpc::SolveHullParams q;
+        std::memset(&q, 0, sizeof(q));
+        q.base.B = B;
+        q.base.rec = h->rec;
+        q.base.ub = h->d_ub; q.base.stuck = h->d_stuck;
+        q.base.out_u0 = h->d_u0;
+        q.base.status = h->d_status; q.base.iters = h->d_iters;
+        q.base.hscratch = h->hull_slot;
+        q.base.tile_words = h->hull_slot_words;
+        q.base.qhead = h->d_qctl + 7;
+        q.base.dbg_inst = -1;
+        q.base.dbg_H = h->d_dbgH;
+        q.warmG = d_warmG;
+        q.hullA = h->d_hullA;
+        q.hull_set = has_set ? h->d_hullset : nullptr;
+        q.hullb = h->d_hullb;
+        q.hull_rows = hull_rows;
+        q.out_tau0 = h->d_tau0;
+        q.out_G = h->d_G;
+        const int grid = (int)std::min<int64_t>(B, h->grid_hull);
+        hipLaunchKernelGGL(ftmpc::ftmpc_solve_hull32_kernel<6>, dim3(grid), dim3(64), 0, s, dcg, q);
+        HIP_TRY(h, hipGetLastError());
+    } else {
     Solve64Params q;
     std::memset(&q, 0, sizeof(q));
     q.base.B = B;
@@ -1143,15 +1191,13 @@ static int wrench_enqueue(ftmpc_handle* h, int64_t B, int32_t hull_rows, bool ha
     q.eN = h->d_eN;
     q.out_tau0 = h->d_tau0;
     q.out_G = h->d_G;
-    // the wrench problem stops at mu 1e-10 unless the caller asked otherwise (general rows: see ftmpc_config.mu_stop)
-    DeviceConsts dcg = h->dc;
-    if (!(h->cfg.mu_stop > 0)) dcg.mu_stop = 1e-10;
     const int grid = (int)std::min<int64_t>(B, h->grid_gen);
     if (h->cfg.terminal_set)
         hipLaunchKernelGGL((ftmpc::ftmpc_solve_f64_kernel<4, 1, 3>), dim3(grid), dim3(ftmpc::f64k::WG), 0, s, dcg, q);
     else
         hipLaunchKernelGGL((ftmpc::ftmpc_solve_f64_kernel<4, 1, 1>), dim3(grid), dim3(ftmpc::f64k::WG), 0, s, dcg, q);
     HIP_TRY(h, hipGetLastError());
+    }
     // second stage: min-norm allocation of the wrench the healthy thrusters have to produce
     hipLaunchKernelGGL(ftmpc::ftmpc_healthy_wrench_kernel, dim3((unsigned)((B * 6 + 255) / 256)), dim3(256), 0, s, h->dc, B,
                        (const double*)h->d_tau0, (const double*)h->d_stuck, h->d_taud);

@@ -1,0 +1,843 @@
+// ftmpc_solve_hull.hip -- kernel 11: the reference's OWN formulation on ONE WAVE per instance, fp32.
+//
+// The reference's controller (spiraling_mpc.py:87-238) optimises the 6-D generalized force of every stage subject to the
+// input hull A tau_k <= b (:133-137,175-177; input_bounds.py:43-76) and hands tau_0 to the allocator.  Per instance that is
+//     min  1/2 d' H_w d + g_w' d     s.t.  A (ubar_k + d_k) <= b  for every stage k,      tau = ubar + d,  6 N variables
+// with m = N * hull_rows inequality rows (26 per stage for every fault set of the 16-thruster vehicle).  The Newton matrix
+// of the interior-point iteration,  H_w + blockdiag_k (A' diag(z_k / s_k) A),  is H_w plus one 6 x 6 block per stage --
+// the very shape kernel 10 (ftmpc_solve_wsw.hip) assembles its S from -- so this kernel is kernel 10's build (condensing
+// with D_a = I on the matrix cores), kernel 2's register-resident Cholesky and sweeps (chol_reg / solve_reg), and a Mehrotra
+// iteration over the hull rows (eight or eleven rows per lane) instead of the thruster boxes:
+//   * stage blocks  G_k = sum_r w_kr a_r a_r'  in FLOAT64 (products of the fp32 normals are exact there), and the
+//     factorisation itself in float64 on the matrix cores (v_mfma_f64_16x16x4, the same register-resident left-looking scheme
+//     as chol_reg with f64k::potrf_inv16_lds on the diagonal tiles): near the solution the active rows carry weights
+//     z / s ~ 1e7, G is a huge low-rank term that is NOT diagonal, and eliminating through it in fp32 leaves noise of
+//     1e-7 |G| ~ 1 on top of H_w's entries (measured: 4 % of the instances diverge, median error 2e-4 f_max, with an fp32
+//     factorisation).  The box rows of kernels 2 / 10 do not have this problem -- their barrier term is diagonal.
+//     The factor is rounded to fp32 afterwards (its entries are benign) and the sweeps run in fp32 (solve_reg);
+//   * seeds of the factorisation = the -H_w' tiles in LDS (fp32, exact in float64) minus the block entries (diagonal and
+//     first sub-diagonal tiles only), through per-lane offsets fixed per launch;
+//   * C x and C' t as short LDS mat-vecs (6 terms per row, hull_rows terms per wrench component);
+//   * gradient by recurrence through the Newton identity, refreshed once (N <= 16) or at every late iterate by the float64
+//     structured gradient (struct_grad with D_a = I), as kernels 2 / 8 / 10.
+// Same iteration as the float64 kernel's hull mode (ftmpc_solve_f64.hip, MODE 1; oracle/qp_oracle.py:ipm_general is the
+// mirror): start at the hull centre D (ub / 2 + stuck), slacks b - A centre, duals mu0 / s.
+// The terminal set (72 rows on x_N: a rank-9 dense term) stays on the float64 kernel.
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "ftmpc_common.h"
+
+namespace ftmpc {
+
+struct SolveHullParams {
+    SolveParams base;          // rec, ub, stuck, status, iters, hscratch / tile_words (float64 scratch of struct_grad), qhead (cursor)
+    const double* warmG;       // [B*N*6] previous wrench solution (already shifted) or nullptr: linearise about D stuck
+    const double* hullA;       // [n_sets][hull_rows*6] facet normals
+    const int32_t* hull_set;   // [B] table number or nullptr (table 0)
+    const double* hullb;       // [B*hull_rows] facet offsets
+    int32_t hull_rows;
+    double* out_tau0;          // [B*6]
+    double* out_G;             // [B*N*6] or nullptr
+};
+
+namespace hullk {
+__host__ __device__ constexpr int nvc_of(int nbw) { return (16 * nbw / 6) * 32 / 64; }      // hull rows per lane (32 per stage slot)
+
+__device__ __forceinline__ f64x4 mm_tn64(const f64x4& X, const f64x4& Y, f64x4 acc) {      // X' Y: both operands ARE accumulator-layout registers
+    acc = mfma_d(X.x, Y.x, acc);
+    acc = mfma_d(X.y, Y.y, acc);
+    acc = mfma_d(X.z, Y.z, acc);
+    acc = mfma_d(X.w, Y.w, acc);
+    return acc;
+}
+
+// One block column of the float64 register-resident factorisation (chol_reg_col's scheme: T[tidx(I,J)] = L_IJ' for I > J,
+// T[tidx(J,J)] = W_J', Wd[J] = W_J = L_JJ^-1), tiles in the float64 MFMA accumulator layout (lane (q, col): rows q + 4 s of
+// column col).  seed(I, J): the tile of -(M_IJ)' in that layout.  S: 16 x 17 doubles (transpose scratch) + 32 (pivot column | row).
+template <int NB, int J, class Seed>
+__device__ __forceinline__ void chol64_col(const Seed& seed, double* S, int lq, int li, bool& ok, f64x4 (&T)[NB * (NB + 1) / 2], f64x4 (&Wd)[NB]) {
+    const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
+    f64x4 a0 = seed(J, J), a1 = zero;
+    f64x4 bacc[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) bacc[I] = (I > J) ? seed(I, J) : zero;
+#pragma unroll
+    for (int K = 0; K < J; ++K) {
+        if (K & 1) a1 = mm_tn64(T[tidx(J, K)], T[tidx(J, K)], a1);
+        else a0 = mm_tn64(T[tidx(J, K)], T[tidx(J, K)], a0);
+#pragma unroll
+        for (int I = J + 1; I < NB; ++I) bacc[I] = mm_tn64(T[tidx(J, K)], T[tidx(I, K)], bacc[I]);
+    }
+    double c[4], w[4], l[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) c[rr] = -(a0[rr] + a1[rr]);      // M_JJ - sum_K L_JK L_JK'
+    ok = f64k::potrf_inv16_lds(c, S + 272, S + 288, lq, li, w, l) && ok;
+    Wd[J] = f64x4{w[0], w[1], w[2], w[3]};
+    wave_lds_fence();
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) S[(lq + 4 * rr) * 17 + li] = w[rr];
+    wave_lds_fence();
+    f64x4 wt, wtn;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        wt[rr] = S[li * 17 + lq + 4 * rr];
+        wtn[rr] = -wt[rr];
+    }
+    wave_lds_fence();
+    T[tidx(J, J)] = wt;
+#pragma unroll
+    for (int I = J + 1; I < NB; ++I) T[tidx(I, J)] = mm_tn64(wtn, bacc[I], zero);      // L_IJ' = W_J (M_IJ' - sum) = -W_J bacc
+    if constexpr (J + 1 < NB) chol64_col<NB, J + 1, Seed>(seed, S, lq, li, ok, T, Wd);
+}
+
+// sum over the 16 lanes of a DPP row (one row group), float64: the two halves travel separately
+__device__ __forceinline__ double row_sum16_d(double x) {
+#define FTMPC_DPP_ADD_D(ctrl)                                                                                                        \
+    {                                                                                                                                \
+        const unsigned long long b_ = __builtin_bit_cast(unsigned long long, x);                                                     \
+        const unsigned lo_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b_, ctrl, 0xf, 0xf, false);                     \
+        const unsigned hi_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b_ >> 32), ctrl, 0xf, 0xf, false);             \
+        x += __builtin_bit_cast(double, ((unsigned long long)hi_ << 32) | lo_);                                                      \
+    }
+    FTMPC_DPP_ADD_D(0x128)      // row_ror:8
+    FTMPC_DPP_ADD_D(0x124)      // row_ror:4
+    FTMPC_DPP_ADD_D(0x122)      // row_ror:2
+    FTMPC_DPP_ADD_D(0x121)      // row_ror:1
+#undef FTMPC_DPP_ADD_D
+    return x;
+}
+
+// The two sweeps on the float64 factor (solve_reg's right-looking scheme): xv is an LDS vector in natural order, right-hand
+// side in, solution out.  With active rows the step's components along their normals are small differences of larger
+// entries: the slack steps need them to full relative accuracy, which fp32 sweeps do not give.
+template <int NB>
+__device__ __forceinline__ void solve64(const f64x4 (&T)[NB * (NB + 1) / 2], const f64x4 (&Wd)[NB], double* xv, int lq, int li) {
+    f64x4 Y[NB];
+    double p[NB];
+#pragma unroll
+    for (int J = 0; J < NB; ++J) p[J] = 0.0;
+#pragma unroll
+    for (int J = 0; J < NB; ++J) {
+        double r = xv[16 * J + li];
+        if (J > 0) r -= quad_sum_d(p[J]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) Y[J][s] = row_sum16_d(Wd[J][s] * r);
+#pragma unroll
+        for (int I = J + 1; I < NB; ++I) {
+            const f64x4& t = T[tidx(I, J)];
+            p[I] += (t.x * Y[J].x + t.y * Y[J].y) + (t.z * Y[J].z + t.w * Y[J].w);
+        }
+    }
+    wave_lds_fence();
+    f64x4 a[NB];
+#pragma unroll
+    for (int J = 0; J < NB; ++J) a[J] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int J = NB - 1; J >= 0; --J) {
+        f64x4 r = Y[J];
+        if (J < NB - 1) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) r[s] -= row_sum16_d(a[J][s]);
+        }
+        const f64x4& wb = Wd[J];
+        const double xr = quad_sum_d((wb.x * r.x + wb.y * r.y) + (wb.z * r.z + wb.w * r.w));
+        if (lq == 0) xv[16 * J + li] = xr;
+#pragma unroll
+        for (int K = 0; K < J; ++K) a[K] += T[tidx(J, K)] * xr;
+    }
+    wave_lds_fence();
+}
+}  // namespace hullk
+
+template <int NBW>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) ftmpc_solve_hull32_kernel(const DeviceConsts C, const SolveHullParams Q) {
+    using namespace wswk;
+    const SolveParams& P = Q.base;
+    constexpr int NPADW = 16 * NBW;
+    constexpr int NTW = NBW * (NBW + 1) / 2;
+    constexpr int NVW = (NPADW + 63) / 64;          // wrench variables per lane
+    constexpr int NTP = 64 * nvt_of(NBW);           // (the struct_grad instantiation kernel 10 already carries)
+    constexpr int NSTG = NPADW / 6;
+    constexpr int MHP = 32;                         // row slots per stage
+    constexpr int NVC = hullk::nvc_of(NBW);         // hull rows per lane
+    constexpr int BUILD_WORDS = 2 * DENSE_WORDS + 256;
+    static_assert(NTW * 256 >= BUILD_WORDS, "the dense stage-matrix images live in the tile area during the build");
+    static_assert(NSTG * MHP <= 64 * NVC, "row slots");
+    __shared__ __attribute__((aligned(16))) float Htl[NTW * 256];       // -H_w' tiles
+    // float64 scratch: stage record (build: as 2 x REC_STRIDE floats) | stage storage of struct_grad; during a factorisation the
+    // 16 x 17 transpose scratch and the pivot column / row of f64k::potrf_inv16_lds
+    constexpr int F64SCR = (REC_STRIDE + 4) + 9 * (NSTG + 2);
+    static_assert(F64SCR >= 272 + 32, "factorisation scratch");
+    __shared__ __attribute__((aligned(32))) double f64scr[F64SCR];
+    float* const recbuf = reinterpret_cast<float*>(f64scr);
+    double* const sSl = f64scr + REC_STRIDE + 4;
+    __shared__ __attribute__((aligned(16))) float xvp[NPADW], dvp[NPADW];
+    __shared__ __attribute__((aligned(16))) double xv64[NPADW];          // right-hand side / solution of the float64 sweeps
+    __shared__ __attribute__((aligned(16))) float rv[NTP];
+    __shared__ __attribute__((aligned(16))) double Sblk[2 + NSTG * 36];  // [0] = 0 | stage blocks G_k at 2 + 36 k + 6 g + h, float64
+    __shared__ __attribute__((aligned(16))) float s_DaT[6 * MAX_NT];    // identity: the wrench components are the inputs
+    __shared__ __attribute__((aligned(16))) float s_hA[MHP * 6];        // normals, row r at 6 r
+    __shared__ __attribute__((aligned(16))) float s_hAT[6 * MHP];       // the same, component g at 32 g
+    __shared__ __attribute__((aligned(16))) float cw[NSTG * MHP];       // per-row values, row r of stage k at 32 k + r (zero beyond hull_rows)
+    static_assert(NSTG * MHP >= MAX_NT * MAX_NT, "the stage block of H_w (build only) borrows the row-value array");
+    float* const mtab = cw;
+    __shared__ float s_ctr[12];                                          // hull centre D (ub / 2 + stuck) | D stuck
+    __shared__ double s_ctr64[6];                                        // the centre again, unrounded (output stage)
+    __shared__ unsigned char s_stg[NPADW], s_thr[NPADW];
+    __shared__ unsigned char s_pg[24], s_ph[24];
+    float* const dense = Htl;
+
+    const int lane0 = threadIdx.x;
+    const int N = C.N, NT = C.NT;
+    TileStore<NTW> htiles;
+    htiles.p = Htl;
+    htiles.bind(P.hscratch);      // (never used: every tile of this store is in LDS)
+    const float mu_stop = (float)C.mu_stop;
+    double* const sbuf = reinterpret_cast<double*>(P.hscratch + (int64_t)blockIdx.x * P.tile_words);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int MH = Q.hull_rows;
+
+    auto pull = [&]() {
+        int i = 0;
+        if (lane0 == 0) i = atomicAdd(P.qhead, 1);
+        return i;
+    };
+    if (lane0 < 21) {
+        int g = 0;
+        while ((g + 1) * (g + 2) / 2 <= lane0) ++g;
+        s_pg[lane0] = (unsigned char)g;
+        s_ph[lane0] = (unsigned char)(lane0 - g * (g + 1) / 2);
+    }
+    // Offsets (doubles) of the stage-block entries this lane subtracts from the seeds of the diagonal tile (I, I) and of the tile
+    // (I, I - 1), element [row q + 4 s][col] of the stored -(M_IJ)' tile = -M[16 I + col][16 J + row]; 0 = the zero word.
+    int goff_d[NBW][4], goff_s[NBW][4];
+    {
+        const int li0 = lane0 & 15, lq0 = lane0 >> 4, n0 = 6 * N;
+#pragma unroll
+        for (int I = 0; I < NBW; ++I) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int e1 = 16 * I + li0, s1 = (e1 * 43) >> 8;       // e / 6 for e < 128
+                const int e2 = 16 * I + lq0 + 4 * rr, s2 = (e2 * 43) >> 8;
+                goff_d[I][rr] = (e1 < n0 && e2 < n0 && s1 == s2) ? 2 + 36 * s1 + 6 * (e1 - 6 * s1) + (e2 - 6 * s2) : 0;
+                const int e3 = 16 * (I - 1) + lq0 + 4 * rr, s3 = (e3 * 43) >> 8;
+                goff_s[I][rr] = (I > 0 && e1 < n0 && s1 == s3) ? 2 + 36 * s1 + 6 * (e1 - 6 * s1) + (e3 - 6 * s3) : 0;
+            }
+        }
+    }
+    for (int i = lane0; i < 2 + NSTG * 36; i += 64) Sblk[i] = 0.0;
+    for (int i = lane0; i < 6 * MAX_NT; i += 64) s_DaT[i] = ((i / MAX_NT) == (i % MAX_NT)) ? 1.f : 0.f;
+    constexpr int na = 6;
+    const int n = N * na;
+    const int nb = (n + 15) >> 4;
+    for (int e = lane0; e < NPADW; e += 64) {
+        const int s = e / na;
+        s_stg[e] = (unsigned char)(e < n ? s : 255);
+        s_thr[e] = (unsigned char)(e < n ? e - s * na : 255);
+    }
+    const int mhull = N * MH;
+    const int64_t qn = P.B;
+    int qnext = pull();
+    for (;;) {
+        const int qi = __builtin_amdgcn_readfirstlane(qnext);
+        if (qi >= qn) break;
+        const int64_t inst = qi;
+        qnext = pull();
+        STAMP_DECL;
+        STAMP_START();
+        wave_lds_fence();
+        int lane = lane_now();
+        int li = lane & 15, lq = lane >> 4;
+        // ---------------- prologue ----------------
+        if (nb > NBW || MH > MHP || MH < 1) {       // (the host routes such shapes to the float64 kernel)
+            if (lane == 0) {
+                if (P.status) P.status[inst] = 2;
+                if (P.iters) P.iters[inst] = 0;
+            }
+            continue;
+        }
+        if (lane < 12) {      // hull centre (the start point: strictly inside every row) and the thrusters-off wrench (cold linearisation point)
+            const int g = lane % 6;
+            double acc = 0.0;
+            for (int i = 0; i < NT; ++i) acc += C.D[g * MAX_NT + i] * ((lane < 6 ? 0.5 * P.ub[inst * NT + i] : 0.0) + P.stuck[inst * NT + i]);
+            s_ctr[lane] = (float)acc;
+            if (lane < 6) s_ctr64[lane] = acc;
+        }
+        {
+            const int64_t set = Q.hull_set ? Q.hull_set[inst] : 0;
+            for (int i = lane; i < MHP * 6; i += 64) {
+                const int r = i / 6, g = i - 6 * r;
+                const float a = (r < MH) ? (float)Q.hullA[set * MH * 6 + i] : 0.f;
+                s_hA[i] = a;
+                s_hAT[g * MHP + r] = a;
+            }
+            for (int t = lane; t < MAX_NT * MAX_NT; t += 64) {     // stage block of H_w: 2 R on the diagonal (build only: in the row-value array)
+                const int a1 = t >> 4, a2 = t & (MAX_NT - 1);
+                float r = 0.f;
+#pragma unroll
+                for (int g = 0; g < 6; ++g) r = (a1 == g) ? (float)C.R[g] : r;
+                mtab[t] = (a1 == a2 && a1 < 6) ? 2.f * r : 0.f;
+            }
+        }
+        wave_lds_fence();
+        typedef double f64x4_t __attribute__((ext_vector_type(4)));
+        const double* recg = reinterpret_cast<const double*>(P.rec) + inst * (int64_t)N * REC_STRIDE;
+        f64x4_t pre64 = {0.0, 0.0, 0.0, 0.0};
+        if (lane < REC_STRIDE / 4) pre64 = *reinterpret_cast<const f64x4_t*>(recg + 4 * lane);
+        int dpos[4] = {DENSE_DUMP, DENSE_DUMP, DENSE_DUMP, DENSE_DUMP};
+        {
+            int w0 = 4 * lane;
+            asm volatile("" : "+v"(w0));
+            if (lane < REC_STRIDE / 4) {
+                const ushort4 t = *reinterpret_cast<const ushort4*>(&k_dense_pos.v[w0]);
+                dpos[0] = t.x;
+                dpos[1] = t.y;
+                dpos[2] = t.z;
+                dpos[3] = t.w;
+            }
+        }
+        for (int i = lane; i < BUILD_WORDS; i += 64) dense[i] = 0.f;
+        wave_lds_fence();
+        if (lane < 6) {
+            const int a = lane % 3, isv = lane / 3;
+#pragma unroll
+            for (int bsel = 0; bsel < 2; ++bsel) {
+                float* dd = dense + bsel * DENSE_WORDS;
+                dd[16 * tile_row(3 * isv + a) + tile_row(3 * isv + a)] = 1.f;
+                if (!isv) dd[16 * tile_row(a) + tile_row(3 + a)] = (float)C.dt;
+            }
+        }
+        for (int i = lane; i < 81; i += 64) {
+            const int r = i / 9, c = i - 9 * r;
+            if (c >= r) dense[2 * DENSE_WORDS + 16 * tile_row(r) + tile_row(c)] = (float)C.LPt[i];
+        }
+        wave_lds_fence();
+        const f32x4 lp4 = lds4(dense + 2 * DENSE_WORDS + 16 * li + 4 * lq);
+
+        // this lane's wrench variables e = v * 64 + lane = (stage, component): linearisation point and start point
+        bool wvalid[NVW];
+        float ubar[NVW], d[NVW], grd[NVW];
+#pragma unroll
+        for (int v = 0; v < NVW; ++v) {
+            const int e = v * 64 + lane;
+            wvalid[v] = e < n;
+            const int k = (e * 10923) >> 16, g = e - 6 * k;
+            ubar[v] = 0.f;
+            d[v] = grd[v] = 0.f;
+            if (wvalid[v]) {
+                ubar[v] = Q.warmG ? (float)Q.warmG[inst * n + e] : s_ctr[6 + g];
+                d[v] = s_ctr[g] - ubar[v];
+            }
+        }
+        float gw[NVW];      // gradient at the linearisation point, column e = v * 64 + lane
+        {
+            // ---------------- build: kernel 10's (kernel 2's stage loop with D_a = I) ----------------
+            f32x4 G[NBW];
+            float gpart[NBW];
+#pragma unroll
+            for (int X = 0; X < NBW; ++X) {
+                G[X] = zero4;
+                gpart[X] = 0.f;
+            }
+            float esc[3];
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) esc[s3] = (lq < 3) ? 2.f * (float)C.Q[3 * s3 + lq] : 0.f;
+            f32x4 acc[NTW];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) acc[t] = zero4;
+            auto finish_tile = [&](int I, int J) {
+                f32x4 h = acc[(I * (I + 1)) / 2 + J];
+                if (J >= I - 1) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int e1 = (I == J) ? 16 * I + 4 * lq + rr : 16 * I + li;
+                        const int e2 = (I == J) ? 16 * J + li : 16 * J + 4 * lq + rr;
+                        const int s1 = s_stg[e1], a1 = s_thr[e1];
+                        const int s2 = s_stg[e2], a2 = s_thr[e2];
+                        float add = (s1 != 255 && s1 == s2) ? mtab[((a1 & (MAX_NT - 1)) << 4) | (a2 & (MAX_NT - 1))] : 0.f;
+                        if (s1 == 255 && e1 == e2) add = 1.f;
+                        h[rr] += add;
+                    }
+                }
+                htiles.st((I * (I + 1)) / 2 + J, lane, -h);
+            };
+            STAMP(0);
+            auto stage = [&](int k, auto TERM) {
+                constexpr bool terminal = decltype(TERM)::value;
+                const int lane = lane_now();
+                const int li = lane & 15, lq = lane >> 4;
+                float* rb = recbuf + (k & 1) * REC_STRIDE;
+                float* dd = dense + (k & 1) * DENSE_WORDS;
+                if (lane < REC_STRIDE / 4) {
+                    const f32x4 pre = {(float)pre64.x, (float)pre64.y, (float)pre64.z, (float)pre64.w};
+                    *reinterpret_cast<f32x4*>(rb + 4 * lane) = pre;
+                    dd[dpos[0]] = pre.x;
+                    dd[dpos[1]] = pre.y;
+                    dd[dpos[2]] = pre.z;
+                    dd[dpos[3]] = pre.w;
+                    if (!terminal) pre64 = *reinterpret_cast<const f64x4_t*>(recg + (k + 1) * REC_STRIDE + 4 * lane);
+                }
+                wave_lds_fence();
+                const f32x4 a4 = lds4(dd + 16 * li + 4 * lq);
+                const float b0 = dd[256 + 8 * li + lq], b1 = dd[256 + 8 * li + 4 + lq];
+                float we[3];
+#pragma unroll
+                for (int s3 = 0; s3 < 3; ++s3) we[s3] = (lq < 3) ? rb[REC_WE + 3 * s3 + lq] : 0.f;
+                const float rut0 = rb[REC_RUT + lq], rut1 = (lq < 2) ? rb[REC_RUT + 4 + lq] : 0.f;
+                const int Imax = ((k + 1) * na - 1) >> 4;
+                const int Xnew = (k * na) >> 4;
+                float E[NBW][3];
+#pragma unroll
+                for (int X = 0; X < NBW; ++X)
+                    if (X <= Imax) {
+                        f32x4 o = zero4;
+                        if (X >= Xnew) {      // the columns of stage k: column a takes wrench component a
+                            const int ax = *(lds_vu8*)&s_thr[16 * X + li];
+                            const bool mine = (*(lds_vu8*)&s_stg[16 * X + li] == k);
+                            const float d0 = (mine && ax == lq) ? 1.f : 0.f;
+                            const float d1 = (mine && lq < 2 && ax == 4 + lq) ? 1.f : 0.f;
+                            o = mfma4(b0, d0, o);
+                            o = mfma4(b1, d1, o);
+                            gpart[X] += d0 * rut0 + d1 * rut1;
+                        }
+                        o = mfma4(a4.x, G[X].x, o);
+                        o = mfma4(a4.y, G[X].y, o);
+                        o = mfma4(a4.z, G[X].z, o);
+                        o = mfma4(a4.w, G[X].w, o);
+                        G[X] = o;
+                    }
+#pragma unroll
+                for (int X = 0; X < NBW; ++X)
+                    if (X <= Imax) {
+                        gpart[X] += we[0] * G[X].x + we[1] * G[X].y + we[2] * G[X].z;
+                        if constexpr (terminal) {
+                            f32x4 o = zero4;
+                            o = mfma4(lp4.x, G[X].x, o);
+                            o = mfma4(lp4.y, G[X].y, o);
+                            o = mfma4(lp4.z, G[X].z, o);
+                            o = mfma4(lp4.w, G[X].w, o);
+                            E[X][0] = o.x;
+                            E[X][1] = o.y;
+                            E[X][2] = o.z;
+                        }
+                    }
+                STAMP(1);
+#pragma unroll
+                for (int I = 0; I < NBW; ++I)
+                    if (I <= Imax) {
+                        float eI[3] = {0.f, 0.f, 0.f};
+                        if constexpr (!terminal) {   // E_J' E_I = G_J' (2 Q) G_I
+                            eI[0] = esc[0] * G[I].x;
+                            eI[1] = esc[1] * G[I].y;
+                            eI[2] = esc[2] * G[I].z;
+                        }
+#pragma unroll
+                        for (int J = 0; J <= I; ++J) {
+                            if constexpr (!terminal) {
+                                acc[(I * (I + 1)) / 2 + J] = mfma4(G[J].x, eI[0], acc[(I * (I + 1)) / 2 + J]);
+                                acc[(I * (I + 1)) / 2 + J] = mfma4(G[J].y, eI[1], acc[(I * (I + 1)) / 2 + J]);
+                                acc[(I * (I + 1)) / 2 + J] = mfma4(G[J].z, eI[2], acc[(I * (I + 1)) / 2 + J]);
+                            } else {
+#pragma unroll
+                                for (int s3 = 0; s3 < 3; ++s3) acc[(I * (I + 1)) / 2 + J] = mfma4(E[J][s3], E[I][s3], acc[(I * (I + 1)) / 2 + J]);
+                                finish_tile(I, J);
+                            }
+                        }
+                    }
+                STAMP(2);
+            };
+            for (int k = 0; k + 1 < N; ++k) stage(k, std::false_type{});
+            stage(N - 1, std::true_type{});
+#pragma unroll
+            for (int I = 0; I < NBW; ++I)
+                if (I > ((N * na - 1) >> 4)) {
+#pragma unroll
+                    for (int J = 0; J <= I; ++J) finish_tile(I, J);
+                }
+            float qs[NBW];
+#pragma unroll
+            for (int X = 0; X < NBW; ++X) qs[X] = quad_sum(gpart[X]);
+#pragma unroll
+            for (int v = 0; v < NVW; ++v) {
+                float t = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (4 * v + j < NBW) t = (lq == j) ? qs[4 * v + j] : t;
+                const int e = v * 64 + lane;
+                gw[v] = (e < n) ? 2.f * t : 0.f;
+            }
+        }
+        wave_lds_fence();   // the dense images in the tile area are dead from here: Htl holds the -H_w' tiles
+        for (int i = lane_now(); i < NSTG * MHP; i += 64) cw[i] = 0.f;      // (was the stage block of H_w during the build)
+
+        // y = H_w x for a vector held NVW per lane, from the -H_w' tiles (one read serves both triangles: ftmpc_solve.hip, start
+        // gradient).  Also the gradient's update: with row weights z / s ~ 1e7 the Newton identity H dd = rhs - C' (w . C dd)
+        // is a difference of huge numbers in fp32, the product itself is not.
+        auto h_times = [&](const float (&x)[NVW], float (&y)[NVW]) {
+            const int lane = lane_now();
+            const int li = lane & 15, lq = lane >> 4;
+            wave_lds_fence();
+#pragma unroll
+            for (int v = 0; v < NVW; ++v) {
+                const int e = v * 64 + lane;
+                if (e < NPADW) dvp[e] = x[v];
+            }
+            wave_lds_fence();
+            f32x2 arow[NBW];
+            f32x4 acol[NBW];
+#pragma unroll
+            for (int I = 0; I < NBW; ++I) {
+                arow[I] = f32x2{0.f, 0.f};
+                acol[I] = zero4;
+            }
+#pragma unroll
+            for (int I = 0; I < NBW; ++I) {
+                const float dI = dvp[16 * I + li];
+#pragma unroll
+                for (int J = 0; J <= I; ++J) {
+                    const f32x4 t4 = htiles.ld(tidx(I, J), lane);
+                    const f32x4 d4 = lds4(dvp + 16 * J + 4 * lq);
+                    arow[I] += f32x2{t4.x, t4.y} * f32x2{d4.x, d4.y};
+                    arow[I] += f32x2{t4.z, t4.w} * f32x2{d4.z, d4.w};
+                    if (J < I) acol[J] += t4 * dI;
+                }
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int J = 0; J < NBW; ++J) {
+                float c0 = acol[J].x, c1 = acol[J].y, c2 = acol[J].z, c3 = acol[J].w;
+                row_sum16x4(c0, c1, c2, c3);
+                if (li == 0) *reinterpret_cast<f32x4*>(xvp + 16 * J + 4 * lq) = f32x4{c0, c1, c2, c3};
+            }
+            wave_lds_fence();
+            float yrow[NBW];
+#pragma unroll
+            for (int I = 0; I < NBW; ++I) yrow[I] = quad_sum(arow[I].x + arow[I].y);
+#pragma unroll
+            for (int v = 0; v < NVW; ++v) {
+                float t = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (4 * v + j < NBW) t = (lq == j) ? yrow[4 * v + j] : t;
+                const int e = v * 64 + lane;
+                y[v] = (e < n) ? -(t + xvp[e]) : 0.f;      // the tiles hold -H_w
+            }
+            wave_lds_fence();
+        };
+        // ---------------- gradient at the start point: g_w + H_w d ----------------
+        {
+            float y[NVW];
+            h_times(d, y);
+#pragma unroll
+            for (int v = 0; v < NVW; ++v) grd[v] = wvalid[v] ? y[v] + gw[v] : 0.f;
+        }
+        STAMP(3);
+
+        // ---------------- the hull rows of this lane: row c = v * 64 + lane = (stage hk, facet hr) ----------------
+        bool hv[NVC];
+        int hcw[NVC], hxs[NVC], hra[NVC];      // word offsets: cw slot, first component of the stage in a natural vector, first component of the normal
+        float sh[NVC], zh[NVC];
+        {
+            const float rmh = 1.0f / (float)MH;
+            float smax = 0.f, gmax = 0.f;
+#pragma unroll
+            for (int v = 0; v < NVC; ++v) {
+                const int c = v * 64 + lane;
+                hv[v] = c < mhull;
+                int k = (int)(((float)c + 0.5f) * rmh);
+                k = (k * MH > c) ? k - 1 : k;
+                k = ((k + 1) * MH <= c) ? k + 1 : k;
+                const int r = c - k * MH;
+                hcw[v] = hv[v] ? k * MHP + r : 0;
+                hxs[v] = hv[v] ? 6 * k : 0;
+                hra[v] = hv[v] ? 6 * r : 0;
+                sh[v] = 1.f;
+                zh[v] = 0.f;
+                if (hv[v]) {      // b - A centre: the same for every stage
+                    float a = (float)Q.hullb[inst * MH + r];
+#pragma unroll
+                    for (int g = 0; g < 6; ++g) a -= s_hA[6 * r + g] * s_ctr[g];
+                    sh[v] = a;
+                    smax = fmaxf(smax, a);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < NVW; ++v) gmax = fmaxf(gmax, wvalid[v] ? fabsf(grd[v]) : 0.f);
+            gmax = wave_max(gmax);
+            smax = wave_max(smax);
+            const float mu0 = fmaxf(0.02f * gmax * smax, 1e-3f);
+#pragma unroll
+            for (int v = 0; v < NVC; ++v) zh[v] = hv[v] ? mu0 / sh[v] : 0.f;
+        }
+        // rows of C x for the float64 natural-order LDS vector (the slack steps: small for active rows, by cancellation)
+        auto rows_Cx = [&](const double* xs, float (&ch)[NVC]) {
+#pragma unroll
+            for (int v = 0; v < NVC; ++v) {
+                const f32x2 a0 = *reinterpret_cast<const f32x2*>(s_hA + hra[v]), a1 = *reinterpret_cast<const f32x2*>(s_hA + hra[v] + 2),
+                            a2 = *reinterpret_cast<const f32x2*>(s_hA + hra[v] + 4);
+                const double* x = xs + hxs[v];
+                const double s2 = ((double)a0.x * x[0] + (double)a0.y * x[1]) + ((double)a1.x * x[2] + (double)a1.y * x[3]) +
+                                  ((double)a2.x * x[4] + (double)a2.y * x[5]);
+                ch[v] = hv[v] ? (float)s2 : 0.f;
+            }
+        };
+        // C' t for per-row values t: element e = v * 64 + lane of the result
+        auto cols_Ct = [&](const float (&th)[NVC], float (&out)[NVW]) {
+            const int lane = lane_now();
+            wave_lds_fence();
+#pragma unroll
+            for (int v = 0; v < NVC; ++v)
+                if (hv[v]) cw[hcw[v]] = th[v];
+            wave_lds_fence();
+#pragma unroll
+            for (int v = 0; v < NVW; ++v) {
+                const int e = v * 64 + lane;
+                float s = 0.f;
+                if (e < n) {
+                    const int k = (e * 10923) >> 16, g = e - 6 * k;
+                    const f32x4* a4 = reinterpret_cast<const f32x4*>(s_hAT + g * MHP);
+                    const f32x4* t4 = reinterpret_cast<const f32x4*>(cw + k * MHP);
+#pragma unroll
+                    for (int r4 = 0; r4 < MHP / 4; ++r4) {
+                        const f32x4 a = a4[r4], t = t4[r4];
+                        s += (a.x * t.x + a.y * t.y) + (a.z * t.z + a.w * t.w);
+                    }
+                }
+                out[v] = s;
+            }
+        };
+        auto to_lds = [&](const float (&x)[NVW], double* dst) {
+            const int lane = lane_now();
+            wave_lds_fence();
+#pragma unroll
+            for (int v = 0; v < NVW; ++v) {
+                const int e = v * 64 + lane;
+                if (e < NPADW) dst[e] = wvalid[v] ? (double)x[v] : 0.0;
+            }
+            wave_lds_fence();
+        };
+        auto from_lds = [&](const double* src, float (&x)[NVW]) {
+            const int lane = lane_now();
+#pragma unroll
+            for (int v = 0; v < NVW; ++v) {
+                const int e = v * 64 + lane;
+                x[v] = (e < n) ? (float)src[e] : 0.f;
+            }
+        };
+        STAMP(4);
+
+        // ---------------- interior-point iterations over the hull rows ----------------
+        f64x4 T64[NTW], W64[NBW];
+        int status = 1, nit = 0;
+#ifndef FTMPC_HULL_REFRESH_ALL
+#define FTMPC_HULL_REFRESH_ALL 0
+#endif
+        int refines_left = (C.mu_refine > 0.0) ? ((NBW > 6 || FTMPC_HULL_REFRESH_ALL) ? C.max_iters + 1 : 1) : 0;
+        float mu_last = 3.0e38f;
+        const float inv_m = 1.0f / (float)mhull;
+        for (int it = 0; it <= C.max_iters; ++it) {
+            wave_lds_fence();
+            lane = lane_now();
+            li = lane & 15;
+            lq = lane >> 4;
+            const bool do_ref = __builtin_amdgcn_readfirstlane(refines_left > 0 && mu_last < (float)C.mu_refine);
+            if (do_ref) {   // float64, structured, at the current iterate
+#pragma unroll
+                for (int v = 0; v < NVW; ++v) rv[v * 64 + lane] = wvalid[v] ? d[v] : 0.f;
+                wave_lds_fence();
+                struct_grad<lds_f64*, NTP>(C, (glb_cf64*)recg, (lds_f64*)reinterpret_cast<double*>(recbuf), (lds_cf32*)s_DaT, (lds_cf32*)rv,
+                                          (lds_f64*)sSl, (glb_f64*)sbuf, 6, lane);
+#pragma unroll
+                for (int v = 0; v < NVW; ++v) grd[v] = wvalid[v] ? (float)sbuf[v * 64 + lane] : 0.f;
+                --refines_left;
+                STAMP(8);
+            }
+            float csum = 0.f;
+#pragma unroll
+            for (int v = 0; v < NVC; ++v) csum += hv[v] ? sh[v] * zh[v] : 0.f;
+            const float mu = wave_sum(csum) * inv_m;
+            mu_last = mu;
+            if (__builtin_amdgcn_readfirstlane(!(mu >= mu_stop))) {
+                status = (mu == mu) ? 0 : 2;
+                break;
+            }
+            if (it == C.max_iters) break;
+            ++nit;
+            float rsh[NVC], wh[NVC];
+#pragma unroll
+            for (int v = 0; v < NVC; ++v) {
+                rsh[v] = __builtin_amdgcn_rcpf(sh[v]);
+                wh[v] = hv[v] ? zh[v] * rsh[v] : 0.f;
+            }
+            // stage blocks G_k = sum_r w_kr a_r a_r'
+            wave_lds_fence();
+#pragma unroll
+            for (int v = 0; v < NVC; ++v)
+                if (hv[v]) cw[hcw[v]] = wh[v];
+            wave_lds_fence();
+            for (int idx = lane; idx < N * 21; idx += 64) {      // float64: the products of the fp32 normals are exact, G keeps its rank
+                const int k = (idx * 3121) >> 16, p = idx - 21 * k;      // idx / 21 for idx < 5000
+                const int g = s_pg[p], hh = s_ph[p];
+                const f32x4* ag4 = reinterpret_cast<const f32x4*>(s_hAT + g * MHP);
+                const f32x4* ah4 = reinterpret_cast<const f32x4*>(s_hAT + hh * MHP);
+                const f32x4* w4 = reinterpret_cast<const f32x4*>(cw + k * MHP);
+                double sacc = 0.0;
+#pragma unroll
+                for (int r4 = 0; r4 < MHP / 4; ++r4) {
+                    const f32x4 a = ag4[r4], b = ah4[r4], w = w4[r4];
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) sacc += (double)w[c4] * ((double)a[c4] * (double)b[c4]);
+                }
+                Sblk[2 + k * 36 + g * 6 + hh] = sacc;
+                Sblk[2 + k * 36 + hh * 6 + g] = sacc;
+            }
+            wave_lds_fence();
+            STAMP(7);
+            {
+                // float64 factorisation of H_w + G: seeds -(H_w + G)' read in the float64 accumulator layout (rows q + 4 s)
+                const float* hb = Htl + 4 * li + lq;
+                auto seed = [&](int I, int J) -> f64x4 {
+                    const float* t = hb + tidx(I, J) * 256;
+                    f64x4 r = {(double)t[0], (double)t[64], (double)t[128], (double)t[192]};
+                    if (J == I) r -= f64x4{Sblk[goff_d[I][0]], Sblk[goff_d[I][1]], Sblk[goff_d[I][2]], Sblk[goff_d[I][3]]};
+                    if (J == I - 1) r -= f64x4{Sblk[goff_s[I][0]], Sblk[goff_s[I][1]], Sblk[goff_s[I][2]], Sblk[goff_s[I][3]]};
+                    return r;
+                };
+                bool ok = true;
+                hullk::chol64_col<NBW, 0>(seed, f64scr, lq, li, ok, T64, W64);
+                STAMP(5);
+                if (__builtin_amdgcn_readfirstlane(!__all(ok))) {     // (float64 too runs out near mu ~ 1e-12 ... 1e-13)
+                    status = (mu < 1e-7f) ? 0 : 2;
+                    --nit;
+                    break;
+                }
+            }
+            STAMP(9);
+            // predictor: (H_w + G) da = -grd
+            float rhs[NVW], dd[NVW];
+#pragma unroll
+            for (int v = 0; v < NVW; ++v) rhs[v] = -grd[v];
+            to_lds(rhs, xv64);
+            hullk::solve64<NBW>(T64, W64, xv64, lq, li);
+            float ch[NVC];
+            rows_Cx(xv64, ch);
+            // ds = -C da,  dz = -z - z ds / s
+            float dzh_a[NVC], ap = 1.f, ad = 1.f;
+#pragma unroll
+            for (int v = 0; v < NVC; ++v) {
+                dzh_a[v] = 0.f;
+                if (hv[v]) {
+                    dzh_a[v] = -zh[v] + zh[v] * ch[v] * rsh[v];
+                    if (ch[v] > 0.f) ap = fminf(ap, sh[v] * __builtin_amdgcn_rcpf(ch[v]));
+                    if (dzh_a[v] < 0.f) ad = fminf(ad, -zh[v] * __builtin_amdgcn_rcpf(dzh_a[v]));
+                }
+            }
+            ap = wave_min(ap);
+            ad = wave_min(ad);
+            csum = 0.f;
+#pragma unroll
+            for (int v = 0; v < NVC; ++v) csum += hv[v] ? (sh[v] - ap * ch[v]) * (zh[v] + ad * dzh_a[v]) : 0.f;
+            const float mu_aff = wave_sum(csum) * inv_m;
+            float sigma = mu_aff / mu;
+            sigma = fminf(fmaxf(sigma * sigma * sigma, 0.f), 1.f);
+            // corrector: rc = s z + ds_a dz_a - sigma mu,  t = -z + rc / s,  rhs = -grd + C' t
+            float rch[NVC], th[NVC];
+#pragma unroll
+            for (int v = 0; v < NVC; ++v) {
+                rch[v] = th[v] = 0.f;
+                if (hv[v]) {
+                    rch[v] = sh[v] * zh[v] - ch[v] * dzh_a[v] - sigma * mu;
+                    th[v] = (-ch[v] * dzh_a[v] - sigma * mu) * rsh[v];      // -z + rc / s without the cancellation
+                }
+            }
+            float ct[NVW];
+            cols_Ct(th, ct);
+#pragma unroll
+            for (int v = 0; v < NVW; ++v) rhs[v] = -grd[v] + ct[v];
+            to_lds(rhs, xv64);
+            hullk::solve64<NBW>(T64, W64, xv64, lq, li);
+            from_lds(xv64, dd);
+            rows_Cx(xv64, ch);
+            float dzh[NVC];
+            ap = 1e30f;
+            ad = 1e30f;
+#pragma unroll
+            for (int v = 0; v < NVC; ++v) {
+                dzh[v] = 0.f;
+                if (hv[v]) {
+                    dzh[v] = (-rch[v] + zh[v] * ch[v]) * rsh[v];
+                    if (ch[v] > 0.f) ap = fminf(ap, sh[v] * __builtin_amdgcn_rcpf(ch[v]));
+                    if (dzh[v] < 0.f) ad = fminf(ad, -zh[v] * __builtin_amdgcn_rcpf(dzh[v]));
+                }
+            }
+            ap = fminf(1.f, 0.9995f * wave_min(ap));
+            ad = fminf(1.f, 0.9995f * wave_min(ad));
+            float hdd[NVW];
+            h_times(dd, hdd);
+#pragma unroll
+            for (int v = 0; v < NVW; ++v)
+                if (wvalid[v]) {
+                    grd[v] += ap * hdd[v];
+                    d[v] += ap * dd[v];
+                }
+#pragma unroll
+            for (int v = 0; v < NVC; ++v)
+                if (hv[v]) {
+                    sh[v] -= ap * ch[v];
+                    zh[v] += ad * dzh[v];
+                }
+            STAMP(10);
+        }
+        // ---------------- outputs ----------------
+        lane = lane_now();
+        wave_lds_fence();
+#pragma unroll
+        for (int v = 0; v < NVW; ++v) {
+            const int e = v * 64 + lane;
+            if (e < n) {
+                const double tau = (status == 2) ? (double)ubar[v] : (double)ubar[v] + (double)d[v];
+                if (e < 6) xv64[e] = tau;
+                if (Q.out_G) Q.out_G[inst * n + e] = tau;
+            }
+        }
+        wave_lds_fence();
+        {
+            // The allocator takes tau_0 next and needs it INSIDE the true hull (float64 normals and offsets): an active facet is
+            // met to fp32 accuracy only, a few 1e-7 outside as often as inside.  Pull tau_0 towards the centre by the smallest
+            // factor that leaves every facet a relative margin of 1e-8 (of the order of 1e-6: far inside the specification).
+            float eps = 0.f;
+            if (lane < MH) {
+                const int64_t set = Q.hull_set ? Q.hull_set[inst] : 0;
+                const double* a = Q.hullA + (set * MH + lane) * 6;
+                const double b = Q.hullb[inst * MH + lane];
+                double s0 = b, st = b;
+#pragma unroll
+                for (int g = 0; g < 6; ++g) {
+                    s0 -= a[g] * s_ctr64[g];
+                    st -= a[g] * xv64[g];
+                }
+                const double need = (1e-8 * s0 - st) / (s0 - st);      // s0 > 0; st < s0 whenever the row matters
+                eps = (st < 1e-8 * s0 && s0 > st) ? (float)need * 1.0001f : 0.f;
+            }
+            eps = wave_max(eps);
+            if (lane < 6) Q.out_tau0[inst * 6 + lane] = s_ctr64[lane] + (1.0 - (double)eps) * (xv64[lane] - s_ctr64[lane]);
+        }
+        if (lane == 0) {
+            if (P.status) P.status[inst] = status;
+            if (P.iters) P.iters[inst] = nit;
+        }
+        STAMP(11);
+#ifdef FTMPC_STAMPS
+        if (lane == 0 && inst < 4096) {
+            unsigned long long* sb = reinterpret_cast<unsigned long long*>(P.dbg_H) + inst * 12;
+            for (int i = 0; i < 12; ++i) sb[i] = st_acc[i];
+        }
+#endif
+    }
+}
+
+template __global__ void ftmpc_solve_hull32_kernel<6>(const DeviceConsts, const SolveHullParams);
+
+}  // namespace ftmpc

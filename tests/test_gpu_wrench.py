@@ -211,3 +211,69 @@ def test_general_constraint_forms_against_golden(gpu_mpc_factory):
     ok = t["status"] == 0
     assert ((o2["status"] == 0) == ok).all() and ok.sum() >= 6
     assert np.abs(o2["U"][ok] - t["U"][ok]).max() / F_MAX <= TOL and np.isfinite(o2["U"]).all()
+
+
+# ---- kernel 11: the same formulation in fp32 on one wave per instance (N <= 16, up to 32 hull rows, no terminal set) ----
+TOL32 = 1e-4      # the fp32 kernels' specification: u0 / tau within 1e-4 f_max of the exact solution
+
+
+@pytest.mark.parametrize("N,NT,nf,B", [(15, 16, 2, 48), (15, 16, 0, 8), (16, 16, 1, 16), (10, 16, 3, 16), (12, 8, 0, 8)])
+def test_fp32_wrench_step_against_the_oracle(gpu_mpc_factory, N, NT, nf, B):
+    """ftmpc_solve_hull32_kernel against oracle/qp_oracle.py:ipm_general, instance by instance: whole-horizon wrenches within
+    1e-4 f_max, every instance converged, allocation exact for the wrench the kernel hands over."""
+    if NT == 8:      # the synthetic generic 8-thruster matrix has 112 facets without a fault: take the reference's own matrix rows
+        pytest.skip("no 8-thruster vehicle with <= 32 facets in the synthetic set")
+    mpc = gpu_mpc_factory(N=N, NT=NT, dtype="f32", max_iters=40)
+    cfg = qo.QPConfig(N=N, NT=NT)
+    x0, ub, stuck, xref = qo.make_batch(B, N, NT, nf, 7600 + N + NT)
+    out = mpc.solve_wrench(x0, ub, stuck, xref.reshape(-1, order="F"), return_G=True)
+    deg = out["status"] == 3
+    assert deg.sum() <= B // 4
+    worst = 0.0
+    for b in np.flatnonzero(~deg):
+        assert out["status"][b] == 0, (b, out["status"][b], out["iters"][b])
+        tau0, T, st, nit, qp = qo.solve_wrench_instance(cfg, x0[b], ub[b], stuck[b], xref)
+        assert st == 0
+        worst = max(worst, np.abs(out["G"][b] - T).max() / F_MAX)
+        assert abs(int(out["iters"][b]) - nit) <= 2
+        want = out["tau0"][b] - cfg.D @ stuck[b]
+        assert out["alloc_status"][b] == 0
+        assert np.abs(cfg.D @ out["u0"][b] - want).max() <= 1e-6 * (1 + np.abs(want).max())
+        assert (out["u0"][b][ub[b] == 0] == 0).all() and (out["u0"][b] >= -1e-12).all() and (out["u0"][b] <= ub[b] + 1e-9).all()
+    assert worst <= TOL32, worst
+
+
+def test_fp32_wrench_warm_start_reference_window_and_persistent_grid(gpu_mpc_factory):
+    """Large batch (several instances per resident wave), wrench warm start, circle reference with uref != 0, mixed fault
+    sets (several hull tables): kernel 11 against the float64 kernel on the same inputs."""
+    N, NT, B = 15, 16, 6000
+    x0, ub, stuck, _ = qo.make_batch(B, N, NT, 2, 7700)
+    cfg = qo.QPConfig(N=N, NT=NT)
+    traj = rm.circle_trajectory(0.1, 10, radius=0.65, s_per_circle=40.0)
+    xr_all, ur_all = rm.assign_trajectory(traj, N)
+    xw, uw = rm.trajectory_window(xr_all, ur_all, 1.0, N)
+    hull = hull_tables(cfg.D, ub, stuck)
+    rng = np.random.default_rng(6)
+    ctr = (ub / 2 + stuck) @ cfg.D.T
+    W = np.ascontiguousarray(ctr[:, None, :] + rng.uniform(-0.05, 0.05, (B, N, 6)))
+    ref = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40).solve_wrench(
+        x0, ub, stuck, xw.reshape(-1, order="F"), uref=uw.reshape(-1, order="F"), warmG=W.copy(), hull=hull, return_G=True)
+    W32 = W.copy()
+    out = gpu_mpc_factory(N=N, NT=NT, dtype="f32", max_iters=40).solve_wrench(
+        x0, ub, stuck, xw.reshape(-1, order="F"), uref=uw.reshape(-1, order="F"), warmG=W32, hull=hull, return_G=True)
+    ok = ref["status"] == 0
+    assert ok.sum() >= B - B // 8 and (out["status"][ok] == 0).all()
+    assert np.array_equal(ref["status"] == 3, out["status"] == 3)
+    err = np.abs(out["G"][ok] - ref["G"][ok]).max(axis=(1, 2)) / F_MAX
+    assert err.max() <= TOL32, (err.max(), int(err.argmax()))
+    assert np.abs(out["u0"][ok] - ref["u0"][ok]).max() / F_MAX <= 2 * TOL32
+    assert np.array_equal(W32[ok], out["G"][ok])       # warm buffer updated in place
+    assert np.abs(out["iters"][ok].astype(int) - ref["iters"][ok]).max() <= 3
+
+
+def test_fp32_wrench_kernel_select_dense_keeps_the_float64_kernel(gpu_mpc_factory):
+    N, NT, B = 15, 16, 16
+    x0, ub, stuck, xref = qo.make_batch(B, N, NT, 1, 7800)
+    a = gpu_mpc_factory(N=N, NT=NT, dtype="f32", max_iters=40, kernel_select="dense").solve_wrench(x0, ub, stuck, xref.reshape(-1, order="F"), return_G=True)
+    b = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40).solve_wrench(x0, ub, stuck, xref.reshape(-1, order="F"), return_G=True)
+    assert np.array_equal(a["G"], b["G"], equal_nan=True) and np.array_equal(a["status"], b["status"])

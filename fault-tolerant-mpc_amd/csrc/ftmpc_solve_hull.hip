@@ -92,6 +92,17 @@ __device__ __forceinline__ void chol64_col(const Seed& seed, double* S, int lq, 
     if constexpr (J + 1 < NB) chol64_col<NB, J + 1, Seed>(seed, S, lq, li, ok, T, Wd);
 }
 
+// an fp32 tile in the registers of a float64 tile (no instruction: a register pair is two registers)
+__device__ __forceinline__ f64x4 park32(const f32x4& v) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    return f64x4{__builtin_bit_cast(double, f32x2_{v.x, v.y}), __builtin_bit_cast(double, f32x2_{v.z, v.w}), 0.0, 0.0};
+}
+__device__ __forceinline__ f32x4 unpark32(const f64x4& v) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ a = __builtin_bit_cast(f32x2_, v.x), b = __builtin_bit_cast(f32x2_, v.y);
+    return f32x4{a.x, a.y, b.x, b.y};
+}
+
 // sum over the 16 lanes of a DPP row (one row group), float64: the two halves travel separately
 __device__ __forceinline__ double row_sum16_d(double x) {
 #define FTMPC_DPP_ADD_D(ctrl)                                                                                                        \
@@ -177,6 +188,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     __shared__ __attribute__((aligned(16))) double xv64[NPADW];          // right-hand side / solution of the float64 sweeps
     __shared__ __attribute__((aligned(16))) float rv[NTP];
     __shared__ __attribute__((aligned(16))) double Sblk[2 + NSTG * 36];  // [0] = 0 | stage blocks G_k at 2 + 36 k + 6 g + h, float64
+    __shared__ __attribute__((aligned(16))) float Sblk32[8 + NSTG * 48]; // the same in fp32 (early iterations), kernel 10's padded layout
     __shared__ __attribute__((aligned(16))) float s_DaT[6 * MAX_NT];    // identity: the wrench components are the inputs
     __shared__ __attribute__((aligned(16))) float s_hA[MHP * 6];        // normals, row r at 6 r
     __shared__ __attribute__((aligned(16))) float s_hAT[6 * MHP];       // the same, component g at 32 g
@@ -210,23 +222,31 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         s_pg[lane0] = (unsigned char)g;
         s_ph[lane0] = (unsigned char)(lane0 - g * (g + 1) / 2);
     }
-    // Offsets (doubles) of the stage-block entries this lane subtracts from the seeds of the diagonal tile (I, I) and of the tile
-    // (I, I - 1), element [row q + 4 s][col] of the stored -(M_IJ)' tile = -M[16 I + col][16 J + row]; 0 = the zero word.
-    int goff_d[NBW][4], goff_s[NBW][4];
+    // fp32 seeds: word offsets into the padded fp32 blocks of the four entries this lane subtracts from the diagonal tile (I, I)
+    // and from the tile (I, I - 1) -- kernel 10's operand offsets for the pairs (M = I, K = I) and (M = I, K = I - 1)
+    int g32_d[NBW], g32_s[NBW];
     {
         const int li0 = lane0 & 15, lq0 = lane0 >> 4, n0 = 6 * N;
 #pragma unroll
-        for (int I = 0; I < NBW; ++I) {
+        for (int M = 0; M < NBW; ++M) {
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int e1 = 16 * I + li0, s1 = (e1 * 43) >> 8;       // e / 6 for e < 128
-                const int e2 = 16 * I + lq0 + 4 * rr, s2 = (e2 * 43) >> 8;
-                goff_d[I][rr] = (e1 < n0 && e2 < n0 && s1 == s2) ? 2 + 36 * s1 + 6 * (e1 - 6 * s1) + (e2 - 6 * s2) : 0;
-                const int e3 = 16 * (I - 1) + lq0 + 4 * rr, s3 = (e3 * 43) >> 8;
-                goff_s[I][rr] = (I > 0 && e1 < n0 && s1 == s3) ? 2 + 36 * s1 + 6 * (e1 - 6 * s1) + (e3 - 6 * s3) : 0;
+            for (int dk = -1; dk <= 0; ++dk) {
+                const int K = M + dk;
+                int off = 0;
+                if (K >= 0) {
+                    const int e1 = 16 * K + 4 * lq0, s1 = (e1 * 43) >> 8, j4 = e1 - 6 * s1;       // e / 6 for e < 128
+                    const int e2 = 16 * M + li0, s2 = (e2 * 43) >> 8, a2 = e2 - 6 * s2;
+                    if (e2 < n0) {
+                        if (s1 == s2) off = 8 + 48 * s1 + 8 * a2 + j4;
+                        else if (j4 == 4 && s2 == s1 + 1) off = 8 + 48 * s2 + 8 * a2 - 2;
+                    }
+                }
+                if (dk == 0) g32_d[M] = off;
+                else g32_s[M] = off;
             }
         }
     }
+    for (int i = lane0; i < 8 + NSTG * 48; i += 64) Sblk32[i] = 0.f;
     for (int i = lane0; i < 2 + NSTG * 36; i += 64) Sblk[i] = 0.0;
     for (int i = lane0; i < 6 * MAX_NT; i += 64) s_DaT[i] = ((i / MAX_NT) == (i % MAX_NT)) ? 1.f : 0.f;
     constexpr int na = 6;
@@ -537,7 +557,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 
         // ---------------- the hull rows of this lane: row c = v * 64 + lane = (stage hk, facet hr) ----------------
         bool hv[NVC];
-        int hcw[NVC], hxs[NVC], hra[NVC];      // word offsets: cw slot, first component of the stage in a natural vector, first component of the normal
+        int hcw[NVC];      // slot 32 k + r of the row in the row-value array (k: stage, r: facet)
         float sh[NVC], zh[NVC];
         {
             const float rmh = 1.0f / (float)MH;
@@ -551,8 +571,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 k = ((k + 1) * MH <= c) ? k + 1 : k;
                 const int r = c - k * MH;
                 hcw[v] = hv[v] ? k * MHP + r : 0;
-                hxs[v] = hv[v] ? 6 * k : 0;
-                hra[v] = hv[v] ? 6 * r : 0;
                 sh[v] = 1.f;
                 zh[v] = 0.f;
                 if (hv[v]) {      // b - A centre: the same for every stage
@@ -571,15 +589,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #pragma unroll
             for (int v = 0; v < NVC; ++v) zh[v] = hv[v] ? mu0 / sh[v] : 0.f;
         }
-        // rows of C x for the float64 natural-order LDS vector (the slack steps: small for active rows, by cancellation)
-        auto rows_Cx = [&](const double* xs, float (&ch)[NVC]) {
+        // rows of C x for a natural-order LDS vector, float64 (late iterations: the slack steps of active rows are small by
+        // cancellation and need the step's components to full relative accuracy) or fp32
+        auto rows_Cx = [&](auto xs, float (&ch)[NVC]) {
+            using XT = std::remove_cv_t<std::remove_pointer_t<decltype(xs)>>;
 #pragma unroll
             for (int v = 0; v < NVC; ++v) {
-                const f32x2 a0 = *reinterpret_cast<const f32x2*>(s_hA + hra[v]), a1 = *reinterpret_cast<const f32x2*>(s_hA + hra[v] + 2),
-                            a2 = *reinterpret_cast<const f32x2*>(s_hA + hra[v] + 4);
-                const double* x = xs + hxs[v];
-                const double s2 = ((double)a0.x * x[0] + (double)a0.y * x[1]) + ((double)a1.x * x[2] + (double)a1.y * x[3]) +
-                                  ((double)a2.x * x[4] + (double)a2.y * x[5]);
+                const int hra = 6 * (hcw[v] & (MHP - 1)), hxs = 6 * (hcw[v] >> 5);
+                const f32x2 a0 = *reinterpret_cast<const f32x2*>(s_hA + hra), a1 = *reinterpret_cast<const f32x2*>(s_hA + hra + 2),
+                            a2 = *reinterpret_cast<const f32x2*>(s_hA + hra + 4);
+                const XT* x = xs + hxs;
+                const XT s2 = ((XT)a0.x * x[0] + (XT)a0.y * x[1]) + ((XT)a1.x * x[2] + (XT)a1.y * x[3]) + ((XT)a2.x * x[4] + (XT)a2.y * x[5]);
                 ch[v] = hv[v] ? (float)s2 : 0.f;
             }
         };
@@ -608,17 +628,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 out[v] = s;
             }
         };
-        auto to_lds = [&](const float (&x)[NVW], double* dst) {
+        auto to_lds = [&](const float (&x)[NVW], auto dst) {
+            using XT = std::remove_pointer_t<decltype(dst)>;
             const int lane = lane_now();
             wave_lds_fence();
 #pragma unroll
             for (int v = 0; v < NVW; ++v) {
                 const int e = v * 64 + lane;
-                if (e < NPADW) dst[e] = wvalid[v] ? (double)x[v] : 0.0;
+                if (e < NPADW) dst[e] = wvalid[v] ? (XT)x[v] : (XT)0;
             }
             wave_lds_fence();
         };
-        auto from_lds = [&](const double* src, float (&x)[NVW]) {
+        auto from_lds = [&](auto src, float (&x)[NVW]) {
             const int lane = lane_now();
 #pragma unroll
             for (int v = 0; v < NVW; ++v) {
@@ -631,6 +652,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         // ---------------- interior-point iterations over the hull rows ----------------
         f64x4 T64[NTW], W64[NBW];
         int status = 1, nit = 0;
+        bool in64 = false;
 #ifndef FTMPC_HULL_REFRESH_ALL
 #define FTMPC_HULL_REFRESH_ALL 0
 #endif
@@ -671,58 +693,146 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 rsh[v] = __builtin_amdgcn_rcpf(sh[v]);
                 wh[v] = hv[v] ? zh[v] * rsh[v] : 0.f;
             }
+            // Early iterations run the factorisation and the sweeps in fp32 (chol_reg / solve_reg); from the iteration in which
+            // a row weight z / s passes FTMPC_HULL_W64 on, in float64.  With weights up to that the stage blocks are no larger
+            // than H_w's own entries and eliminating through them in fp32 is harmless; beyond, see the header.
+#ifndef FTMPC_HULL_W64
+#define FTMPC_HULL_W64 8.f      // measured (16 384 instances): 4 and 32 give the same rate and iteration count, 256 costs an iteration
+#endif
+            if (!in64) {
+                float wmax = 0.f;
+#pragma unroll
+                for (int v = 0; v < NVC; ++v) wmax = fmaxf(wmax, wh[v]);
+                in64 = __builtin_amdgcn_readfirstlane(wave_max(wmax) > FTMPC_HULL_W64);
+            }
             // stage blocks G_k = sum_r w_kr a_r a_r'
             wave_lds_fence();
 #pragma unroll
             for (int v = 0; v < NVC; ++v)
                 if (hv[v]) cw[hcw[v]] = wh[v];
             wave_lds_fence();
-            for (int idx = lane; idx < N * 21; idx += 64) {      // float64: the products of the fp32 normals are exact, G keeps its rank
-                const int k = (idx * 3121) >> 16, p = idx - 21 * k;      // idx / 21 for idx < 5000
-                const int g = s_pg[p], hh = s_ph[p];
-                const f32x4* ag4 = reinterpret_cast<const f32x4*>(s_hAT + g * MHP);
-                const f32x4* ah4 = reinterpret_cast<const f32x4*>(s_hAT + hh * MHP);
-                const f32x4* w4 = reinterpret_cast<const f32x4*>(cw + k * MHP);
-                double sacc = 0.0;
+            bool ok = true;
+            if (in64) {
+                for (int idx = lane; idx < N * 21; idx += 64) {      // float64: the products of the fp32 normals are exact, G keeps its rank
+                    const int k = (idx * 3121) >> 16, p = idx - 21 * k;      // idx / 21 for idx < 5000
+                    const int g = s_pg[p], hh = s_ph[p];
+                    const f32x4* ag4 = reinterpret_cast<const f32x4*>(s_hAT + g * MHP);
+                    const f32x4* ah4 = reinterpret_cast<const f32x4*>(s_hAT + hh * MHP);
+                    const f32x4* w4 = reinterpret_cast<const f32x4*>(cw + k * MHP);
+                    double sacc = 0.0, sacb = 0.0;
 #pragma unroll
-                for (int r4 = 0; r4 < MHP / 4; ++r4) {
-                    const f32x4 a = ag4[r4], b = ah4[r4], w = w4[r4];
-#pragma unroll
-                    for (int c4 = 0; c4 < 4; ++c4) sacc += (double)w[c4] * ((double)a[c4] * (double)b[c4]);
+                    for (int r4 = 0; r4 < MHP / 4; ++r4) {
+                        const f32x4 a = ag4[r4], b = ah4[r4], w = w4[r4];
+                        sacc += (double)w[0] * ((double)a[0] * (double)b[0]);
+                        sacb += (double)w[1] * ((double)a[1] * (double)b[1]);
+                        sacc += (double)w[2] * ((double)a[2] * (double)b[2]);
+                        sacb += (double)w[3] * ((double)a[3] * (double)b[3]);
+                    }
+                    sacc += sacb;
+                    Sblk[2 + k * 36 + g * 6 + hh] = sacc;
+                    Sblk[2 + k * 36 + hh * 6 + g] = sacc;
                 }
-                Sblk[2 + k * 36 + g * 6 + hh] = sacc;
-                Sblk[2 + k * 36 + hh * 6 + g] = sacc;
-            }
-            wave_lds_fence();
-            STAMP(7);
-            {
-                // float64 factorisation of H_w + G: seeds -(H_w + G)' read in the float64 accumulator layout (rows q + 4 s)
+                wave_lds_fence();
+                STAMP(7);
+                // float64 factorisation of H_w + G: seeds -(H_w + G)' read in the float64 accumulator layout (rows q + 4 s);
+                // element [row][col] of the stored -(M_IJ)' tile is -M[16 I + col][16 J + row]
                 const float* hb = Htl + 4 * li + lq;
+                auto gsub = [&](int I, int J, f64x4& r) {
+                    const int c1 = 16 * I + li, t1 = (c1 * 43) >> 8;       // e / 6 for e < 128
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int c2 = 16 * J + lq + 4 * rr, t2 = (c2 * 43) >> 8;
+                        const int off = (c1 < n && c2 < n && t1 == t2) ? 2 + 36 * t1 + 6 * (c1 - 6 * t1) + (c2 - 6 * t2) : 0;
+                        r[rr] -= Sblk[off];
+                    }
+                };
                 auto seed = [&](int I, int J) -> f64x4 {
                     const float* t = hb + tidx(I, J) * 256;
                     f64x4 r = {(double)t[0], (double)t[64], (double)t[128], (double)t[192]};
-                    if (J == I) r -= f64x4{Sblk[goff_d[I][0]], Sblk[goff_d[I][1]], Sblk[goff_d[I][2]], Sblk[goff_d[I][3]]};
-                    if (J == I - 1) r -= f64x4{Sblk[goff_s[I][0]], Sblk[goff_s[I][1]], Sblk[goff_s[I][2]], Sblk[goff_s[I][3]]};
+                    if (J == I || J == I - 1) gsub(I, J, r);
                     return r;
                 };
-                bool ok = true;
                 hullk::chol64_col<NBW, 0>(seed, f64scr, lq, li, ok, T64, W64);
                 STAMP(5);
-                if (__builtin_amdgcn_readfirstlane(!__all(ok))) {     // (float64 too runs out near mu ~ 1e-12 ... 1e-13)
-                    status = (mu < 1e-7f) ? 0 : 2;
-                    --nit;
-                    break;
+            } else {
+                for (int idx = lane; idx < N * 21; idx += 64) {
+                    const int k = (idx * 3121) >> 16, p = idx - 21 * k;
+                    const int g = s_pg[p], hh = s_ph[p];
+                    const f32x4* ag4 = reinterpret_cast<const f32x4*>(s_hAT + g * MHP);
+                    const f32x4* ah4 = reinterpret_cast<const f32x4*>(s_hAT + hh * MHP);
+                    const f32x4* w4 = reinterpret_cast<const f32x4*>(cw + k * MHP);
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int r4 = 0; r4 < MHP / 4; ++r4) {
+                        const f32x4 ab = ag4[r4] * ah4[r4], w = w4[r4];
+                        sacc += (ab.x * w.x + ab.y * w.y) + (ab.z * w.z + ab.w * w.w);
+                    }
+                    Sblk32[8 + k * 48 + g * 8 + hh] = sacc;
+                    Sblk32[8 + k * 48 + hh * 8 + g] = sacc;
                 }
+                wave_lds_fence();
+                STAMP(7);
+                f32x4 Xt[NTW], Tt[NTW], Wd[NBW];
+#pragma unroll
+                for (int I = 0; I < NBW; ++I) {
+#pragma unroll
+                    for (int J = 0; J <= I; ++J) {
+                        f32x4 t = htiles.ld(tidx(I, J), lane);
+                        if (J == I || J == I - 1) {
+                            const int off = (J == I) ? g32_d[I] : g32_s[I];
+                            const f32x2 lo2 = *reinterpret_cast<const f32x2*>(Sblk32 + off);
+                            const f32x2 hi2 = *reinterpret_cast<const f32x2*>(Sblk32 + off + 2);
+                            t -= f32x4{lo2.x, lo2.y, hi2.x, hi2.y};
+                        }
+                        Xt[tidx(I, J)] = t;
+                    }
+                }
+                for (int e = lane; e < NPADW; e += 64) dvp[e] = 0.f;      // (no diagonal shift)
+                wave_lds_fence();
+                f32x4 pre0[NBW];
+#pragma unroll
+                for (int I = 0; I < NBW; ++I) pre0[I] = zero4;
+                const RegTiles<NTW> xt{Xt};
+                ok = chol_reg<NBW, RegTiles<NTW>, false, false, false>(xt, dvp, recbuf, n, lane, Tt, Wd, pre0, nullptr);
+                // parked in the float64 arrays' registers (two fp32 tiles' worth per slot would fit; one is enough): one factor
+                // storage for both precisions, so the register allocator sees one live set across the iteration
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) T64[t] = hullk::park32(Tt[t]);
+#pragma unroll
+                for (int J = 0; J < NBW; ++J) W64[J] = hullk::park32(Wd[J]);
+                STAMP(5);
             }
+            if (__builtin_amdgcn_readfirstlane(!__all(ok))) {     // (float64 too runs out near mu ~ 1e-12 ... 1e-13)
+                status = (mu < 1e-7f) ? 0 : 2;
+                --nit;
+                break;
+            }
+            // (H_w + G) x = rhs; the rows C x of the solution
+            auto solve_rows = [&](const float (&rhs)[NVW], float (&ch)[NVC], float* xout) {
+                if (in64) {
+                    to_lds(rhs, xv64);
+                    hullk::solve64<NBW>(T64, W64, xv64, lq, li);
+                    rows_Cx((const double*)xv64, ch);
+                    if (xout) from_lds((const double*)xv64, *reinterpret_cast<float(*)[NVW]>(xout));
+                } else {
+                    f32x4 Tt[NTW], Wd[NBW];
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t) Tt[t] = hullk::unpark32(T64[t]);
+#pragma unroll
+                    for (int J = 0; J < NBW; ++J) Wd[J] = hullk::unpark32(W64[J]);
+                    to_lds(rhs, xvp);
+                    solve_reg<NBW>(Tt, Wd, xvp, NBW, lane);
+                    rows_Cx((const float*)xvp, ch);
+                    if (xout) from_lds((const float*)xvp, *reinterpret_cast<float(*)[NVW]>(xout));
+                }
+            };
             STAMP(9);
             // predictor: (H_w + G) da = -grd
             float rhs[NVW], dd[NVW];
 #pragma unroll
             for (int v = 0; v < NVW; ++v) rhs[v] = -grd[v];
-            to_lds(rhs, xv64);
-            hullk::solve64<NBW>(T64, W64, xv64, lq, li);
             float ch[NVC];
-            rows_Cx(xv64, ch);
+            solve_rows(rhs, ch, nullptr);
             // ds = -C da,  dz = -z - z ds / s
             float dzh_a[NVC], ap = 1.f, ad = 1.f;
 #pragma unroll
@@ -756,10 +866,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             cols_Ct(th, ct);
 #pragma unroll
             for (int v = 0; v < NVW; ++v) rhs[v] = -grd[v] + ct[v];
-            to_lds(rhs, xv64);
-            hullk::solve64<NBW>(T64, W64, xv64, lq, li);
-            from_lds(xv64, dd);
-            rows_Cx(xv64, ch);
+            solve_rows(rhs, ch, dd);
             float dzh[NVC];
             ap = 1e30f;
             ad = 1e30f;

@@ -9,18 +9,35 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 15
 NT = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 16384
 nf = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+MU32 = float(sys.argv[5]) if len(sys.argv) > 5 else 0.0      # mu_stop of the fp32 handle (0: library default)
 x0, ub, stuck, xref = qo.make_batch(B, N, NT, nf, 7900)
 cfg = qo.QPConfig(N=N, NT=NT)
 t0 = time.time(); hull = hull_tables(cfg.D, ub, stuck); print("hull tables %.2f s, %d sets" % (time.time() - t0, hull["A"].shape[0]))
 xr = xref.reshape(-1, order="F")
 res = {}
 for dt in ("f64", "f32"):
-    m = ft_mpc_amd.BatchedMPC(N=N, NT=NT, dtype=dt, max_iters=40)
+    m = ft_mpc_amd.BatchedMPC(N=N, NT=NT, dtype=dt, max_iters=40, mu_stop=(MU32 if dt == "f32" else 0.0))
     out = m.solve_wrench(x0, ub, stuck, xr, hull=hull, return_G=True)
     best = 1e9
     for _ in range(3):
         t0 = time.perf_counter(); m.solve_wrench(x0, ub, stuck, xr, hull=hull); best = min(best, time.perf_counter() - t0)
     res[dt] = out
+    # the C entry alone (arrays prepared, outputs preallocated): what a C caller sees
+    import ctypes as C
+    from ft_mpc_amd.batch import _ptr
+    sel = np.flatnonzero(~np.asarray(hull["degenerate"], bool)); b = sel.size
+    tk = lambda a: np.ascontiguousarray(a[sel])
+    ax0, aub, ast_, ahs, ahb = tk(x0), tk(ub), tk(stuck), np.ascontiguousarray(hull["set"][sel], dtype=np.int32), tk(hull["b"])
+    A = np.ascontiguousarray(hull["A"], dtype=np.float64)
+    o_u0, o_t0 = np.empty((b, NT)), np.empty((b, 6)); o_st, o_it, o_as = (np.empty(b, np.int32) for _ in range(3))
+    bestc = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        rc = m.lib.ftmpc_solve_wrench_batch(m._h, b, _ptr(ax0), _ptr(aub), _ptr(ast_), _ptr(A), A.shape[0], _ptr(ahs, C.c_int32), _ptr(ahb), int(hull["rows"]),
+                                            _ptr(xr), 0, None, 0, None, _ptr(o_u0), _ptr(o_t0), None, _ptr(o_st, C.c_int32), _ptr(o_it, C.c_int32), _ptr(o_as, C.c_int32))
+        bestc = min(bestc, time.perf_counter() - t0)
+    assert rc == 0
+    print("   C entry alone: %.2f ms -> %.0f QP/s (%d instances with a hull)" % (bestc * 1e3, b / bestc, b))
     print(dt, "status", np.bincount(out["status"], minlength=4), "iters mean %.2f max %d" % (out["iters"].mean(), out["iters"].max()),
           "alloc", np.bincount(out["alloc_status"], minlength=3), "%.2f ms -> %.0f QP/s (host buffers)" % (best * 1e3, B / best))
     m.close()

@@ -30,7 +30,9 @@ struct AllocParams {
 
 namespace {
 
-__device__ inline double alloc_dual(const DeviceConsts& C, int NT, const double lam[6], const double tau[6], const double* ubv,
+// Dm: the allocation matrix, 6 x MAX_NT, in LDS (ninety-six kernel-argument doubles do not fit the scalar registers beside
+// the rest: the unrolled loops spilled 381 of them)
+__device__ inline double alloc_dual(const double* Dm, int NT, const double lam[6], const double tau[6], const double* ubv,
                                     double u[MAX_NT], double F[6]) {
     double q = 0.0;
 #pragma unroll
@@ -41,12 +43,12 @@ __device__ inline double alloc_dual(const DeviceConsts& C, int NT, const double 
         if (i < NT) {
             double v = 0.0;
 #pragma unroll
-            for (int g = 0; g < 6; ++g) v += C.D[g * MAX_NT + i] * lam[g];
+            for (int g = 0; g < 6; ++g) v += Dm[g * MAX_NT + i] * lam[g];
             const double ui = fmin(fmax(v, 0.0), ubv[i]);
             u[i] = ui;
             q += v * ui - 0.5 * ui * ui;
 #pragma unroll
-            for (int g = 0; g < 6; ++g) F[g] += C.D[g * MAX_NT + i] * ui;
+            for (int g = 0; g < 6; ++g) F[g] += Dm[g * MAX_NT + i] * ui;
         }
     }
 #pragma unroll
@@ -102,6 +104,9 @@ __device__ inline void solve6(double J[6][6], const double b[6], double x[6]) {
 }  // namespace
 
 __global__ void __launch_bounds__(64) ftmpc_allocate_kernel(const DeviceConsts C, const AllocParams P) {
+    __shared__ double Dm[6 * MAX_NT];
+    for (int i = threadIdx.x; i < 6 * MAX_NT; i += 64) Dm[i] = C.D[i];
+    __syncthreads();
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= P.B) return;
     const int NT = C.NT;
@@ -125,91 +130,17 @@ __global__ void __launch_bounds__(64) ftmpc_allocate_kernel(const DeviceConsts C
                 double s = 0.0;
 #pragma unroll
                 for (int i = 0; i < MAX_NT; ++i)
-                    if (i < NT && ubv[i] > 0.0) s += C.D[r * MAX_NT + i] * C.D[c * MAX_NT + i];
+                    if (i < NT && ubv[i] > 0.0) s += Dm[r * MAX_NT + i] * Dm[c * MAX_NT + i];
                 J[r][c] = s;
             }
         solve6(J, tau, lam);
     }
-    double q = alloc_dual(C, NT, lam, tau, ubv, u, F);
+    double q = alloc_dual(Dm, NT, lam, tau, ubv, u, F);
     const double tol = P.tol * (1.0 + tmax);
-    int status = 1, it = 0;
-    for (; it < P.max_iters; ++it) {
-        double fmaxabs = 0.0;
-#pragma unroll
-        for (int g = 0; g < 6; ++g) fmaxabs = fmax(fmaxabs, fabs(F[g]));
-        if (fmaxabs <= tol) {
-            status = 0;
-            break;
-        }
-        // an unattainable tau makes the dual unbounded below: the multiplier runs away
-        double lmax = 0.0;
-#pragma unroll
-        for (int g = 0; g < 6; ++g) lmax = fmax(lmax, fabs(lam[g]));
-        if (lmax > 1e9 * (1.0 + tmax)) {
-            status = 2;
-            break;
-        }
-        // generalised Hessian over the thrusters strictly inside their bounds
-        double J[6][6];
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = 0; c < 6; ++c) J[r][c] = 0.0;
-#pragma unroll
-        for (int i = 0; i < MAX_NT; ++i)
-            if (i < NT && u[i] > 0.0 && u[i] < ubv[i]) {
-#pragma unroll
-                for (int r = 0; r < 6; ++r)
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) J[r][c] += C.D[r * MAX_NT + i] * C.D[c * MAX_NT + i];
-            }
-        double nF[6], dl[6];
-#pragma unroll
-        for (int g = 0; g < 6; ++g) nF[g] = -F[g];
-        solve6(J, nF, dl);
-        double slope = 0.0;
-#pragma unroll
-        for (int g = 0; g < 6; ++g) slope += F[g] * dl[g];
-        if (!(slope < 0.0)) {   // no descent along the Newton direction: steepest descent
-#pragma unroll
-            for (int g = 0; g < 6; ++g) dl[g] = -F[g];
-            slope = 0.0;
-#pragma unroll
-            for (int g = 0; g < 6; ++g) slope -= F[g] * F[g];
-        }
-        double t = 1.0;
-        double ln[6], un[MAX_NT], Fn[6], qn = q;
-        bool moved = false;
-        for (int ls = 0; ls < 40; ++ls) {
-#pragma unroll
-            for (int g = 0; g < 6; ++g) ln[g] = lam[g] + t * dl[g];
-            qn = alloc_dual(C, NT, ln, tau, ubv, un, Fn);
-            if (qn <= q + 1e-4 * t * slope) {
-                moved = true;
-                break;
-            }
-            t *= 0.5;
-        }
-        if (!moved) break;   // stationary for the line search: the residual that is left is infeasibility
-#pragma unroll
-        for (int g = 0; g < 6; ++g) {
-            lam[g] = ln[g];
-            F[g] = Fn[g];
-        }
-#pragma unroll
-        for (int i = 0; i < MAX_NT; ++i) u[i] = un[i];
-        q = qn;
-    }
-    if (status == 1) {
-        double fmaxabs = 0.0;
-#pragma unroll
-        for (int g = 0; g < 6; ++g) fmaxabs = fmax(fmaxabs, fabs(F[g]));
-        status = (fmaxabs <= tol) ? 0 : (it >= P.max_iters ? 1 : 2);
-    }
-    if (status != 0) {
-        // A tau on the boundary of the attainable set (an MPC solution with active hull rows: several thrusters exactly at a
-        // bound) leaves the dual flat and the Newton iteration stalls a few 1e-7 short.  Polish: thrusters within 1e-6 f_max
-        // of a bound are put ON it, the rest take the least-norm share of what is left; accepted if the residual passes.
+    // A tau on the boundary of the attainable set (an MPC solution with active hull rows: several thrusters exactly at a
+    // bound) leaves the dual flat and the Newton iteration stalls a few 1e-7 short.  Polish: thrusters within 1e-6 f_max
+    // of a bound are put ON it, the rest take the least-norm share of what is left; accepted if the residual passes.
+    auto polish = [&]() -> bool {
         double ubmax = 0.0;
 #pragma unroll
         for (int i = 0; i < MAX_NT; ++i) ubmax = fmax(ubmax, ubv[i]);
@@ -232,13 +163,13 @@ __global__ void __launch_bounds__(64) ftmpc_allocate_kernel(const DeviceConsts C
             any_free = any_free || fr[i];
             if (hi) {
 #pragma unroll
-                for (int g = 0; g < 6; ++g) r[g] -= C.D[g * MAX_NT + i] * ubv[i];
+                for (int g = 0; g < 6; ++g) r[g] -= Dm[g * MAX_NT + i] * ubv[i];
             }
             if (fr[i]) {
 #pragma unroll
                 for (int r6 = 0; r6 < 6; ++r6)
 #pragma unroll
-                    for (int c = 0; c < 6; ++c) J[r6][c] += C.D[r6 * MAX_NT + i] * C.D[c * MAX_NT + i];
+                    for (int c = 0; c < 6; ++c) J[r6][c] += Dm[r6 * MAX_NT + i] * Dm[c * MAX_NT + i];
             }
         }
         if (any_free) {
@@ -248,7 +179,7 @@ __global__ void __launch_bounds__(64) ftmpc_allocate_kernel(const DeviceConsts C
                 if (fr[i]) {
                     double v = 0.0;
 #pragma unroll
-                    for (int g = 0; g < 6; ++g) v += C.D[g * MAX_NT + i] * lf[g];
+                    for (int g = 0; g < 6; ++g) v += Dm[g * MAX_NT + i] * lf[g];
                     up[i] = fmin(fmax(v, 0.0), ubv[i]);
                 }
         }
@@ -258,15 +189,105 @@ __global__ void __launch_bounds__(64) ftmpc_allocate_kernel(const DeviceConsts C
             double t = -tau[g];
 #pragma unroll
             for (int i = 0; i < MAX_NT; ++i)
-                if (i < NT) t += C.D[g * MAX_NT + i] * up[i];
+                if (i < NT) t += Dm[g * MAX_NT + i] * up[i];
             res = fmax(res, fabs(t));
         }
-        if (res <= tol) {
+        if (res > tol) return false;
 #pragma unroll
-            for (int i = 0; i < MAX_NT; ++i) u[i] = up[i];
+        for (int i = 0; i < MAX_NT; ++i) u[i] = up[i];
+        return true;
+    };
+    // (the polish is also tried EARLY, once, when the residual has stopped halving over three iterations: left to the iteration
+    // cap, the boundary wrenches the wrench-space MPC hands over cost fifty Newton steps with a line search each before it runs,
+    // and one such lane holds up its whole wave)
+    double fh[3] = {1e300, 1e300, 1e300};
+    bool tried = false;
+    int status = 1, it = 0;
+    for (; it < P.max_iters; ++it) {
+        double fmaxabs = 0.0;
+#pragma unroll
+        for (int g = 0; g < 6; ++g) fmaxabs = fmax(fmaxabs, fabs(F[g]));
+        if (fmaxabs <= tol) {
             status = 0;
+            break;
         }
+        if (!tried && fmaxabs > 0.5 * fh[0] && fmaxabs <= 1e-3 * (1.0 + tmax)) {
+            tried = true;
+            if (polish()) {
+                status = 0;
+                break;
+            }
+        }
+        fh[0] = fh[1];
+        fh[1] = fh[2];
+        fh[2] = fmaxabs;
+        // an unattainable tau makes the dual unbounded below: the multiplier runs away
+        double lmax = 0.0;
+#pragma unroll
+        for (int g = 0; g < 6; ++g) lmax = fmax(lmax, fabs(lam[g]));
+        if (lmax > 1e9 * (1.0 + tmax)) {
+            status = 2;
+            break;
+        }
+        // generalised Hessian over the thrusters strictly inside their bounds
+        double J[6][6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) J[r][c] = 0.0;
+#pragma unroll
+        for (int i = 0; i < MAX_NT; ++i)
+            if (i < NT && u[i] > 0.0 && u[i] < ubv[i]) {
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) J[r][c] += Dm[r * MAX_NT + i] * Dm[c * MAX_NT + i];
+            }
+        double nF[6], dl[6];
+#pragma unroll
+        for (int g = 0; g < 6; ++g) nF[g] = -F[g];
+        solve6(J, nF, dl);
+        double slope = 0.0;
+#pragma unroll
+        for (int g = 0; g < 6; ++g) slope += F[g] * dl[g];
+        if (!(slope < 0.0)) {   // no descent along the Newton direction: steepest descent
+#pragma unroll
+            for (int g = 0; g < 6; ++g) dl[g] = -F[g];
+            slope = 0.0;
+#pragma unroll
+            for (int g = 0; g < 6; ++g) slope -= F[g] * F[g];
+        }
+        double t = 1.0;
+        double ln[6], Fn[6], qn = q;
+        bool moved = false;
+        for (int ls = 0; ls < 40; ++ls) {
+#pragma unroll
+            for (int g = 0; g < 6; ++g) ln[g] = lam[g] + t * dl[g];
+            qn = alloc_dual(Dm, NT, ln, tau, ubv, u, Fn);      // (u follows the trial point: restored below if nothing is accepted)
+            if (qn <= q + 1e-4 * t * slope) {
+                moved = true;
+                break;
+            }
+            t *= 0.5;
+        }
+        if (!moved) {        // stationary for the line search: the residual that is left is infeasibility
+            q = alloc_dual(Dm, NT, lam, tau, ubv, u, F);
+            break;
+        }
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            lam[g] = ln[g];
+            F[g] = Fn[g];
+        }
+        q = qn;
     }
+    if (status == 1) {
+        double fmaxabs = 0.0;
+#pragma unroll
+        for (int g = 0; g < 6; ++g) fmaxabs = fmax(fmaxabs, fabs(F[g]));
+        status = (fmaxabs <= tol) ? 0 : (it >= P.max_iters ? 1 : 2);
+    }
+    if (status != 0 && polish()) status = 0;
 #pragma unroll
     for (int i = 0; i < MAX_NT; ++i)
         if (i < NT) P.out_u[b * NT + i] = u[i];

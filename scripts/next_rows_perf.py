@@ -26,6 +26,14 @@ for (N, NT, B) in ((20, 16, 16384), (15, 16, 16384)):
     dt2, o2 = best(lambda: mpc.solve(x0, ub, stuck, xr))
     print(f"   thruster form, same handle (float64 kernel, n = {N*(NT-2)}): {dt2*1e3:8.1f} ms  {B/dt2:9.0f} QP/s", flush=True)
     mpc.close()
+    if 6 * N <= 96:      # kernel 11: the same formulation on one wave per instance (fp32 handle)
+        m32 = ft_mpc_amd.BatchedMPC(N=N, NT=NT, dtype="f32", max_iters=40)
+        dt3, o3 = best(lambda: m32.solve_wrench(x0, ub, stuck, xr, hull=hull))
+        both = ok & (o3["status"] == 0)
+        err = np.abs(o3["u0"][both] - out["u0"][both]).max() / 3.4
+        print(f"   the same on an fp32 handle (kernel 11, one wave per instance): {dt3*1e3:8.1f} ms  {B/dt3:9.0f} QP/s  iters {o3['iters'][both].mean():.2f}  "
+              f"solved {int((o3['status']==0).sum())}  u0 within {err:.1e} f_max of the float64 kernel", flush=True)
+        m32.close()
 N, NT, B = 20, 8, 16384
 x0, ub, stuck, xref = ft_mpc_amd.make_synthetic_batch(B, N, NT, 2, 1012)
 x0[:, 0:3] *= 0.05; x0[:, 3:6] *= 0.1

@@ -69,6 +69,7 @@ _AB_CASES = [  # (name, N, NT, faults, B, dtype, kernel_select): one batch per k
     ("config5_ws64", 40, 16, 2, 128, "f64", "auto"),
     ("config5_f64_dense", 40, 16, 2, 64, "f64", "dense"),
     ("refvehicle_f64", 15, 16, 2, 256, "f64", "dense"),
+    ("refvehicle_hull32", 15, 16, 2, 512, "f32", "wrench"),      # kernel 11 through ftmpc_solve_wrench_batch
 ]
 
 _AB_SCRIPT = r"""
@@ -79,6 +80,15 @@ cases = eval(sys.argv[3])
 out = {}
 for name, N, NT, nf, B, dtype, sel in cases:
     x0, ub, stuck, xref = ft_mpc_amd.make_synthetic_batch(B, N, NT, nf, 7300 + N + NT + nf)
+    if sel == "wrench":
+        mpc = ft_mpc_amd.BatchedMPC(N=N, NT=NT, dtype=dtype)
+        r = mpc.solve_wrench(x0, ub, stuck, np.ascontiguousarray(xref.reshape(-1, order="F")), return_G=True)
+        mpc.close()
+        keep = r["status"] != 3                      # (no hull: the healthy thrusters do not span R^6)
+        for k in ("u0", "G", "tau0", "iters"):
+            out[name + "/" + k] = r[k][keep]
+        out[name + "/status"] = r["status"][keep]
+        continue
     mpc = ft_mpc_amd.BatchedMPC(N=N, NT=NT, dtype=dtype, kernel_select=sel)
     r = mpc.solve(x0, ub, stuck, np.ascontiguousarray(xref.reshape(-1, order="F")), return_U=True)
     mpc.close()

@@ -90,9 +90,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     // words of one padded block row (S_k is symmetric), or of two when the four rows straddle a stage boundary (then the column's
     // stage picks the half, the other half reads the zero padding), or the zero words in front.  Word offsets, fixed per launch.
     constexpr int NPAIR = 3 * NBW - 2;
-    int skoff[NPAIR];
-    {
-        const int li0 = lane0 & 15, lq0 = lane0 >> 4, n0 = 6 * N;
+    constexpr bool SKTAB = NBW <= 6;     // the eight-tile instantiation has no registers to spare: it computes the offsets where it uses them
+    auto sk_offset = [&](int M, int K, int lq_, int li_) -> int {
+        const int e1 = 16 * K + 4 * lq_, s1 = (e1 * 43) >> 8, j4 = e1 - 6 * s1;       // e / 6 for e < 128
+        const int e2 = 16 * M + li_, s2 = (e2 * 43) >> 8, a2 = e2 - 6 * s2;
+        int off = 0;
+        if (e2 < 6 * N) {
+            if (s1 == s2) off = 8 + 48 * s1 + 8 * a2 + j4;
+            else if (j4 == 4 && s2 == s1 + 1) off = 8 + 48 * s2 + 8 * a2 - 2;
+        }
+        return off;
+    };
+    int skoff[SKTAB ? NPAIR : 1];
+    if constexpr (SKTAB) {
         int pi = 0;
 #pragma unroll
         for (int M = 0; M < NBW; ++M) {
@@ -100,14 +110,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             for (int dk = -1; dk <= 1; ++dk) {
                 const int K = M + dk;
                 if (K < 0 || K >= NBW) continue;
-                const int e1 = 16 * K + 4 * lq0, s1 = (e1 * 43) >> 8, j4 = e1 - 6 * s1;       // e / 6 for e < 128
-                const int e2 = 16 * M + li0, s2 = (e2 * 43) >> 8, a2 = e2 - 6 * s2;
-                int off = 0;
-                if (e2 < n0) {
-                    if (s1 == s2) off = 8 + 48 * s1 + 8 * a2 + j4;
-                    else if (j4 == 4 && s2 == s1 + 1) off = 8 + 48 * s2 + 8 * a2 - 2;
-                }
-                skoff[pi++] = off;
+                skoff[pi++] = sk_offset(M, K, lane0 >> 4, lane0 & 15);
             }
         }
     }
@@ -643,12 +646,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 f32x4 Pt[NTW];
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) Pt[t] = zero4;
-                f32x4 skv[NPAIR];
+                f32x4 skv[SKTAB ? NPAIR : 1];
+                if constexpr (SKTAB) {
 #pragma unroll
-                for (int pi = 0; pi < NPAIR; ++pi) {
-                    const f32x2 lo2 = *reinterpret_cast<const f32x2*>(Sblk + skoff[pi]);
-                    const f32x2 hi2 = *reinterpret_cast<const f32x2*>(Sblk + skoff[pi] + 2);
-                    skv[pi] = f32x4{lo2.x, lo2.y, hi2.x, hi2.y};
+                    for (int pi = 0; pi < NPAIR; ++pi) {
+                        const f32x2 lo2 = *reinterpret_cast<const f32x2*>(Sblk + skoff[pi]);
+                        const f32x2 hi2 = *reinterpret_cast<const f32x2*>(Sblk + skoff[pi] + 2);
+                        skv[pi] = f32x4{lo2.x, lo2.y, hi2.x, hi2.y};
+                    }
                 }
                 {
                     int pi = 0;
@@ -658,7 +663,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                         for (int dk = -1; dk <= 1; ++dk) {
                             const int K = M + dk;
                             if (K < 0 || K >= NBW) continue;
-                            const f32x4 sk = skv[pi++];
+                            f32x4 sk;
+                            if constexpr (SKTAB) {
+                                sk = skv[pi++];
+                            } else {
+                                const int off = sk_offset(M, K, lq, li);
+                                const f32x2 lo2 = *reinterpret_cast<const f32x2*>(Sblk + off);
+                                const f32x2 hi2 = *reinterpret_cast<const f32x2*>(Sblk + off + 2);
+                                sk = f32x4{lo2.x, lo2.y, hi2.x, hi2.y};
+                            }
 #pragma unroll
                             for (int J = 0; J < NBW; ++J)
                                 if (J <= K && J <= M) Pt[tidx(M, J)] = mm_tn(sk, ltiles.ld(tidx(K, J), lane), Pt[tidx(M, J)]);

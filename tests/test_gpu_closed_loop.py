@@ -204,14 +204,15 @@ def test_closed_loop_in_the_reference_two_stage_structure():
     assert np.abs(c_w[0:9] - c_t[0:9]).max() < 0.1
 
 
-def test_on_device_two_stage_loop_equals_the_step_by_step_loop(gpu_mpc_factory):
+@pytest.mark.parametrize("dtype,tol", [("f64", 1e-8), ("f32", 2e-5)])      # f32: kernel 11 (an x perturbed by 1e-15 moves an fp32 iterate by 1e-7)
+def test_on_device_two_stage_loop_equals_the_step_by_step_loop(gpu_mpc_factory, dtype, tol):
     """ftmpc_simulate_wrench_batch (the reference's structure at every step -- generalized-force MPC with the input hull,
     then allocation -- with plant, noise and the repeat-last warm-start shift on the device) against the same loop driven
     step by step from the host: solve_wrench per step, the oracle's plant and counter-based noise.  Mixed faults, so
     several hull tables are in play."""
     from oracle import closed_loop as cl
     N, NT, B, T = 15, 16, 6, 6
-    mpc = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=60)
+    mpc = gpu_mpc_factory(N=N, NT=NT, dtype=dtype, max_iters=60)
     cfg = qo.QPConfig(N=N, NT=NT)
     x0, ub, stuck, _ = qo.make_batch(B, N, NT, 2, 8500)
     ub[0] = 3.4; stuck[0] = 0.0                                       # one healthy vehicle among the faulty ones
@@ -224,12 +225,12 @@ def test_on_device_two_stage_loop_equals_the_step_by_step_loop(gpu_mpc_factory):
     for t in range(T):
         step = mpc.solve_wrench(x, ub, stuck, np.ascontiguousarray(xr[:, t:t + N + 1]).reshape(-1, order="F"), warmG=warm, return_G=True)
         assert (step["status"] == 0).all() and (step["alloc_status"] == 0).all()
-        assert np.abs(step["u0"] - out["u"][t]).max() < 1e-8, t
+        assert np.abs(step["u0"] - out["u"][t]).max() < tol, t
         warm = np.ascontiguousarray(np.concatenate([step["G"][:, 1:], step["G"][:, -1:]], axis=1))
         for b in range(B):
             x[b] = co.plant_step(cfg, x[b], step["u0"][b], ub[b], stuck[b])
         idx = (np.uint64(t) * np.uint64(B) + np.arange(B, dtype=np.uint64))[:, None] * np.uint64(13) + np.arange(13, dtype=np.uint64)[None, :]
         x = x + amp[None, :] * cl.u01(9, idx)
         x[:, 6:10] /= np.linalg.norm(x[:, 6:10], axis=1, keepdims=True)
-    assert np.abs(out["x"] - x).max() < 1e-8
+    assert np.abs(out["x"] - x).max() < tol
     assert (out["u"] >= -1e-9).all() and (out["u"] <= ub[None] + 1e-9).all()

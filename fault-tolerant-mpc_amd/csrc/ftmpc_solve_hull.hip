@@ -652,7 +652,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         // ---------------- interior-point iterations over the hull rows ----------------
         f64x4 T64[NTW], W64[NBW];
         int status = 1, nit = 0;
-        bool in64 = false;
+        bool in64 = false, fac64 = false;
 #ifndef FTMPC_HULL_REFRESH_ALL
 #define FTMPC_HULL_REFRESH_ALL 0
 #endif
@@ -699,11 +699,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #ifndef FTMPC_HULL_W64
 #define FTMPC_HULL_W64 8.f      // measured (16 384 instances): 4 and 32 give the same rate and iteration count, 256 costs an iteration
 #endif
-            if (!in64) {
+#ifndef FTMPC_HULL_WF64
+#define FTMPC_HULL_WF64 512.f    // ... and the factorisation itself stays fp32 (rounded up to float64 for the sweeps) up to this weight
+#endif
+            if (!fac64) {
                 float wmax = 0.f;
 #pragma unroll
                 for (int v = 0; v < NVC; ++v) wmax = fmaxf(wmax, wh[v]);
-                in64 = __builtin_amdgcn_readfirstlane(wave_max(wmax) > FTMPC_HULL_W64);
+                wmax = wave_max(wmax);
+                in64 = in64 || __builtin_amdgcn_readfirstlane(wmax > FTMPC_HULL_W64);
+                fac64 = __builtin_amdgcn_readfirstlane(wmax > FTMPC_HULL_WF64);
             }
             // stage blocks G_k = sum_r w_kr a_r a_r'
             wave_lds_fence();
@@ -712,7 +717,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 if (hv[v]) cw[hcw[v]] = wh[v];
             wave_lds_fence();
             bool ok = true;
-            if (in64) {
+            if (fac64) {
                 for (int idx = lane; idx < N * 21; idx += 64) {      // float64: the products of the fp32 normals are exact, G keeps its rank
                     const int k = (idx * 3121) >> 16, p = idx - 21 * k;      // idx / 21 for idx < 5000
                     const int g = s_pg[p], hh = s_ph[p];
@@ -796,10 +801,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 ok = chol_reg<NBW, RegTiles<NTW>, false, false, false>(xt, dvp, recbuf, n, lane, Tt, Wd, pre0, nullptr);
                 // parked in the float64 arrays' registers (two fp32 tiles' worth per slot would fit; one is enough): one factor
                 // storage for both precisions, so the register allocator sees one live set across the iteration
+                if (in64) {      // float64 sweeps on the fp32 factor (the sweeps take any consistent row order of the tiles)
 #pragma unroll
-                for (int t = 0; t < NTW; ++t) T64[t] = hullk::park32(Tt[t]);
+                    for (int t = 0; t < NTW; ++t) T64[t] = f64x4{(double)Tt[t].x, (double)Tt[t].y, (double)Tt[t].z, (double)Tt[t].w};
 #pragma unroll
-                for (int J = 0; J < NBW; ++J) W64[J] = hullk::park32(Wd[J]);
+                    for (int J = 0; J < NBW; ++J) W64[J] = f64x4{(double)Wd[J].x, (double)Wd[J].y, (double)Wd[J].z, (double)Wd[J].w};
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t) T64[t] = hullk::park32(Tt[t]);
+#pragma unroll
+                    for (int J = 0; J < NBW; ++J) W64[J] = hullk::park32(Wd[J]);
+                }
                 STAMP(5);
             }
             if (__builtin_amdgcn_readfirstlane(!__all(ok))) {     // (float64 too runs out near mu ~ 1e-12 ... 1e-13)

@@ -22,6 +22,18 @@ shape() {   # name, bench arguments...
   timeout -k 10 200 rocprofv3 --pmc $SQ2 --output-format csv -d $D/pmc_SQ2 -- python3 bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $D/pmc_SQ2.err || true
   echo "$name done" >> $OUT/progress.log
 }
+script_shape() {   # name, script + arguments (no bench line: kernel stats and counters only)
+  local name=$1; shift
+  local D=$OUT/$name
+  mkdir -p $D
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- python3 "$@" > $D/run.log 2> $D/prof.err || true
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d $D/pmc_$c -- python3 "$@" > /dev/null 2> $D/pmc_$c.err || true
+  done
+  timeout -k 10 200 rocprofv3 --pmc $SQ1 --output-format csv -d $D/pmc_SQ -- python3 "$@" > /dev/null 2> $D/pmc_SQ.err || true
+  timeout -k 10 200 rocprofv3 --pmc $SQ2 --output-format csv -d $D/pmc_SQ2 -- python3 "$@" > /dev/null 2> $D/pmc_SQ2.err || true
+  echo "$name done" >> $OUT/progress.log
+}
 shape headline
 shape config2 --batch 4096 --faults 1 --no-cpu-baseline
 shape config4shard --batch 32768 --no-cpu-baseline
@@ -30,4 +42,6 @@ shape refvehicle --horizon 15 --thrusters 16 --batch 4096 --no-cpu-baseline
 shape refvehicle_f64 --horizon 15 --thrusters 16 --batch 4096 --dtype f64 --no-cpu-baseline
 shape n20nt16 --horizon 20 --thrusters 16 --batch 4096 --no-cpu-baseline
 shape nominal8 --faults 0 --no-cpu-baseline
+script_shape wrench_hull32 scripts/wrench_trace.py f32       # the two-stage step: linearise, kernel 11, allocation (N = 15, 16 thrusters, B = 16 384)
+script_shape wrench_f64 scripts/wrench_trace.py f64
 cat $OUT/headline/bench.json

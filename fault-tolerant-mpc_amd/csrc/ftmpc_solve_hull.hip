@@ -700,7 +700,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #define FTMPC_HULL_W64 8.f      // measured (16 384 instances): 4 and 32 give the same rate and iteration count, 256 costs an iteration
 #endif
 #ifndef FTMPC_HULL_WF64
-#define FTMPC_HULL_WF64 512.f    // ... and the factorisation itself stays fp32 (rounded up to float64 for the sweeps) up to this weight
+#define FTMPC_HULL_WF64 1.0e5f   // ... and the factorisation itself stays fp32 (widened to float64 for the sweeps) up to this weight.
+// Measured on 16 384 instances (scripts/hull32_check.py): thresholds 512, 4 096, 65 536 and 1e6 all give the float64 kernel's
+// iteration counts and the same errors (7.2e-5 f_max worst) at 1.69 / 1.74 / 1.78 / 1.83 M QP-steps/s; with no float64
+// factorisation at all 22 % of the instances break down.  Where the fp32 factorisation does fail below the threshold, the
+// iteration is redone in float64.
 #endif
             if (!fac64) {
                 float wmax = 0.f;
@@ -717,102 +721,109 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 if (hv[v]) cw[hcw[v]] = wh[v];
             wave_lds_fence();
             bool ok = true;
-            if (fac64) {
-                for (int idx = lane; idx < N * 21; idx += 64) {      // float64: the products of the fp32 normals are exact, G keeps its rank
-                    const int k = (idx * 3121) >> 16, p = idx - 21 * k;      // idx / 21 for idx < 5000
-                    const int g = s_pg[p], hh = s_ph[p];
-                    const f32x4* ag4 = reinterpret_cast<const f32x4*>(s_hAT + g * MHP);
-                    const f32x4* ah4 = reinterpret_cast<const f32x4*>(s_hAT + hh * MHP);
-                    const f32x4* w4 = reinterpret_cast<const f32x4*>(cw + k * MHP);
-                    double sacc = 0.0, sacb = 0.0;
-#pragma unroll
-                    for (int r4 = 0; r4 < MHP / 4; ++r4) {
-                        const f32x4 a = ag4[r4], b = ah4[r4], w = w4[r4];
-                        sacc += (double)w[0] * ((double)a[0] * (double)b[0]);
-                        sacb += (double)w[1] * ((double)a[1] * (double)b[1]);
-                        sacc += (double)w[2] * ((double)a[2] * (double)b[2]);
-                        sacb += (double)w[3] * ((double)a[3] * (double)b[3]);
-                    }
-                    sacc += sacb;
-                    Sblk[2 + k * 36 + g * 6 + hh] = sacc;
-                    Sblk[2 + k * 36 + hh * 6 + g] = sacc;
-                }
-                wave_lds_fence();
-                STAMP(7);
-                // float64 factorisation of H_w + G: seeds -(H_w + G)' read in the float64 accumulator layout (rows q + 4 s);
-                // element [row][col] of the stored -(M_IJ)' tile is -M[16 I + col][16 J + row]
-                const float* hb = Htl + 4 * li + lq;
-                auto gsub = [&](int I, int J, f64x4& r) {
-                    const int c1 = 16 * I + li, t1 = (c1 * 43) >> 8;       // e / 6 for e < 128
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const int c2 = 16 * J + lq + 4 * rr, t2 = (c2 * 43) >> 8;
-                        const int off = (c1 < n && c2 < n && t1 == t2) ? 2 + 36 * t1 + 6 * (c1 - 6 * t1) + (c2 - 6 * t2) : 0;
-                        r[rr] -= Sblk[off];
-                    }
-                };
-                auto seed = [&](int I, int J) -> f64x4 {
-                    const float* t = hb + tidx(I, J) * 256;
-                    f64x4 r = {(double)t[0], (double)t[64], (double)t[128], (double)t[192]};
-                    if (J == I || J == I - 1) gsub(I, J, r);
-                    return r;
-                };
-                hullk::chol64_col<NBW, 0>(seed, f64scr, lq, li, ok, T64, W64);
-                STAMP(5);
-            } else {
-                for (int idx = lane; idx < N * 21; idx += 64) {
-                    const int k = (idx * 3121) >> 16, p = idx - 21 * k;
-                    const int g = s_pg[p], hh = s_ph[p];
-                    const f32x4* ag4 = reinterpret_cast<const f32x4*>(s_hAT + g * MHP);
-                    const f32x4* ah4 = reinterpret_cast<const f32x4*>(s_hAT + hh * MHP);
-                    const f32x4* w4 = reinterpret_cast<const f32x4*>(cw + k * MHP);
-                    float sacc = 0.f;
-#pragma unroll
-                    for (int r4 = 0; r4 < MHP / 4; ++r4) {
-                        const f32x4 ab = ag4[r4] * ah4[r4], w = w4[r4];
-                        sacc += (ab.x * w.x + ab.y * w.y) + (ab.z * w.z + ab.w * w.w);
-                    }
-                    Sblk32[8 + k * 48 + g * 8 + hh] = sacc;
-                    Sblk32[8 + k * 48 + hh * 8 + g] = sacc;
-                }
-                wave_lds_fence();
-                STAMP(7);
-                f32x4 Xt[NTW], Tt[NTW], Wd[NBW];
-#pragma unroll
-                for (int I = 0; I < NBW; ++I) {
-#pragma unroll
-                    for (int J = 0; J <= I; ++J) {
-                        f32x4 t = htiles.ld(tidx(I, J), lane);
-                        if (J == I || J == I - 1) {
-                            const int off = (J == I) ? g32_d[I] : g32_s[I];
-                            const f32x2 lo2 = *reinterpret_cast<const f32x2*>(Sblk32 + off);
-                            const f32x2 hi2 = *reinterpret_cast<const f32x2*>(Sblk32 + off + 2);
-                            t -= f32x4{lo2.x, lo2.y, hi2.x, hi2.y};
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                ok = true;
+                if (fac64) {
+                    for (int idx = lane; idx < N * 21; idx += 64) {      // float64: the products of the fp32 normals are exact, G keeps its rank
+                        const int k = (idx * 3121) >> 16, p = idx - 21 * k;      // idx / 21 for idx < 5000
+                        const int g = s_pg[p], hh = s_ph[p];
+                        const f32x4* ag4 = reinterpret_cast<const f32x4*>(s_hAT + g * MHP);
+                        const f32x4* ah4 = reinterpret_cast<const f32x4*>(s_hAT + hh * MHP);
+                        const f32x4* w4 = reinterpret_cast<const f32x4*>(cw + k * MHP);
+                        double sacc = 0.0, sacb = 0.0;
+    #pragma unroll
+                        for (int r4 = 0; r4 < MHP / 4; ++r4) {
+                            const f32x4 a = ag4[r4], b = ah4[r4], w = w4[r4];
+                            sacc += (double)w[0] * ((double)a[0] * (double)b[0]);
+                            sacb += (double)w[1] * ((double)a[1] * (double)b[1]);
+                            sacc += (double)w[2] * ((double)a[2] * (double)b[2]);
+                            sacb += (double)w[3] * ((double)a[3] * (double)b[3]);
                         }
-                        Xt[tidx(I, J)] = t;
+                        sacc += sacb;
+                        Sblk[2 + k * 36 + g * 6 + hh] = sacc;
+                        Sblk[2 + k * 36 + hh * 6 + g] = sacc;
                     }
-                }
-                for (int e = lane; e < NPADW; e += 64) dvp[e] = 0.f;      // (no diagonal shift)
-                wave_lds_fence();
-                f32x4 pre0[NBW];
-#pragma unroll
-                for (int I = 0; I < NBW; ++I) pre0[I] = zero4;
-                const RegTiles<NTW> xt{Xt};
-                ok = chol_reg<NBW, RegTiles<NTW>, false, false, false>(xt, dvp, recbuf, n, lane, Tt, Wd, pre0, nullptr);
-                // parked in the float64 arrays' registers (two fp32 tiles' worth per slot would fit; one is enough): one factor
-                // storage for both precisions, so the register allocator sees one live set across the iteration
-                if (in64) {      // float64 sweeps on the fp32 factor (the sweeps take any consistent row order of the tiles)
-#pragma unroll
-                    for (int t = 0; t < NTW; ++t) T64[t] = f64x4{(double)Tt[t].x, (double)Tt[t].y, (double)Tt[t].z, (double)Tt[t].w};
-#pragma unroll
-                    for (int J = 0; J < NBW; ++J) W64[J] = f64x4{(double)Wd[J].x, (double)Wd[J].y, (double)Wd[J].z, (double)Wd[J].w};
+                    wave_lds_fence();
+                    STAMP(7);
+                    // float64 factorisation of H_w + G: seeds -(H_w + G)' read in the float64 accumulator layout (rows q + 4 s);
+                    // element [row][col] of the stored -(M_IJ)' tile is -M[16 I + col][16 J + row]
+                    const float* hb = Htl + 4 * li + lq;
+                    auto gsub = [&](int I, int J, f64x4& r) {
+                        const int c1 = 16 * I + li, t1 = (c1 * 43) >> 8;       // e / 6 for e < 128
+    #pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const int c2 = 16 * J + lq + 4 * rr, t2 = (c2 * 43) >> 8;
+                            const int off = (c1 < n && c2 < n && t1 == t2) ? 2 + 36 * t1 + 6 * (c1 - 6 * t1) + (c2 - 6 * t2) : 0;
+                            r[rr] -= Sblk[off];
+                        }
+                    };
+                    auto seed = [&](int I, int J) -> f64x4 {
+                        const float* t = hb + tidx(I, J) * 256;
+                        f64x4 r = {(double)t[0], (double)t[64], (double)t[128], (double)t[192]};
+                        if (J == I || J == I - 1) gsub(I, J, r);
+                        return r;
+                    };
+                    hullk::chol64_col<NBW, 0>(seed, f64scr, lq, li, ok, T64, W64);
+                    STAMP(5);
+                    break;
                 } else {
-#pragma unroll
-                    for (int t = 0; t < NTW; ++t) T64[t] = hullk::park32(Tt[t]);
-#pragma unroll
-                    for (int J = 0; J < NBW; ++J) W64[J] = hullk::park32(Wd[J]);
+                    for (int idx = lane; idx < N * 21; idx += 64) {
+                        const int k = (idx * 3121) >> 16, p = idx - 21 * k;
+                        const int g = s_pg[p], hh = s_ph[p];
+                        const f32x4* ag4 = reinterpret_cast<const f32x4*>(s_hAT + g * MHP);
+                        const f32x4* ah4 = reinterpret_cast<const f32x4*>(s_hAT + hh * MHP);
+                        const f32x4* w4 = reinterpret_cast<const f32x4*>(cw + k * MHP);
+                        float sacc = 0.f;
+    #pragma unroll
+                        for (int r4 = 0; r4 < MHP / 4; ++r4) {
+                            const f32x4 ab = ag4[r4] * ah4[r4], w = w4[r4];
+                            sacc += (ab.x * w.x + ab.y * w.y) + (ab.z * w.z + ab.w * w.w);
+                        }
+                        Sblk32[8 + k * 48 + g * 8 + hh] = sacc;
+                        Sblk32[8 + k * 48 + hh * 8 + g] = sacc;
+                    }
+                    wave_lds_fence();
+                    STAMP(7);
+                    f32x4 Xt[NTW], Tt[NTW], Wd[NBW];
+    #pragma unroll
+                    for (int I = 0; I < NBW; ++I) {
+    #pragma unroll
+                        for (int J = 0; J <= I; ++J) {
+                            f32x4 t = htiles.ld(tidx(I, J), lane);
+                            if (J == I || J == I - 1) {
+                                const int off = (J == I) ? g32_d[I] : g32_s[I];
+                                const f32x2 lo2 = *reinterpret_cast<const f32x2*>(Sblk32 + off);
+                                const f32x2 hi2 = *reinterpret_cast<const f32x2*>(Sblk32 + off + 2);
+                                t -= f32x4{lo2.x, lo2.y, hi2.x, hi2.y};
+                            }
+                            Xt[tidx(I, J)] = t;
+                        }
+                    }
+                    for (int e = lane; e < NPADW; e += 64) dvp[e] = 0.f;      // (no diagonal shift)
+                    wave_lds_fence();
+                    f32x4 pre0[NBW];
+    #pragma unroll
+                    for (int I = 0; I < NBW; ++I) pre0[I] = zero4;
+                    const RegTiles<NTW> xt{Xt};
+                    ok = chol_reg<NBW, RegTiles<NTW>, false, false, false>(xt, dvp, recbuf, n, lane, Tt, Wd, pre0, nullptr);
+                    // parked in the float64 arrays' registers (two fp32 tiles' worth per slot would fit; one is enough): one factor
+                    // storage for both precisions, so the register allocator sees one live set across the iteration
+                    if (in64) {      // float64 sweeps on the fp32 factor (the sweeps take any consistent row order of the tiles)
+    #pragma unroll
+                        for (int t = 0; t < NTW; ++t) T64[t] = f64x4{(double)Tt[t].x, (double)Tt[t].y, (double)Tt[t].z, (double)Tt[t].w};
+    #pragma unroll
+                        for (int J = 0; J < NBW; ++J) W64[J] = f64x4{(double)Wd[J].x, (double)Wd[J].y, (double)Wd[J].z, (double)Wd[J].w};
+                    } else {
+    #pragma unroll
+                        for (int t = 0; t < NTW; ++t) T64[t] = hullk::park32(Tt[t]);
+    #pragma unroll
+                        for (int J = 0; J < NBW; ++J) W64[J] = hullk::park32(Wd[J]);
+                    }
+                    STAMP(5);
+                    if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
+                    fac64 = true;      // the fp32 factorisation broke down below the weight it is trusted to: this iteration again, and
+                    in64 = true;       // all later ones, in float64
                 }
-                STAMP(5);
             }
             if (__builtin_amdgcn_readfirstlane(!__all(ok))) {     // (float64 too runs out near mu ~ 1e-12 ... 1e-13)
                 status = (mu < 1e-7f) ? 0 : 2;

@@ -10,7 +10,8 @@ NT = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 16384
 nf = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 MU32 = float(sys.argv[5]) if len(sys.argv) > 5 else 0.0      # mu_stop of the fp32 handle (0: library default)
-x0, ub, stuck, xref = qo.make_batch(B, N, NT, nf, 7900)
+SEED = int(sys.argv[6]) if len(sys.argv) > 6 else 7900
+x0, ub, stuck, xref = qo.make_batch(B, N, NT, nf, SEED)
 cfg = qo.QPConfig(N=N, NT=NT)
 t0 = time.time(); hull = hull_tables(cfg.D, ub, stuck); print("hull tables %.2f s, %d sets" % (time.time() - t0, hull["A"].shape[0]))
 xr = xref.reshape(-1, order="F")

@@ -68,6 +68,13 @@ struct ftmpc_handle {
     // work lists of the fp32 instantiations: qlist [3][cap_batch], qctl = {count[3], pad, head[3], pad}
     int32_t* d_qlist = nullptr;
     int32_t* d_qctl = nullptr;
+    // Hint from the previous step: the list lengths it ended with, copied to pinned memory behind its kernels.  A list that was
+    // empty then gets a SMALL grid now (the kernels are persistent: any grid drains any list, a small one just slower if the hint
+    // is wrong) -- most batches fill one list, and an idle launch of a full grid costs 0.05 - 0.09 ms.
+    int32_t* h_qcnt = nullptr;      // pinned, 4 ints
+    hipEvent_t ev_qcnt = nullptr;
+    bool qcnt_pending = false, qcnt_valid = false;
+    int32_t last_cnt[4] = {0, 0, 0, 0};
     // pinned staging of the host-buffer entry points (hipHostMalloc; mirrors of the device buffers)
     struct Pinned {
         void* p = nullptr;
@@ -279,6 +286,21 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
     lp.qcount = h->d_qctl;
     lp.qvmax = h->use_wg ? 3 : nvar - 1;   // list 3: ceil(n/16) >= 11, the workgroup kernel
     if (!h->use_f64) HIP_TRY(h, hipMemsetAsync(h->d_qctl, 0, 8 * sizeof(int32_t), s));
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+    if (h->qcnt_pending && !capturing) {
+        if (hipEventQuery(h->ev_qcnt) == hipSuccess) {
+            for (int v = 0; v < 4; ++v) h->last_cnt[v] = h->h_qcnt[v];
+            h->qcnt_pending = false;
+            h->qcnt_valid = true;
+        } else {
+            (void)hipGetLastError();      // (not ready yet is not an error)
+        }
+    }
+    auto grid_for = [&](int v, int64_t full) -> int {   // list v: the full persistent grid, or a small one when the list was empty last step
+        const int64_t g = std::min<int64_t>(B, full);
+        return (int)((h->qcnt_valid && !capturing && h->last_cnt[v] == 0) ? std::min<int64_t>(g, 128) : g);
+    };
     const int lin_blocks = (int)((B + 63) / 64);
     for (bool& u : h->ev_used) u = false;
     if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[0], s));
@@ -371,7 +393,7 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
         w.base.qhead = h->d_qctl + 4 + v;
         w.slot = h->ws_slot;
         w.slot_words = h->ws_slot_words;
-        const int grid = (int)std::min<int64_t>(B, h->grid_ws);
+        const int grid = grid_for(v, h->grid_ws);
         if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[2 * ev_slot], s));
         if (h->ws_nb == 6) hipLaunchKernelGGL(ftmpc::ftmpc_solve_ws32_kernel<6>, dim3(grid), dim3(ftmpc::wsk::WG), 0, s, h->dc, w);
         else hipLaunchKernelGGL(ftmpc::ftmpc_solve_ws32_kernel<8>, dim3(grid), dim3(ftmpc::wsk::WG), 0, s, h->dc, w);
@@ -389,7 +411,7 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
         sp.qlist = h->d_qlist + (int64_t)v * B;
         sp.qcount = h->d_qctl + v;
         sp.qhead = h->d_qctl + 4 + v;
-        const int grid = (int)std::min<int64_t>(B, h->grid[v]);
+        const int grid = grid_for(v, h->grid[v]);
         if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[2 + 2 * v], s));
         if (v == 0) hipLaunchKernelGGL(ftmpc::ftmpc_solve_f32_kernel<8>, dim3(grid), dim3(64), 0, s, h->dc, sp);
         else if (v == 1) hipLaunchKernelGGL(ftmpc::ftmpc_solve_f32_kernel<9>, dim3(grid), dim3(64), 0, s, h->dc, sp);
@@ -406,7 +428,7 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
         sp.qlist = h->d_qlist + (int64_t)3 * B;
         sp.qcount = h->d_qctl + 3;
         sp.qhead = h->d_qctl + 7;
-        const int grid = (int)std::min<int64_t>(B, h->grid_wsw);
+        const int grid = grid_for(3, h->grid_wsw);
         if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[10], s));
         if (h->ws_nb == 6) hipLaunchKernelGGL(ftmpc::ftmpc_solve_wsw32_kernel<6>, dim3(grid), dim3(64), 0, s, h->dc, sp);
         else hipLaunchKernelGGL(ftmpc::ftmpc_solve_wsw32_kernel<8>, dim3(grid), dim3(64), 0, s, h->dc, sp);
@@ -428,7 +450,7 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
         w.base.qhead = h->d_qctl + 7;
         w.slot = h->wg_slot;
         w.slot_words = h->wg_slot_words;
-        const int grid = (int)std::min<int64_t>(B, h->grid_wg);
+        const int grid = grid_for(3, h->grid_wg);
         if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[10], s));
         hipLaunchKernelGGL(ftmpc::ftmpc_solve_wg32_kernel<15>, dim3(grid), dim3(ftmpc::wgk::WG), 0, s, h->dc, w);
         HIP_TRY(h, hipGetLastError());
@@ -438,6 +460,11 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
         }
     }
     if (h->profiling) h->ev_valid = true;
+    if (h->h_qcnt && !capturing && !h->qcnt_pending) {     // this step's list lengths, for the next one
+        HIP_TRY(h, hipMemcpyAsync(h->h_qcnt, h->d_qctl, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipEventRecord(h->ev_qcnt, s));
+        h->qcnt_pending = true;
+    }
     return FTMPC_OK;
 }
 
@@ -594,6 +621,12 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
         sbad = sbad || hipEventCreateWithFlags(&h->ev_in[i], hipEventDisableTiming) != hipSuccess ||
                hipEventCreateWithFlags(&h->ev_k[i], hipEventDisableTiming) != hipSuccess ||
                hipEventCreateWithFlags(&h->ev_out[i], hipEventDisableTiming) != hipSuccess;
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->h_qcnt), 4 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_qcnt, hipEventDisableTiming) != hipSuccess) {
+        if (h->h_qcnt) (void)hipHostFree(h->h_qcnt);
+        h->h_qcnt = nullptr;      // (no hint: every launch takes its full grid)
+        (void)hipGetLastError();
+    }
     if (sbad || grow(h, &h->d_qctl, 8) != FTMPC_OK) {
         g_create_error = "stream / event / work-list allocation failed";
         ftmpc_destroy(h);
@@ -713,6 +746,8 @@ int ftmpc_destroy(ftmpc_handle* h) {
                     h->gEall, h->wg_slot, h->ws_slot, h->ws64_slot, h->wsw_slot, h->hull_slot, h->d_tcost, h->d_cost, h->d_sqU, h->d_sqQ, h->d_sqT, h->d_sqJ, h->d_sqF, h->d_hullA, h->d_hullb, h->d_warmG, h->d_tau0, h->d_G, h->d_taud, h->d_hullset, h->d_ast2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (h->h_qcnt) (void)hipHostFree(h->h_qcnt);
+    if (h->ev_qcnt) (void)hipEventDestroy(h->ev_qcnt);
     if (h->pin_in.p) (void)hipHostFree(h->pin_in.p);
     if (h->pin_out.p) (void)hipHostFree(h->pin_out.p);
     for (int i = 0; i < 2 * FTMPC_KERNEL_SLOTS; ++i)

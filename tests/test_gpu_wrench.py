@@ -277,3 +277,13 @@ def test_fp32_wrench_kernel_select_dense_keeps_the_float64_kernel(gpu_mpc_factor
     a = gpu_mpc_factory(N=N, NT=NT, dtype="f32", max_iters=40, kernel_select="dense").solve_wrench(x0, ub, stuck, xref.reshape(-1, order="F"), return_G=True)
     b = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40).solve_wrench(x0, ub, stuck, xref.reshape(-1, order="F"), return_G=True)
     assert np.array_equal(a["G"], b["G"], equal_nan=True) and np.array_equal(a["status"], b["status"])
+
+
+def test_fp32_wrench_step_against_golden(gpu_mpc_factory):
+    """Kernel 11 against the committed fixture of the reference's own formulation (tests/golden/qp_wrench_hull_n15.npz)."""
+    from pathlib import Path
+    d = np.load(Path(__file__).parent / "golden" / "qp_wrench_hull_n15.npz")
+    mpc = gpu_mpc_factory(N=int(d["N"]), NT=int(d["NT"]), dtype="f32", max_iters=40)
+    out = mpc.solve_wrench(d["x0"], d["ub"], d["stuck"], d["xref"].reshape(-1, order="F"), return_G=True)
+    assert (out["status"] == 0).all() and (out["alloc_status"] == 0).all()
+    assert np.abs(out["G"] - d["G"]).max() / F_MAX <= TOL32 and np.abs(out["tau0"] - d["tau0"]).max() / F_MAX <= TOL32

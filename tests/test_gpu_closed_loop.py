@@ -234,3 +234,29 @@ def test_on_device_two_stage_loop_equals_the_step_by_step_loop(gpu_mpc_factory, 
         x[:, 6:10] /= np.linalg.norm(x[:, 6:10], axis=1, keepdims=True)
     assert np.abs(out["x"] - x).max() < tol
     assert (out["u"] >= -1e-9).all() and (out["u"] <= ub[None] + 1e-9).all()
+
+
+def test_on_device_two_stage_campaign_fp32_against_float64(gpu_mpc_factory):
+    """A Monte-Carlo campaign in the reference's two-stage structure on kernel 11 (fp32 handle): 2 048 vehicles with random
+    double faults, 30 closed-loop steps with measurement noise -- every step of every vehicle converges and allocates, and the
+    trajectories stay with the float64 kernel's (same loop, same noise)."""
+    N, NT, B, T = 15, 16, 2048, 30
+    x0, ub, stuck, _ = qo.make_batch(B, N, NT, 2, 8600)
+    from ft_mpc_amd.controllers.tools.input_bounds import hull_tables
+    hull = hull_tables(qo.QPConfig(N=N, NT=NT).D, ub, stuck)
+    ok = ~np.asarray(hull["degenerate"], bool)
+    x0, ub, stuck = x0[ok], ub[ok], stuck[ok]
+    hull = hull_tables(qo.QPConfig(N=N, NT=NT).D, ub, stuck)
+    xr = _hover_traj(N, T)
+    res = {}
+    for dt in ("f32", "f64"):
+        mpc = gpu_mpc_factory(N=N, NT=NT, dtype=dt, max_iters=60)
+        res[dt] = mpc.simulate(x0, ub, stuck, xr, T, seed=31, return_inputs=True, formulation="wrench", hull=hull)
+        assert res[dt]["not_converged"].sum() == 0, (dt, res[dt]["not_converged"])
+        assert res[dt]["alloc_failed"].sum() == 0, (dt, res[dt]["alloc_failed"])
+        assert np.isfinite(res[dt]["x"]).all()
+    assert (res["f32"]["u"] >= -1e-9).all() and (res["f32"]["u"] <= ub[None] + 1e-9).all()
+    # 1e-4 f_max per step; perturbations grow over 30 steps of an unstable plant under feedback
+    assert np.abs(res["f32"]["u"] - res["f64"]["u"]).max() / 3.4 < 5e-3
+    assert np.median(np.abs(res["f32"]["u"] - res["f64"]["u"]).max(axis=(0, 2))) / 3.4 < 2e-4
+    assert np.abs(res["f32"]["x"] - res["f64"]["x"]).max() < 5e-3

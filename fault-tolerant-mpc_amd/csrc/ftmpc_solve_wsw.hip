@@ -27,7 +27,11 @@ namespace ftmpc {
 namespace wswk {
 __host__ __device__ constexpr int nvt_of(int nbw) { return nbw <= 6 ? 4 : 6; }     // thruster variables per lane
 // per-workgroup global slot (4-byte words): float64 scratch of the reference gradient (gradient | wrenches | stage storage)
-__host__ __device__ constexpr int64_t slot_words(int nbw, int N) { return ((wgk::slot_f64_words(64 * nvt_of(nbw), N) + 255) / 256) * 256; }
+// tiles of L kept in LDS: all 21 of the six-tile instantiation; 24 of the 36 of the eight-tile one -- the last twelve (block row 7
+// and most of row 6) live in the global slot, read through the Infinity Cache, so that FOUR waves fit a CU's LDS instead of three
+__host__ __device__ constexpr int nlds_of(int nbw) { return nbw <= 6 ? nbw * (nbw + 1) / 2 : 24; }
+__host__ __device__ constexpr int64_t slot_f64_part(int nbw, int N) { return ((wgk::slot_f64_words(64 * nvt_of(nbw), N) + 255) / 256) * 256; }
+__host__ __device__ constexpr int64_t slot_words(int nbw, int N) { return slot_f64_part(nbw, N) + (int64_t)(nbw * (nbw + 1) / 2 - nlds_of(nbw)) * 256; }
 // the factorisation reads its seeds (-M' tiles) from registers
 template <int NT>
 struct RegTiles {
@@ -48,7 +52,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     constexpr int NSTG = NPADW / 6;
     constexpr int BUILD_WORDS = 2 * DENSE_WORDS + 256;
     static_assert(NTW * 256 >= BUILD_WORDS, "the dense stage-matrix images live in the tile area during the build");
-    __shared__ __attribute__((aligned(16))) float Ltl[NTW * 256];       // -H_w' tiles (build) -> tiles of L (H_w = L L')
+    constexpr int NLDSW = nlds_of(NBW);
+    static_assert(NLDSW * 256 >= BUILD_WORDS, "the dense stage-matrix images live in the LDS tile area during the build");
+    __shared__ __attribute__((aligned(16))) float Ltl[NLDSW * 256];     // -H_w' tiles (build) -> tiles of L (H_w = L L'); the rest: global slot
     __shared__ __attribute__((aligned(16))) float recbuf[2 * REC_STRIDE + 8];
     __shared__ __attribute__((aligned(16))) float xvp[NPADW], dvp[NPADW], twv[NPADW], yvv[NPADW];
     __shared__ __attribute__((aligned(16))) float rv[NTP];
@@ -67,9 +73,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 
     const int lane0 = threadIdx.x;
     const int N = C.N, NT = C.NT;
-    TileStore<NTW> ltiles;
+    TileStore<NLDSW> ltiles;
     ltiles.p = Ltl;
-    ltiles.bind(P.hscratch);      // (never used: every tile of this store is in LDS)
+    ltiles.bind(P.hscratch + (int64_t)blockIdx.x * P.tile_words + slot_f64_part(NBW, C.N));      // tiles [NLDSW, NTW) behind the float64 scratch
     const float rho = (float)C.rho;
     const float mu_stop = (float)C.mu_stop;
     double* const sbuf = reinterpret_cast<double*>(P.hscratch + (int64_t)blockIdx.x * P.tile_words);
@@ -368,6 +374,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             }
         }
         wave_lds_fence();   // the dense images in the tile area are dead from here: Ltl holds the -H_w' tiles
+        if constexpr (NLDSW < NTW) wave_global_fence();     // ... and the global slot the rest: the stores have landed before the loads below
 
         // ---- helpers on LDS vectors (natural order) ----
         // wrench image of a thruster-space vector held NVT per lane: out[w] = sum_a D_a[g][a] x[k nat + a]
@@ -510,9 +517,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             for (int e = lane_now(); e < NPADW; e += 64) dvp[e] = 0.f;
             wave_lds_fence();
             f32x4 pre0[NBW];
-#pragma unroll
-            for (int I = 0; I < NBW; ++I) pre0[I] = zero4;
-            const bool ok = chol_reg<NBW, TileStore<NTW>, true, false, true>(ltiles, dvp, recbuf, n, lane, Tt, Wd, pre0, nullptr);
+            chol_prefetch_col0<NBW>(ltiles, lane, pre0);      // (zero for tiles that live in LDS)
+            const bool ok = chol_reg<NBW, TileStore<NLDSW>, true, false, true>(ltiles, dvp, recbuf, n, lane, Tt, Wd, pre0, nullptr);
+            if constexpr (NLDSW < NTW) wave_global_fence();   // the tiles of L written to the global slot
             if (__builtin_amdgcn_readfirstlane(!ok)) {     // H_w not positive definite in fp32: report the linearisation point
                 wave_lds_fence();
                 float* ub0 = Ltl;

@@ -23,11 +23,11 @@ run("cfg2-shape at 65536",65536,20,8,1,"f32",1002)
 run("nominal 8 thrusters",65536,20,8,0,"f32",1001)
 run("cfg3 double fault (headline)",65536,20,8,2,"f32",1003)
 run("cfg4 shard (32768/GPU)",32768,20,8,2,"f32",1004)
-run("reference vehicle N=15 NT=16 2f (fp32 workgroup kernel)",4096,15,16,2,"f32",1011)
+run("reference vehicle N=15 NT=16 2f (fp32, kernel 10)",4096,15,16,2,"f32",1011)
 run("reference vehicle, nominal (n=240)",4096,15,16,0,"f32",1012)
 run("reference vehicle N=15 NT=16 2f",4096,15,16,2,"f64",1011)
 run("cfg5 shard (2048/GPU) N=40 NT=16 (wrench-space f64)",2048,40,16,2,"f64",1005)
 run("cfg5 shard, dense f64 kernel",2048,40,16,2,"f64",1005,sel="dense")
-run("N=20 NT=16 2f fp32 (kernel 8, two variables per thread)",4096,20,16,2,"f32",1013)
+run("N=20 NT=16 2f fp32 (kernel 10, eight tiles a side)",4096,20,16,2,"f32",1013)
 run("N=20 NT=16 nominal fp32",4096,20,16,0,"f32",1014)
 run("N=20 NT=16 2f f64 dense (what it ran on before)",2048,20,16,2,"f64",1013,sel="dense")

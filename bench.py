@@ -105,7 +105,7 @@ def csrc_hash():
     """sha256 over the kernel sources: the committed PMC traffic figure is only quoted for the code it was measured on."""
     h = hashlib.sha256()
     for f in sorted((ROOT / "fault-tolerant-mpc_amd" / "csrc").glob("*")):
-        if f.suffix in (".hip", ".h"):
+        if f.suffix in (".hip", ".h", ".inc"):
             h.update(f.name.encode())
             h.update(f.read_bytes())
     return h.hexdigest()[:16]

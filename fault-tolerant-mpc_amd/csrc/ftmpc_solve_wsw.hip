@@ -179,39 +179,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             const int hh = p - g * (g + 1) / 2;
             s_DD[e] = (a < nat) ? s_DaT[g * MAX_NT + a] * s_DaT[hh * MAX_NT + a] : 0.f;
         }
-        typedef double f64x4_t __attribute__((ext_vector_type(4)));
-        const double* recg = reinterpret_cast<const double*>(P.rec) + inst * (int64_t)N * REC_STRIDE;
-        f64x4_t pre64 = {0.0, 0.0, 0.0, 0.0};
-        if (lane < REC_STRIDE / 4) pre64 = *reinterpret_cast<const f64x4_t*>(recg + 4 * lane);
-        int dpos[4] = {DENSE_DUMP, DENSE_DUMP, DENSE_DUMP, DENSE_DUMP};
-        {
-            int w0 = 4 * lane;
-            asm volatile("" : "+v"(w0));
-            if (lane < REC_STRIDE / 4) {
-                const ushort4 t = *reinterpret_cast<const ushort4*>(&k_dense_pos.v[w0]);
-                dpos[0] = t.x;
-                dpos[1] = t.y;
-                dpos[2] = t.z;
-                dpos[3] = t.w;
-            }
-        }
-        for (int i = lane; i < BUILD_WORDS; i += 64) dense[i] = 0.f;
-        wave_lds_fence();
-        if (lane < 6) {
-            const int a = lane % 3, isv = lane / 3;
-#pragma unroll
-            for (int bsel = 0; bsel < 2; ++bsel) {
-                float* dd = dense + bsel * DENSE_WORDS;
-                dd[16 * tile_row(3 * isv + a) + tile_row(3 * isv + a)] = 1.f;
-                if (!isv) dd[16 * tile_row(a) + tile_row(3 + a)] = (float)C.dt;
-            }
-        }
-        for (int i = lane; i < 81; i += 64) {
-            const int r = i / 9, c = i - 9 * r;
-            if (c >= r) dense[2 * DENSE_WORDS + 16 * tile_row(r) + tile_row(c)] = (float)C.LPt[i];
-        }
-        wave_lds_fence();
-        const f32x4 lp4 = lds4(dense + 2 * DENSE_WORDS + 16 * li + 4 * lq);
+#define FTMPC_WB_PART 1
+#include "ftmpc_wrench_build.inc"
+#undef FTMPC_WB_PART
 
         // thruster-space role of this lane: variables e = v * 64 + lane = (stage tk, healthy thruster ta)
         bool tvalid[NVT];
@@ -235,144 +205,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 if (P.warmU) ubar[v] = fminf(fmaxf((float)P.warmU[(inst * N + tk[v]) * NT + t], 0.f), ubv[v]);
             }
         }
-        float gw[NVW];      // wrench-space gradient at the linearisation point, column e = v * 64 + lane
-        {
-            // ---------------- build: kernel 2's stage loop with D_a = I ----------------
-            f32x4 G[NBW];
-            float gpart[NBW];
-#pragma unroll
-            for (int X = 0; X < NBW; ++X) {
-                G[X] = zero4;
-                gpart[X] = 0.f;
-            }
-            float esc[3];
-#pragma unroll
-            for (int s3 = 0; s3 < 3; ++s3) esc[s3] = (lq < 3) ? 2.f * (float)C.Q[3 * s3 + lq] : 0.f;
-            f32x4 acc[NTW];
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) acc[t] = zero4;
-            auto finish_tile = [&](int I, int J) {
-                f32x4 h = acc[(I * (I + 1)) / 2 + J];
-                if (J >= I - 1) {
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const int e1 = (I == J) ? 16 * I + 4 * lq + rr : 16 * I + li;
-                        const int e2 = (I == J) ? 16 * J + li : 16 * J + 4 * lq + rr;
-                        const int s1 = s_stg[e1], a1 = s_thr[e1];
-                        const int s2 = s_stg[e2], a2 = s_thr[e2];
-                        float add = (s1 != 255 && s1 == s2) ? mtab[((a1 & (MAX_NT - 1)) << 4) | (a2 & (MAX_NT - 1))] : 0.f;
-                        if (s1 == 255 && e1 == e2) add = 1.f;
-                        h[rr] += add;
-                    }
-                }
-                ltiles.st((I * (I + 1)) / 2 + J, lane, -h);
-            };
-            STAMP(0);
-            auto stage = [&](int k, auto TERM) {
-                constexpr bool terminal = decltype(TERM)::value;
-                const int lane = lane_now();
-                const int li = lane & 15, lq = lane >> 4;
-                float* rb = recbuf + (k & 1) * REC_STRIDE;
-                float* dd = dense + (k & 1) * DENSE_WORDS;
-                if (lane < REC_STRIDE / 4) {
-                    const f32x4 pre = {(float)pre64.x, (float)pre64.y, (float)pre64.z, (float)pre64.w};
-                    *reinterpret_cast<f32x4*>(rb + 4 * lane) = pre;
-                    dd[dpos[0]] = pre.x;
-                    dd[dpos[1]] = pre.y;
-                    dd[dpos[2]] = pre.z;
-                    dd[dpos[3]] = pre.w;
-                    if (!terminal) pre64 = *reinterpret_cast<const f64x4_t*>(recg + (k + 1) * REC_STRIDE + 4 * lane);
-                }
-                wave_lds_fence();
-                const f32x4 a4 = lds4(dd + 16 * li + 4 * lq);
-                const float b0 = dd[256 + 8 * li + lq], b1 = dd[256 + 8 * li + 4 + lq];
-                float we[3];
-#pragma unroll
-                for (int s3 = 0; s3 < 3; ++s3) we[s3] = (lq < 3) ? rb[REC_WE + 3 * s3 + lq] : 0.f;
-                const float rut0 = rb[REC_RUT + lq], rut1 = (lq < 2) ? rb[REC_RUT + 4 + lq] : 0.f;
-                const int Imax = ((k + 1) * na - 1) >> 4;
-                const int Xnew = (k * na) >> 4;
-                float E[NBW][3];
-#pragma unroll
-                for (int X = 0; X < NBW; ++X)
-                    if (X <= Imax) {
-                        f32x4 o = zero4;
-                        if (X >= Xnew) {      // the columns of stage k: D_a = I, column a takes wrench component a
-                            const int ax = *(lds_vu8*)&s_thr[16 * X + li];
-                            const bool mine = (*(lds_vu8*)&s_stg[16 * X + li] == k);
-                            const float d0 = (mine && ax == lq) ? 1.f : 0.f;
-                            const float d1 = (mine && lq < 2 && ax == 4 + lq) ? 1.f : 0.f;
-                            o = mfma4(b0, d0, o);
-                            o = mfma4(b1, d1, o);
-                            gpart[X] += d0 * rut0 + d1 * rut1;
-                        }
-                        o = mfma4(a4.x, G[X].x, o);
-                        o = mfma4(a4.y, G[X].y, o);
-                        o = mfma4(a4.z, G[X].z, o);
-                        o = mfma4(a4.w, G[X].w, o);
-                        G[X] = o;
-                    }
-#pragma unroll
-                for (int X = 0; X < NBW; ++X)
-                    if (X <= Imax) {
-                        gpart[X] += we[0] * G[X].x + we[1] * G[X].y + we[2] * G[X].z;
-                        if constexpr (terminal) {
-                            f32x4 o = zero4;
-                            o = mfma4(lp4.x, G[X].x, o);
-                            o = mfma4(lp4.y, G[X].y, o);
-                            o = mfma4(lp4.z, G[X].z, o);
-                            o = mfma4(lp4.w, G[X].w, o);
-                            E[X][0] = o.x;
-                            E[X][1] = o.y;
-                            E[X][2] = o.z;
-                        }
-                    }
-                STAMP(1);
-#pragma unroll
-                for (int I = 0; I < NBW; ++I)
-                    if (I <= Imax) {
-                        float eI[3] = {0.f, 0.f, 0.f};
-                        if constexpr (!terminal) {   // E_J' E_I = G_J' (2 Q) G_I
-                            eI[0] = esc[0] * G[I].x;
-                            eI[1] = esc[1] * G[I].y;
-                            eI[2] = esc[2] * G[I].z;
-                        }
-#pragma unroll
-                        for (int J = 0; J <= I; ++J) {
-                            if constexpr (!terminal) {
-                                acc[(I * (I + 1)) / 2 + J] = mfma4(G[J].x, eI[0], acc[(I * (I + 1)) / 2 + J]);
-                                acc[(I * (I + 1)) / 2 + J] = mfma4(G[J].y, eI[1], acc[(I * (I + 1)) / 2 + J]);
-                                acc[(I * (I + 1)) / 2 + J] = mfma4(G[J].z, eI[2], acc[(I * (I + 1)) / 2 + J]);
-                            } else {
-#pragma unroll
-                                for (int s3 = 0; s3 < 3; ++s3) acc[(I * (I + 1)) / 2 + J] = mfma4(E[J][s3], E[I][s3], acc[(I * (I + 1)) / 2 + J]);
-                                finish_tile(I, J);
-                            }
-                        }
-                    }
-                STAMP(2);
-            };
-            for (int k = 0; k + 1 < N; ++k) stage(k, std::false_type{});
-            stage(N - 1, std::true_type{});
-#pragma unroll
-            for (int I = 0; I < NBW; ++I)
-                if (I > ((N * na - 1) >> 4)) {
-#pragma unroll
-                    for (int J = 0; J <= I; ++J) finish_tile(I, J);
-                }
-            float qs[NBW];
-#pragma unroll
-            for (int X = 0; X < NBW; ++X) qs[X] = quad_sum(gpart[X]);
-#pragma unroll
-            for (int v = 0; v < NVW; ++v) {
-                float t = 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (4 * v + j < NBW) t = (lq == j) ? qs[4 * v + j] : t;
-                const int e = v * 64 + lane;
-                gw[v] = (e < n) ? 2.f * t : 0.f;
-            }
-        }
+#define FTMPC_WB_PART 2
+#define FTMPC_WB_TILES ltiles
+#include "ftmpc_wrench_build.inc"
+#undef FTMPC_WB_TILES
+#undef FTMPC_WB_PART
         wave_lds_fence();   // the dense images in the tile area are dead from here: Ltl holds the -H_w' tiles
         if constexpr (NLDSW < NTW) wave_global_fence();     // ... and the global slot the rest: the stores have landed before the loads below
 

@@ -578,12 +578,15 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
     // to N = 16, two beyond); kernel_select = FTMPC_KERNEL_DENSE: kernel 7 (n <= 240) or the float64 kernel instead.
     // The one-wave kernels keep n <= 160: a workgroup per instance does not compete with a wave per instance there.
     h->ws_nb = (6 * cfg->N <= 96) ? 6 : 8;
-    h->use_ws = cfg->dtype != FTMPC_DTYPE_F64 && cfg->kernel_select != FTMPC_KERNEL_DENSE && h->nb_max > 10 && 6 * cfg->N <= 128 &&
+    // the terminal set: the thruster-space solve with those rows exists in float64 only, so an fp32 handle that asks for it
+    // solves THAT form on the float64 kernel; its two-stage form (ftmpc_solve_wrench_batch) still runs on kernel 11
+    const bool solve_f64 = cfg->dtype == FTMPC_DTYPE_F64 || cfg->terminal_set != 0;
+    h->use_ws = !solve_f64 && cfg->kernel_select != FTMPC_KERNEL_DENSE && h->nb_max > 10 && 6 * cfg->N <= 128 &&
                 cfg->N * cfg->NT <= ftmpc::wsk::WG * ftmpc::wsk::nvt_of(h->ws_nb);
     // ... on one wave per instance (kernel 10) when the thruster variables fit four (N <= 16) / six (N <= 21) per lane;
     // kernel_select = FTMPC_KERNEL_WORKGROUP keeps the workgroup-per-instance kernel 8
     h->use_wsw = h->use_ws && cfg->kernel_select != FTMPC_KERNEL_WORKGROUP && cfg->N * cfg->NT <= 64 * ftmpc::wswk::nvt_of(h->ws_nb);
-    h->use_f64 = (cfg->dtype == FTMPC_DTYPE_F64) || (h->nb_max > 15 && !h->use_ws);
+    h->use_f64 = solve_f64 || (h->nb_max > 15 && !h->use_ws);
     h->use_wg = !h->use_f64 && h->nb_max > 10;
     // float64: through the wrench-space form where the thrusters outnumber the wrench components by enough to pay for the
     // assembly of K (ten or more thrusters), the wrench-space system fits sixteen tiles a side and three thruster variables
@@ -595,7 +598,6 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
     if (h->tset) {
         const char* why = nullptr;
         if (cfg->term_rows < 1 || cfg->term_rows > FTMPC_MAX_TERM_ROWS) why = "term_rows out of range 1..80";
-        else if (cfg->dtype != FTMPC_DTYPE_F64) why = "terminal_set needs dtype FTMPC_DTYPE_F64 (the fp32 kernels solve the box-constrained QP only)";
         else if (16 * h->nb_max > 256) why = "terminal_set needs N * NT <= 256";
         if (why) {
             delete h;
@@ -1092,8 +1094,8 @@ int ftmpc_solve_batch_device(ftmpc_handle* h, int64_t B, const double* x0, const
 // fits six tiles a side (N <= 16) and eight row slots per lane, and no terminal set is asked for; else on the float64 kernel
 // (dtype FTMPC_DTYPE_F64, kernel_select = FTMPC_KERNEL_DENSE, longer horizons, the terminal set).
 static bool hull_fp32(const ftmpc_handle* h, int32_t hull_rows) {
-    return h->cfg.dtype != FTMPC_DTYPE_F64 && h->cfg.kernel_select != FTMPC_KERNEL_DENSE && !h->cfg.terminal_set && 6 * h->cfg.N <= 96 &&
-           hull_rows <= 32 && (int64_t)h->cfg.N * 32 <= 64 * ftmpc::hullk::nvc_of(6);
+    return h->cfg.dtype != FTMPC_DTYPE_F64 && h->cfg.kernel_select != FTMPC_KERNEL_DENSE && 6 * h->cfg.N <= 96 && hull_rows <= 32 &&
+           (int64_t)h->cfg.N * 32 <= 64 * ftmpc::hullk::nvc_of(6) && (!h->cfg.terminal_set || h->cfg.term_rows <= 80);
 }
 
 // Validation, workspace and hull tables of the generalized-force formulation (shared by the one-step entry and the closed loop).
@@ -1114,7 +1116,8 @@ static int wrench_prepare(ftmpc_handle* h, int64_t B, const double* hull_A, int3
     if (hull_fp32(h, hull_rows)) {     // kernel 11: one wave per instance, H_w tiles in LDS; only the float64 gradient scratch is global
         if (!h->hull_slot) {
             int per = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_hull32_kernel<6>, 64, 0);
+            if (h->cfg.terminal_set) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_hull32_kernel<6, true>, 64, 0);
+            else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_hull32_kernel<6, false>, 64, 0);
             h->grid_hull = h->num_cu * (per > 0 ? per : 1);
             h->hull_slot_words = ftmpc::wswk::slot_words(6, N);
             if ((rc = grow(h, &h->hull_slot, (int64_t)h->grid_hull * h->hull_slot_words)) != FTMPC_OK) return rc;
@@ -1191,7 +1194,7 @@ static int wrench_enqueue(ftmpc_handle* h, int64_t B, int32_t hull_rows, bool ha
         q.base.tile_words = h->hull_slot_words;
         q.base.qhead = h->d_qctl + 7;
         q.base.dbg_inst = -1;
-        q.base.dbg_H = h->d_dbgH;
+        q.base.dbg_H = h->use_f64 ? reinterpret_cast<float*>(h->d_dbgH64) : h->d_dbgH;     // (diagnostic build: phase stamps)
         q.warmG = d_warmG;
         q.hullA = h->d_hullA;
         q.hull_set = has_set ? h->d_hullset : nullptr;
@@ -1199,8 +1202,13 @@ static int wrench_enqueue(ftmpc_handle* h, int64_t B, int32_t hull_rows, bool ha
         q.hull_rows = hull_rows;
         q.out_tau0 = h->d_tau0;
         q.out_G = h->d_G;
+        q.termA = h->cfg.terminal_set ? h->d_term : nullptr;
+        q.termb = h->cfg.terminal_set ? h->d_term + (int64_t)h->cfg.term_rows * 9 : nullptr;
+        q.term_rows = h->cfg.terminal_set ? h->cfg.term_rows : 0;
+        q.eN = h->d_eN;
         const int grid = (int)std::min<int64_t>(B, h->grid_hull);
-        hipLaunchKernelGGL(ftmpc::ftmpc_solve_hull32_kernel<6>, dim3(grid), dim3(64), 0, s, dcg, q);
+        if (h->cfg.terminal_set) hipLaunchKernelGGL((ftmpc::ftmpc_solve_hull32_kernel<6, true>), dim3(grid), dim3(64), 0, s, dcg, q);
+        else hipLaunchKernelGGL((ftmpc::ftmpc_solve_hull32_kernel<6, false>), dim3(grid), dim3(64), 0, s, dcg, q);
         HIP_TRY(h, hipGetLastError());
     } else {
     Solve64Params q;

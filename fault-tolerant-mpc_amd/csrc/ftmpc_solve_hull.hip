@@ -40,6 +40,11 @@ struct SolveHullParams {
     int32_t hull_rows;
     double* out_tau0;          // [B*6]
     double* out_G;             // [B*N*6] or nullptr
+    // terminal set (template TSET): rows term_A (e_N + GN d) <= term_b on the terminal tracking error (spiraling_mpc.py:199-202)
+    const double* termA;       // [term_rows*9]
+    const double* termb;       // [term_rows]
+    const double* eN;          // [B*9] terminal tracking error at the linearisation point (ftmpc_linearize.hip)
+    int32_t term_rows;         // <= 80
 };
 
 namespace hullk {
@@ -120,6 +125,10 @@ __device__ __forceinline__ double row_sum16_d(double x) {
     return x;
 }
 
+__device__ __forceinline__ double wave_sum_d(double x) { return quad_sum_d(row_sum16_d(x)); }
+__device__ __forceinline__ float wave_sum_t(float x) { return wave_sum(x); }
+__device__ __forceinline__ double wave_sum_t(double x) { return wave_sum_d(x); }
+
 // The two sweeps on the float64 factor (solve_reg's right-looking scheme): xv is an LDS vector in natural order, right-hand
 // side in, solution out.  With active rows the step's components along their normals are small differences of larger
 // entries: the slack steps need them to full relative accuracy, which fp32 sweeps do not give.
@@ -162,7 +171,7 @@ __device__ __forceinline__ void solve64(const f64x4 (&T)[NB * (NB + 1) / 2], con
 }
 }  // namespace hullk
 
-template <int NBW>
+template <int NBW, bool TSET = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) ftmpc_solve_hull32_kernel(const DeviceConsts C, const SolveHullParams Q) {
     using namespace wswk;
     const SolveParams& P = Q.base;
@@ -195,6 +204,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     __shared__ __attribute__((aligned(16))) float cw[NSTG * MHP];       // per-row values, row r of stage k at 32 k + r (zero beyond hull_rows)
     static_assert(NSTG * MHP >= MAX_NT * MAX_NT, "the stage block of H_w (build only) borrows the row-value array");
     float* const mtab = cw;
+    // terminal set: raw terminal sensitivity GN (9 x n, row r at NPADW r), rows of term_A (row i at 9 i), offsets, per-row values,
+    // the 9 x 9 core A_T' W A_T and a 9-vector (float64: late iterations)
+    constexpr int MTP = 80, NTR = 2;              // row slots, rows per lane
+    __shared__ __attribute__((aligned(16))) float s_GN[TSET ? 9 * NPADW : 4];
+    __shared__ __attribute__((aligned(16))) float s_tA[TSET ? MTP * 9 : 4];
+    __shared__ float s_tb[TSET ? MTP : 4], cwt[TSET ? MTP : 4];
+    __shared__ __attribute__((aligned(16))) double M9s[TSET ? 81 : 2], y9s[TSET ? 16 : 2];
     __shared__ float s_ctr[12];                                          // hull centre D (ub / 2 + stuck) | D stuck
     __shared__ double s_ctr64[6];                                        // the centre again, unrounded (output stage)
     __shared__ unsigned char s_stg[NPADW], s_thr[NPADW];
@@ -210,6 +226,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     double* const sbuf = reinterpret_cast<double*>(P.hscratch + (int64_t)blockIdx.x * P.tile_words);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const int MH = Q.hull_rows;
+    const int MT = TSET ? Q.term_rows : 0;
+    if constexpr (TSET) {
+        for (int i = lane0; i < MTP * 9; i += 64) s_tA[i] = (i < MT * 9) ? (float)Q.termA[i] : 0.f;
+        for (int i = lane0; i < MTP; i += 64) {
+            s_tb[i] = (i < MT) ? (float)Q.termb[i] : 1.f;
+            cwt[i] = 0.f;
+        }
+    }
 
     auto pull = [&]() {
         int i = 0;
@@ -321,9 +345,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 d[v] = s_ctr[g] - ubar[v];
             }
         }
+        f32x4 GNt[TSET ? NBW : 1];      // d x_N / d tau as operand tiles: register s of row group q < 3 = state component 3 s + q, the rest zero
 #define FTMPC_WB_PART 2
 #define FTMPC_WB_TILES htiles
+#define FTMPC_WB_TAIL                                                                                            \
+    if constexpr (TSET) {                                                                                       \
+        _Pragma("unroll") for (int X = 0; X < NBW; ++X) {                                                       \
+            GNt[X] = (lq < 3) ? f32x4{G[X].x, G[X].y, G[X].z, 0.f} : zero4;                                     \
+            if (lq < 3) {                                                                                       \
+                s_GN[(0 + lq) * NPADW + 16 * X + li] = G[X].x;                                                  \
+                s_GN[(3 + lq) * NPADW + 16 * X + li] = G[X].y;                                                  \
+                s_GN[(6 + lq) * NPADW + 16 * X + li] = G[X].z;                                                  \
+            }                                                                                                   \
+        }                                                                                                       \
+    }
 #include "ftmpc_wrench_build.inc"
+#undef FTMPC_WB_TAIL
 #undef FTMPC_WB_TILES
 #undef FTMPC_WB_PART
         wave_lds_fence();   // the dense images in the tile area are dead from here: Htl holds the -H_w' tiles
@@ -396,9 +433,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         bool hv[NVC];
         int hcw[NVC];      // slot 32 k + r of the row in the row-value array (k: stage, r: facet)
         float sh[NVC], zh[NVC];
+        float smax = 0.f, gmax = 0.f;
         {
             const float rmh = 1.0f / (float)MH;
-            float smax = 0.f, gmax = 0.f;
 #pragma unroll
             for (int v = 0; v < NVC; ++v) {
                 const int c = v * 64 + lane;
@@ -422,9 +459,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             for (int v = 0; v < NVW; ++v) gmax = fmaxf(gmax, wvalid[v] ? fabsf(grd[v]) : 0.f);
             gmax = wave_max(gmax);
             smax = wave_max(smax);
-            const float mu0 = fmaxf(0.02f * gmax * smax, 1e-3f);
-#pragma unroll
-            for (int v = 0; v < NVC; ++v) zh[v] = hv[v] ? mu0 / sh[v] : 0.f;
         }
         // rows of C x for a natural-order LDS vector, float64 (late iterations: the slack steps of active rows are small by
         // cancellation and need the step's components to full relative accuracy) or fp32
@@ -484,6 +518,89 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 x[v] = (e < n) ? (float)src[e] : 0.f;
             }
         };
+        // ---- terminal rows (TSET): row i = lane + 64 j of term_A (e_N + GN d) <= term_b ----
+        bool tvr[NTR];
+        int tri[NTR];
+        float st[NTR], zt[NTR], rpt[NTR];
+#pragma unroll
+        for (int j = 0; j < NTR; ++j) {
+            tri[j] = lane + 64 * j;
+            tvr[j] = TSET && tri[j] < MT;
+            tri[j] = tvr[j] ? tri[j] : 0;
+            st[j] = 1.f;
+            zt[j] = rpt[j] = 0.f;
+        }
+        // A_T (GN x) for a natural-order LDS vector (float64 or fp32)
+        auto term_rows = [&](auto xs, float (&ct)[NTR]) {
+            using XT = std::remove_cv_t<std::remove_pointer_t<decltype(xs)>>;
+            const int lane = lane_now();
+            XT part[9];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) part[r] = (XT)0;
+#pragma unroll
+            for (int v = 0; v < NVW; ++v) {
+                const int e = v * 64 + lane;
+                if (e < n) {
+                    const XT x = xs[e];
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) part[r] += (XT)s_GN[r * NPADW + e] * x;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 9; ++r) part[r] = hullk::wave_sum_t(part[r]);
+#pragma unroll
+            for (int j = 0; j < NTR; ++j) {
+                XT a = (XT)0;
+#pragma unroll
+                for (int r = 0; r < 9; ++r) a += (XT)s_tA[tri[j] * 9 + r] * part[r];
+                ct[j] = tvr[j] ? (float)a : 0.f;
+            }
+        };
+        // out += GN' (A_T' t)
+        auto term_cols = [&](const float (&tt)[NTR], float (&out)[NVW]) {
+            const int lane = lane_now();
+            float p9[9];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < NTR; ++j) a += tvr[j] ? s_tA[tri[j] * 9 + r] * tt[j] : 0.f;
+                p9[r] = wave_sum(a);
+            }
+#pragma unroll
+            for (int v = 0; v < NVW; ++v) {
+                const int e = v * 64 + lane;
+                if (e < n) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) a += s_GN[r * NPADW + e] * p9[r];
+                    out[v] += a;
+                }
+            }
+        };
+        if constexpr (TSET) {      // residual at the start point: slack max(residual, 0.1) and the primal residual the steps shrink
+            to_lds(d, xvp);
+            float ct[NTR];
+            term_rows((const float*)xvp, ct);
+#pragma unroll
+            for (int j = 0; j < NTR; ++j)
+                if (tvr[j]) {
+                    float res = s_tb[tri[j]] - ct[j];
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) res -= s_tA[tri[j] * 9 + r] * (float)Q.eN[inst * 9 + r];
+                    st[j] = fmaxf(res, 0.1f);
+                    rpt[j] = st[j] - res;
+                    smax = fmaxf(smax, st[j]);
+                }
+            smax = wave_max(smax);
+        }
+        {
+            const float mu0 = fmaxf(0.02f * gmax * smax, 1e-3f);
+#pragma unroll
+            for (int v = 0; v < NVC; ++v) zh[v] = hv[v] ? mu0 / sh[v] : 0.f;
+#pragma unroll
+            for (int j = 0; j < NTR; ++j) zt[j] = tvr[j] ? mu0 / st[j] : 0.f;
+        }
         STAMP(4);
 
         // ---------------- interior-point iterations over the hull rows ----------------
@@ -495,7 +612,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #endif
         int refines_left = (C.mu_refine > 0.0) ? ((NBW > 6 || FTMPC_HULL_REFRESH_ALL) ? C.max_iters + 1 : 1) : 0;
         float mu_last = 3.0e38f;
-        const float inv_m = 1.0f / (float)mhull;
+        const float inv_m = 1.0f / (float)(mhull + MT);
         for (int it = 0; it <= C.max_iters; ++it) {
             wave_lds_fence();
             lane = lane_now();
@@ -513,22 +630,37 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 --refines_left;
                 STAMP(8);
             }
-            float csum = 0.f;
+            float csum = 0.f, rpn = 0.f;
 #pragma unroll
             for (int v = 0; v < NVC; ++v) csum += hv[v] ? sh[v] * zh[v] : 0.f;
+#pragma unroll
+            for (int j = 0; j < NTR; ++j) {
+                csum += tvr[j] ? st[j] * zt[j] : 0.f;
+                rpn = fmaxf(rpn, tvr[j] ? fabsf(rpt[j]) : 0.f);
+            }
             const float mu = wave_sum(csum) * inv_m;
+            if constexpr (TSET) rpn = wave_max(rpn);
             mu_last = mu;
-            if (__builtin_amdgcn_readfirstlane(!(mu >= mu_stop))) {
-                status = (mu == mu) ? 0 : 2;
+            if (__builtin_amdgcn_readfirstlane(!(mu == mu) || !(rpn == rpn))) {
+                status = 2;
+                break;
+            }
+            if (__builtin_amdgcn_readfirstlane(mu < mu_stop && rpn < 1e-7f)) {
+                status = 0;
                 break;
             }
             if (it == C.max_iters) break;
             ++nit;
-            float rsh[NVC], wh[NVC];
+            float rsh[NVC], wh[NVC], rst[NTR], wt[NTR];
 #pragma unroll
             for (int v = 0; v < NVC; ++v) {
                 rsh[v] = __builtin_amdgcn_rcpf(sh[v]);
                 wh[v] = hv[v] ? zh[v] * rsh[v] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < NTR; ++j) {
+                rst[j] = __builtin_amdgcn_rcpf(st[j]);
+                wt[j] = tvr[j] ? zt[j] * rst[j] : 0.f;
             }
             // Early iterations run the factorisation and the sweeps in fp32 (chol_reg / solve_reg); from the iteration in which
             // a row weight z / s passes FTMPC_HULL_W64 on, in float64.  With weights up to that the stage blocks are no larger
@@ -547,6 +679,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 float wmax = 0.f;
 #pragma unroll
                 for (int v = 0; v < NVC; ++v) wmax = fmaxf(wmax, wh[v]);
+#pragma unroll
+                for (int j = 0; j < NTR; ++j) wmax = fmaxf(wmax, wt[j]);
                 wmax = wave_max(wmax);
                 in64 = in64 || __builtin_amdgcn_readfirstlane(wmax > FTMPC_HULL_W64);
                 fac64 = __builtin_amdgcn_readfirstlane(wmax > FTMPC_HULL_WF64);
@@ -557,6 +691,45 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             for (int v = 0; v < NVC; ++v)
                 if (hv[v]) cw[hcw[v]] = wh[v];
             wave_lds_fence();
+            // terminal rows: the 9 x 9 core A_T' W A_T (float64: products of the fp32 rows are exact) and  -P = -(core) GN  as operand tiles
+            f32x4 nPt[TSET ? NBW : 1];
+            f64x4 nP64[TSET ? NBW : 1];      // (unrounded: with weights ~1e7 the rounding of P to fp32 would be noise of order 1 on H_w again)
+            if constexpr (TSET) {
+#pragma unroll
+                for (int j = 0; j < NTR; ++j)
+                    if (tvr[j]) cwt[tri[j]] = wt[j];
+                wave_lds_fence();
+                if (lane < 45) {
+                    int r1 = 0;
+                    while ((r1 + 1) * (r1 + 2) / 2 <= lane) ++r1;
+                    const int r2 = lane - r1 * (r1 + 1) / 2;
+                    double acc = 0.0;
+                    for (int i = 0; i < MT; ++i) acc += (double)cwt[i] * ((double)s_tA[i * 9 + r1] * (double)s_tA[i * 9 + r2]);
+                    M9s[r1 * 9 + r2] = acc;
+                    M9s[r2 * 9 + r1] = acc;
+                }
+                wave_lds_fence();
+#pragma unroll
+                for (int X = 0; X < NBW; ++X) {
+                    f32x4 t = zero4;
+                    f64x4 t64 = {0.0, 0.0, 0.0, 0.0};
+                    if (lq < 3) {
+                        float gc[9];
+#pragma unroll
+                        for (int r = 0; r < 9; ++r) gc[r] = s_GN[r * NPADW + 16 * X + li];
+#pragma unroll
+                        for (int rr = 0; rr < 3; ++rr) {
+                            double a = 0.0;
+#pragma unroll
+                            for (int r = 0; r < 9; ++r) a += M9s[(3 * rr + lq) * 9 + r] * (double)gc[r];
+                            t[rr] = -(float)a;
+                            t64[rr] = -a;
+                        }
+                    }
+                    nPt[X] = t;
+                    nP64[X] = t64;
+                }
+            }
             bool ok = true;
             for (int attempt = 0; attempt < 2; ++attempt) {
                 ok = true;
@@ -598,6 +771,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                         const float* t = hb + tidx(I, J) * 256;
                         f64x4 r = {(double)t[0], (double)t[64], (double)t[128], (double)t[192]};
                         if (J == I || J == I - 1) gsub(I, J, r);
+                        if constexpr (TSET) {      // - (GN' core GN)' block: the float64 operands are the fp32 ones widened (same row order)
+                            const f64x4 gj = {(double)GNt[J].x, (double)GNt[J].y, (double)GNt[J].z, 0.0};
+                            r = hullk::mm_tn64(gj, nP64[I], r);
+                        }
                         return r;
                     };
                     hullk::chol64_col<NBW, 0>(seed, f64scr, lq, li, ok, T64, W64);
@@ -633,6 +810,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                                 const f32x2 hi2 = *reinterpret_cast<const f32x2*>(Sblk32 + off + 2);
                                 t -= f32x4{lo2.x, lo2.y, hi2.x, hi2.y};
                             }
+                            if constexpr (TSET) t = mm_tn(GNt[J], nPt[I], t);
                             Xt[tidx(I, J)] = t;
                         }
                     }
@@ -668,11 +846,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 break;
             }
             // (H_w + G) x = rhs; the rows C x of the solution
-            auto solve_rows = [&](const float (&rhs)[NVW], float (&ch)[NVC], float* xout) {
+            auto solve_rows = [&](const float (&rhs)[NVW], float (&ch)[NVC], float (&ctt)[NTR], float* xout) {
                 if (in64) {
                     to_lds(rhs, xv64);
                     hullk::solve64<NBW>(T64, W64, xv64, lq, li);
                     rows_Cx((const double*)xv64, ch);
+                    if constexpr (TSET) term_rows((const double*)xv64, ctt);
                     if (xout) from_lds((const double*)xv64, *reinterpret_cast<float(*)[NVW]>(xout));
                 } else {
                     f32x4 Tt[NTW], Wd[NBW];
@@ -683,6 +862,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                     to_lds(rhs, xvp);
                     solve_reg<NBW>(Tt, Wd, xvp, NBW, lane);
                     rows_Cx((const float*)xvp, ch);
+                    if constexpr (TSET) term_rows((const float*)xvp, ctt);
                     if (xout) from_lds((const float*)xvp, *reinterpret_cast<float(*)[NVW]>(xout));
                 }
             };
@@ -691,10 +871,26 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             float rhs[NVW], dd[NVW];
 #pragma unroll
             for (int v = 0; v < NVW; ++v) rhs[v] = -grd[v];
-            float ch[NVC];
-            solve_rows(rhs, ch, nullptr);
-            // ds = -C da,  dz = -z - z ds / s
-            float dzh_a[NVC], ap = 1.f, ad = 1.f;
+            float ch[NVC], ctt[NTR] = {0.f, 0.f};
+            if constexpr (TSET) {      // the terminal rows carry their primal residual: t = -z rp / s
+                float t0[NTR];
+#pragma unroll
+                for (int j = 0; j < NTR; ++j) t0[j] = tvr[j] ? -zt[j] * rpt[j] * rst[j] : 0.f;
+                term_cols(t0, rhs);
+            }
+            solve_rows(rhs, ch, ctt, nullptr);
+            // ds = -C da (terminal rows: -rp - C da),  dz = -z - z ds / s
+            float dzh_a[NVC], dst_a[NTR], dzt_a[NTR], ap = 1.f, ad = 1.f;
+#pragma unroll
+            for (int j = 0; j < NTR; ++j) {
+                dst_a[j] = dzt_a[j] = 0.f;
+                if (tvr[j]) {
+                    dst_a[j] = -rpt[j] - ctt[j];
+                    dzt_a[j] = -zt[j] - zt[j] * dst_a[j] * rst[j];
+                    if (dst_a[j] < 0.f) ap = fminf(ap, -st[j] * __builtin_amdgcn_rcpf(dst_a[j]));
+                    if (dzt_a[j] < 0.f) ad = fminf(ad, -zt[j] * __builtin_amdgcn_rcpf(dzt_a[j]));
+                }
+            }
 #pragma unroll
             for (int v = 0; v < NVC; ++v) {
                 dzh_a[v] = 0.f;
@@ -709,6 +905,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             csum = 0.f;
 #pragma unroll
             for (int v = 0; v < NVC; ++v) csum += hv[v] ? (sh[v] - ap * ch[v]) * (zh[v] + ad * dzh_a[v]) : 0.f;
+#pragma unroll
+            for (int j = 0; j < NTR; ++j) csum += tvr[j] ? (st[j] + ap * dst_a[j]) * (zt[j] + ad * dzt_a[j]) : 0.f;
             const float mu_aff = wave_sum(csum) * inv_m;
             float sigma = mu_aff / mu;
             sigma = fminf(fmaxf(sigma * sigma * sigma, 0.f), 1.f);
@@ -726,10 +924,33 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             cols_Ct(th, ct);
 #pragma unroll
             for (int v = 0; v < NVW; ++v) rhs[v] = -grd[v] + ct[v];
-            solve_rows(rhs, ch, dd);
-            float dzh[NVC];
+            float rct[NTR];
+            if constexpr (TSET) {      // rc = s z + ds_a dz_a - sigma mu,  t = -z + (rc - z rp) / s
+                float tt[NTR];
+#pragma unroll
+                for (int j = 0; j < NTR; ++j) {
+                    rct[j] = tt[j] = 0.f;
+                    if (tvr[j]) {
+                        rct[j] = st[j] * zt[j] + dst_a[j] * dzt_a[j] - sigma * mu;
+                        tt[j] = (dst_a[j] * dzt_a[j] - sigma * mu - zt[j] * rpt[j]) * rst[j];
+                    }
+                }
+                term_cols(tt, rhs);
+            }
+            solve_rows(rhs, ch, ctt, dd);
+            float dzh[NVC], dst[NTR], dzt[NTR];
             ap = 1e30f;
             ad = 1e30f;
+#pragma unroll
+            for (int j = 0; j < NTR; ++j) {
+                dst[j] = dzt[j] = 0.f;
+                if (tvr[j]) {
+                    dst[j] = -rpt[j] - ctt[j];
+                    dzt[j] = (-rct[j] - zt[j] * dst[j]) * rst[j];
+                    if (dst[j] < 0.f) ap = fminf(ap, -st[j] * __builtin_amdgcn_rcpf(dst[j]));
+                    if (dzt[j] < 0.f) ad = fminf(ad, -zt[j] * __builtin_amdgcn_rcpf(dzt[j]));
+                }
+            }
 #pragma unroll
             for (int v = 0; v < NVC; ++v) {
                 dzh[v] = 0.f;
@@ -754,6 +975,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 if (hv[v]) {
                     sh[v] -= ap * ch[v];
                     zh[v] += ad * dzh[v];
+                }
+#pragma unroll
+            for (int j = 0; j < NTR; ++j)
+                if (tvr[j]) {
+                    st[j] += ap * dst[j];
+                    zt[j] += ad * dzt[j];
+                    rpt[j] *= (1.f - ap);
                 }
             STAMP(10);
         }
@@ -805,6 +1033,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     }
 }
 
-template __global__ void ftmpc_solve_hull32_kernel<6>(const DeviceConsts, const SolveHullParams);
+template __global__ void ftmpc_solve_hull32_kernel<6, false>(const DeviceConsts, const SolveHullParams);
+template __global__ void ftmpc_solve_hull32_kernel<6, true>(const DeviceConsts, const SolveHullParams);      // + the terminal set
 
 }  // namespace ftmpc

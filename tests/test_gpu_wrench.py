@@ -189,10 +189,31 @@ def test_hull_with_more_facets_than_the_kernel_holds_is_refused():
         hull_tables(qo.QPConfig(N=20, NT=8).D, ub, stuck)
 
 
-def test_terminal_set_needs_the_float64_kernel():
-    with pytest.raises(ft_mpc_amd.FtmpcError) as e:
-        ft_mpc_amd.BatchedMPC(N=20, NT=8, dtype="f32", terminal_set=True)
-    assert "F64" in str(e.value)
+def test_terminal_set_on_an_fp32_handle(gpu_mpc_factory):
+    """An fp32 handle with the terminal set: the thruster form (box + terminal rows exist in float64 only) runs on the float64
+    kernel -- the bits of a float64 handle; the reference's two-stage form (hull rows + terminal set, spiraling_mpc.py:175-202)
+    runs on kernel 11 with the rank-9 terminal term: same reachable / unreachable verdicts as the float64 kernel, wrenches
+    within 1e-4 f_max where the set is reachable, some of them with active terminal rows."""
+    N, NT, B = 15, 16, 96
+    term = load_terminal().term_set
+    At, bt = term.A, term.b.reshape(-1)
+    x0, ub, stuck, xref = _near_terminal_set(B, N, NT, 2, 31, At, bt, scale=1.5)
+    xr = xref.reshape(-1, order="F")
+    m32 = gpu_mpc_factory(N=N, NT=NT, dtype="f32", max_iters=60, terminal_set=term)
+    m64 = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=60, terminal_set=term)
+    a, b = m32.solve(x0, ub, stuck, xr, return_U=True), m64.solve(x0, ub, stuck, xr, return_U=True)
+    assert np.array_equal(a["U"], b["U"], equal_nan=True) and np.array_equal(a["status"], b["status"])
+    w32, w64 = m32.solve_wrench(x0, ub, stuck, xr, return_G=True), m64.solve_wrench(x0, ub, stuck, xr, return_G=True)
+    has = w64["status"] != 3
+    ok64, ok32 = (w64["status"] == 0) & has, (w32["status"] == 0) & has
+    assert ok64.sum() >= 12 and (has & ~ok64).sum() >= 4                     # reachable and unreachable both occur
+    assert (ok64 == ok32).mean() >= 0.95, (ok64.sum(), ok32.sum())           # (borderline instances may fall either way)
+    both = ok64 & ok32
+    err = np.abs(w32["G"][both] - w64["G"][both]).max(axis=(1, 2)) / F_MAX
+    assert err.max() <= 1e-4, (err.max(), int(err.argmax()))
+    assert np.isfinite(w32["G"][has]).all()
+    free = gpu_mpc_factory(N=N, NT=NT, dtype="f32", max_iters=60).solve_wrench(x0, ub, stuck, xr, return_G=True)
+    assert (np.abs(free["G"][both] - w32["G"][both]).max(axis=(1, 2)) / F_MAX > 1e-3).sum() >= 4      # the rows matter
 
 
 def test_general_constraint_forms_against_golden(gpu_mpc_factory):

@@ -88,8 +88,9 @@ typedef struct ftmpc_config {
     double mu_stop;     /* stop when mean complementarity < mu_stop (<=0: library default) */
     /*
      * Terminal set  term_A (c_N[0:9] - xref_N) <= term_b  (the polytope of config/terminal.yaml, term_set; reference
-     * spiraling_mpc.py:199-202).  terminal_set != 0 adds these rows to the QP; they need the float64 kernel
-     * (dtype FTMPC_DTYPE_F64) and N * (number of variables per stage) <= 256.  An instance whose terminal set cannot
+     * spiraling_mpc.py:199-202).  terminal_set != 0 adds these rows to the QP; ftmpc_solve_batch then runs on the float64
+     * kernel whatever the dtype (N * (number of variables per stage) <= 256), ftmpc_solve_wrench_batch on the fp32
+     * one-wave kernel for dtype FTMPC_DTYPE_F32 and N <= 16.  An instance whose terminal set cannot
      * be reached within the horizon ends with FTMPC_STATUS_MAXITER / _NUMERIC (the reference logs IPOPT's failure
      * and carries on, spiraling_mpc.py:347-352).
      */
@@ -230,7 +231,8 @@ int ftmpc_solve_batch_device(ftmpc_handle* h, int64_t B,
  *     decision  tau_k in R^6, k < N: the TOTAL generalized force on the body ( = the reference's u_t + u_r + u_comp + D f_fault )
  *     cost      as ftmpc_solve_batch with ut_k = tau_k - ur_k - [f_virt;0] ( = the reference's deviation input u_t ), no rho term
  *     s.t.      hull_A tau_k <= hull_b  for every stage  [+ the terminal set when the handle's config has terminal_set != 0]
- * and u0 = argmin |u|^2 s.t. D u = tau_0 - D stuck, 0 <= u <= ub.  float64 kernel; needs 6 N <= 256 and N * hull_rows <= 1024.
+ * and u0 = argmin |u|^2 s.t. D u = tau_0 - D stuck, 0 <= u <= ub.  Needs 6 N <= 256 and N * hull_rows <= 1024.  dtype
+ * FTMPC_DTYPE_F32 with N <= 16: one wave per instance, wrenches within 1e-4 f_max; otherwise the float64 kernel (1e-7).
  *   hull_A    [n_sets][hull_rows*6] row-major facet normals, one table per fault INDEX SET (the normals do not depend on
  *             the fault intensities);  hull_set [B] table number of every instance (NULL: table 0 for all)
  *   hull_b    [B*hull_rows] facet offsets (they carry the intensities: b = n . D (ub/2 + stuck) + sum_i |n . D_i| ub_i / 2);

@@ -841,7 +841,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 }
             }
             if (__builtin_amdgcn_readfirstlane(!__all(ok))) {     // (float64 too runs out near mu ~ 1e-12 ... 1e-13)
-                status = (mu < 1e-7f) ? 0 : 2;
+                status = (mu < 1e-7f && rpn < 1e-7f) ? 0 : 2;      // (as the float64 kernel: the terminal rows must have closed their residual)
                 --nit;
                 break;
             }

@@ -42,3 +42,10 @@ print("instances above 1e-4:", int((e > 1e-4).sum()))
 for b in idx:
     sl = bt - At @ np.zeros(9)      # (placeholder: slack of the set itself)
     print("inst %5d err %.2e  iters f32 %2d f64 %2d  faults %s" % (b, np.abs(res["f32"]["G"][b] - res["f64"]["G"][b]).max() / 3.4, res["f32"]["iters"][b], res["f64"]["iters"][b], np.flatnonzero(ub[b] == 0)))
+# the three worst against the NumPy oracle (ipm_general with the same rows): which kernel is off?
+cfg = qo.QPConfig(N=N, NT=NT)
+for b in idx[:3]:
+    with np.errstate(all="ignore"):
+        _, T, st_, nit, qp = qo.solve_wrench_instance(cfg, x0[b], ub[b], stuck[b], xref, term_set=(At, bt), iters=60)
+    print("inst %5d oracle status %d iters %d | kernel 11 vs oracle %.2e, float64 kernel vs oracle %.2e (f_max)" %
+          (b, st_, nit, np.abs(res["f32"]["G"][b] - T).max() / 3.4, np.abs(res["f64"]["G"][b] - T).max() / 3.4))

@@ -174,12 +174,13 @@ def test_closed_loop_in_the_reference_two_stage_structure():
     own structure, spiraling_mpc.py:288-317) in the examples/sim.py scenario (10, 11 stuck fully on).  The loop settles on
     the micro-orbit like the thruster-space loop does; the two differ only by the allocation weight rho the
     thruster-space QP carries (the commands stay within a few percent of f_max of each other)."""
-    def run(formulation):
+    def run(formulation, **kw):
         m = SystemModel(0.1)
         for i in (10, 11):
             m.set_fault(BrokenThruster(i, 1.0))
         sm = SpiralModel.from_system_model(m)
-        ctrl = SpiralingController(sm, dict(PARAMS, formulation=formulation), ControllerDebug(), quiet=True)
+        extra = {k: kw.pop(k) for k in ("terminal_set",) if k in kw}
+        ctrl = SpiralingController(sm, dict(PARAMS, formulation=formulation, **extra), ControllerDebug(), quiet=True, **kw)
         ctrl.load_trajectory("hover", 30)
         us = []
 
@@ -202,6 +203,10 @@ def test_closed_loop_in_the_reference_two_stage_structure():
     assert np.linalg.norm(c_w[0:6]) < 0.6 * e0 and np.linalg.norm(c_t[0:6]) < 0.6 * e0      # both close in on the reference
     assert np.abs(c_w[6:9] - [0, 0, 0.6]).max() < 0.1
     assert np.abs(c_w[0:9] - c_t[0:9]).max() < 0.1
+    # the reference's full formulation -- hull rows AND the terminal set -- on kernel 11 (fp32 handle): same loop, same place
+    c_k, u_k, _ = run("wrench", dtype="f32", terminal_set=True)
+    assert (u_k >= -1e-9).all() and (u_k <= m.u_ub_physical + 1e-9).all() and (u_k[:, [10, 11]] == 0).all()
+    assert np.abs(c_k[0:9] - c_w[0:9]).max() < 0.1
 
 
 @pytest.mark.parametrize("dtype,tol", [("f64", 1e-8), ("f32", 2e-5)])      # f32: kernel 11 (an x perturbed by 1e-15 moves an fp32 iterate by 1e-7)

@@ -70,7 +70,8 @@ struct ftmpc_handle {
     int32_t* d_qctl = nullptr;
     // Hint from the previous step: the list lengths it ended with, copied to pinned memory behind its kernels.  A list that was
     // empty then gets a SMALL grid now (the kernels are persistent: any grid drains any list, a small one just slower if the hint
-    // is wrong) -- most batches fill one list, and an idle launch of a full grid costs 0.05 - 0.09 ms.
+    // is wrong: one step, then the hint is right again) -- most batches fill one list, and an idle launch of a full grid costs
+    // 0.05 - 0.09 ms.
     int32_t* h_qcnt = nullptr;      // pinned, 4 ints
     hipEvent_t ev_qcnt = nullptr;
     bool qcnt_pending = false, qcnt_valid = false;
@@ -299,7 +300,7 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
     }
     auto grid_for = [&](int v, int64_t full) -> int {   // list v: the full persistent grid, or a small one when the list was empty last step
         const int64_t g = std::min<int64_t>(B, full);
-        return (int)((h->qcnt_valid && !capturing && h->last_cnt[v] == 0) ? std::min<int64_t>(g, 128) : g);
+        return (int)((h->qcnt_valid && !capturing && h->last_cnt[v] == 0) ? std::min<int64_t>(g, h->num_cu) : g);     // (one workgroup per CU)
     };
     const int lin_blocks = (int)((B + 63) / 64);
     for (bool& u : h->ev_used) u = false;

@@ -70,6 +70,7 @@ _AB_CASES = [  # (name, N, NT, faults, B, dtype, kernel_select): one batch per k
     ("config5_f64_dense", 40, 16, 2, 64, "f64", "dense"),
     ("refvehicle_f64", 15, 16, 2, 256, "f64", "dense"),
     ("refvehicle_hull32", 15, 16, 2, 512, "f32", "wrench"),      # kernel 11 through ftmpc_solve_wrench_batch
+    ("refvehicle_hull32_tset", 15, 16, 2, 256, "f32", "wrench_tset"),      # ... with the terminal set (its own instantiation)
 ]
 
 _AB_SCRIPT = r"""
@@ -80,14 +81,20 @@ cases = eval(sys.argv[3])
 out = {}
 for name, N, NT, nf, B, dtype, sel in cases:
     x0, ub, stuck, xref = ft_mpc_amd.make_synthetic_batch(B, N, NT, nf, 7300 + N + NT + nf)
-    if sel == "wrench":
-        mpc = ft_mpc_amd.BatchedMPC(N=N, NT=NT, dtype=dtype)
+    if sel.startswith("wrench"):
+        kw = {}
+        if sel == "wrench_tset":
+            from ft_mpc_amd.controllers.tools.terminal_ingredients import load_terminal
+            kw = dict(terminal_set=load_terminal().term_set, max_iters=60)
+            x0[:, 0:6] *= 0.02                           # near the reference: the set is reachable for most
+        mpc = ft_mpc_amd.BatchedMPC(N=N, NT=NT, dtype=dtype, **kw)
         r = mpc.solve_wrench(x0, ub, stuck, np.ascontiguousarray(xref.reshape(-1, order="F")), return_G=True)
         mpc.close()
-        keep = r["status"] != 3                      # (no hull: the healthy thrusters do not span R^6)
+        keep = (r["status"] != 3) if sel == "wrench" else (r["status"] == 0)      # (3: no hull; with the set: the reachable ones)
         for k in ("u0", "G", "tau0", "iters"):
             out[name + "/" + k] = r[k][keep]
         out[name + "/status"] = r["status"][keep]
+        out[name + "/all_status"] = r["status"] * 0 + (r["status"] == 0)      # (bitwise the same verdicts on both builds)
         continue
     mpc = ft_mpc_amd.BatchedMPC(N=N, NT=NT, dtype=dtype, kernel_select=sel)
     r = mpc.solve(x0, ub, stuck, np.ascontiguousarray(xref.reshape(-1, order="F")), return_U=True)

@@ -1091,9 +1091,10 @@ int ftmpc_solve_batch_device(ftmpc_handle* h, int64_t B, const double* x0, const
                    reinterpret_cast<hipStream_t>(stream), -1);
 }
 
-// The generalized-force formulation runs on kernel 11 (fp32, one wave per instance) when the handle computes in fp32, the problem
-// fits six tiles a side (N <= 16) and eight row slots per lane, and no terminal set is asked for; else on the float64 kernel
-// (dtype FTMPC_DTYPE_F64, kernel_select = FTMPC_KERNEL_DENSE, longer horizons, the terminal set).
+// The generalized-force formulation runs on kernel 11 (fp32, one wave per instance; hull rows, and the terminal set when the
+// handle has one) when the handle computes in fp32 and the problem fits six tiles a side (N <= 16) and eight row slots per
+// lane; the instances kernel 11 does not certify, and everything else (dtype FTMPC_DTYPE_F64, kernel_select =
+// FTMPC_KERNEL_DENSE, longer horizons), on the float64 kernel.
 static bool hull_fp32(const ftmpc_handle* h, int32_t hull_rows) {
     return h->cfg.dtype != FTMPC_DTYPE_F64 && h->cfg.kernel_select != FTMPC_KERNEL_DENSE && 6 * h->cfg.N <= 96 && hull_rows <= 32 &&
            (int64_t)h->cfg.N * 32 <= 64 * ftmpc::hullk::nvc_of(6) && (!h->cfg.terminal_set || h->cfg.term_rows <= 80);
@@ -1123,7 +1124,10 @@ static int wrench_prepare(ftmpc_handle* h, int64_t B, const double* hull_A, int3
             h->hull_slot_words = ftmpc::wswk::slot_words(6, N);
             if ((rc = grow(h, &h->hull_slot, (int64_t)h->grid_hull * h->hull_slot_words)) != FTMPC_OK) return rc;
         }
-    } else if (!h->gHs) {   // per-workgroup slots of the 6N-variable problem (separate from the thruster-space slots of this handle)
+    }
+    // the float64 kernel's slots: it solves the whole batch where kernel 11 does not apply, and otherwise the instances kernel 11
+    // hands over (weakly active rows / hull and terminal rows active together: see SolveHullParams::fb_list)
+    if (!h->gHs) {   // per-workgroup slots of the 6N-variable problem (separate from the thruster-space slots of this handle)
         const int nbg = (6 * N + 15) / 16;
         h->npad_gen = 16 * nbg;
         h->grid_gen = h->num_cu;
@@ -1150,7 +1154,7 @@ static int wrench_prepare(ftmpc_handle* h, int64_t B, const double* hull_A, int3
         h->cap_wrench = 0;   // (a failed growth must not leave a stale capacity)
         if ((rc = grow(h, &h->d_hullb, B * FTMPC_MAX_HULL_ROWS)) != FTMPC_OK || (rc = grow(h, &h->d_hullset, B)) != FTMPC_OK ||
             (rc = grow(h, &h->d_warmG, B * N * 6)) != FTMPC_OK || (rc = grow(h, &h->d_tau0, B * 6)) != FTMPC_OK ||
-            (rc = grow(h, &h->d_G, B * N * 6)) != FTMPC_OK || (rc = grow(h, &h->d_taud, B * 6)) != FTMPC_OK || (rc = grow(h, &h->d_ast2, 2 * B)) != FTMPC_OK)
+            (rc = grow(h, &h->d_G, B * N * 6)) != FTMPC_OK || (rc = grow(h, &h->d_taud, B * 6)) != FTMPC_OK || (rc = grow(h, &h->d_ast2, 3 * B)) != FTMPC_OK)      // allocation status | iterations | kernel 11's hand-over list
             return rc;
         h->cap_wrench = B;
     }
@@ -1208,10 +1212,15 @@ static int wrench_enqueue(ftmpc_handle* h, int64_t B, int32_t hull_rows, bool ha
         q.term_rows = h->cfg.terminal_set ? h->cfg.term_rows : 0;
         q.eN = h->d_eN;
         const int grid = (int)std::min<int64_t>(B, h->grid_hull);
+        q.fb_list = h->d_ast2 + 2 * h->cap_wrench;
+        q.fb_count = h->d_qctl;      // (the generalized-force path builds no work lists: the counter of list 0 is free)
         if (h->cfg.terminal_set) hipLaunchKernelGGL((ftmpc::ftmpc_solve_hull32_kernel<6, true>), dim3(grid), dim3(64), 0, s, dcg, q);
         else hipLaunchKernelGGL((ftmpc::ftmpc_solve_hull32_kernel<6, false>), dim3(grid), dim3(64), 0, s, dcg, q);
         HIP_TRY(h, hipGetLastError());
-    } else {
+    }
+    {
+    // the float64 kernel: the whole batch, or what kernel 11 handed over
+    const bool handed = hull_fp32(h, hull_rows);
     Solve64Params q;
     std::memset(&q, 0, sizeof(q));
     q.base.B = B;
@@ -1220,6 +1229,8 @@ static int wrench_enqueue(ftmpc_handle* h, int64_t B, int32_t hull_rows, bool ha
     q.base.out_u0 = h->d_u0;
     q.base.status = h->d_status; q.base.iters = h->d_iters;
     q.base.dbg_inst = -1;
+    q.base.qlist = handed ? h->d_ast2 + 2 * h->cap_wrench : nullptr;
+    q.base.qcount = handed ? h->d_qctl : nullptr;
     q.Hs = h->gHs; q.Ls = h->gLs; q.Eall = h->gEall;
     q.tile_doubles = h->tile_doubles_gen;
     q.e_doubles = h->e_doubles_gen;

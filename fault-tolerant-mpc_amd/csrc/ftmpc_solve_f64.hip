@@ -233,7 +233,11 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4 && MODE == 0) ? 2 :
     double* Ls = Q.Ls + (int64_t)blockIdx.x * Q.tile_doubles;
     double* Eall = Q.Eall + (int64_t)blockIdx.x * Q.e_doubles;
 
-    for (int64_t inst = blockIdx.x; inst < P.B; inst += gridDim.x) {
+    // instances: the whole batch, or (P.qlist != nullptr) the *P.qcount entries of a list an earlier kernel on the stream wrote
+    // -- kernel 11 hands over the instances whose fp32 answer it does not certify (ftmpc_solve_hull.hip)
+    const int64_t n_inst = P.qlist ? (int64_t)*P.qcount : P.B;
+    for (int64_t qi = blockIdx.x; qi < n_inst; qi += gridDim.x) {
+        const int64_t inst = P.qlist ? (int64_t)P.qlist[qi] : qi;
         __syncthreads();
         S64_DECL;
         S64_START();
@@ -1218,28 +1222,34 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4 && MODE == 0) ? 2 :
             };
             auto pos_step = [](double sv, double dsv) { return (dsv < 0.0) ? -sv / dsv : 1e300; };
 
-            // gradient at the start point: H d + g (tile mat-vec; afterwards the gradient follows the step)
-            __syncthreads();
-            if (tid < npad) dv[xp] = val ? d : 0.0;
-            __syncthreads();
-            for (int I = wave; I < nb; I += NWAVE) {
-                double a = 0.0;
-                for (int J = 0; J < nb; ++J) {
-                    if (J <= I) {
-                        const f64x4 t4 = ld4(Hs + (int64_t)t64idx(I, J) * 256 + 16 * li + 4 * lq);
-                        const double* d4 = dv + 16 * J + 4 * lq;
-                        a += t4.x * d4[0] + t4.y * d4[1] + t4.z * d4[2] + t4.w * d4[3];
-                    } else {
-                        const double* t = Hs + (int64_t)t64idx(J, I) * 256;
+            // (H x)_e for a vector held one element per thread: tile mat-vec over the global Hessian tiles.  The gradient
+            // follows every step through H dd itself (as the oracle's does): with row weights z / s ~ 1e7 and more the Newton
+            // identity H dd = rhs - C' (w . C dd) is a difference of huge numbers and carries the solve's residual.
+            auto h_times = [&](double xval) -> double {
+                __syncthreads();
+                if (tid < npad) dv[xp] = val ? xval : 0.0;
+                __syncthreads();
+                for (int I = wave; I < nb; I += NWAVE) {
+                    double a = 0.0;
+                    for (int J = 0; J < nb; ++J) {
+                        if (J <= I) {
+                            const f64x4 t4 = ld4(Hs + (int64_t)t64idx(I, J) * 256 + 16 * li + 4 * lq);
+                            const double* d4 = dv + 16 * J + 4 * lq;
+                            a += t4.x * d4[0] + t4.y * d4[1] + t4.z * d4[2] + t4.w * d4[3];
+                        } else {
+                            const double* t = Hs + (int64_t)t64idx(J, I) * 256;
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) a += t[t64off(4 * lq + rr, li)] * dv[16 * J + rr * 4 + lq];
+                            for (int rr = 0; rr < 4; ++rr) a += t[t64off(4 * lq + rr, li)] * dv[16 * J + rr * 4 + lq];
+                        }
                     }
+                    a = quad_sum64(a);
+                    if (lq == 0) xv[16 * I + li] = a;
                 }
-                a = quad_sum64(a);
-                if (lq == 0) xv[16 * I + li] = a;
-            }
-            __syncthreads();
-            grd = (tid < npad && val) ? xv[tid] + gv[0] : 0.0;
+                __syncthreads();
+                return (tid < npad && val) ? xv[tid] : 0.0;
+            };
+            // gradient at the start point: H d + g
+            grd = h_times(d) + ((tid < npad && val) ? gv[0] : 0.0);
             {
                 // terminal rows: residual at the start point, slack and primal residual
                 double cl, cu, ch[NVC], ct;
@@ -1412,11 +1422,7 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4 && MODE == 0) ? 2 :
                 }
                 ap = fmin(1.0, 0.9995 * wg_min(ap, red, tid));
                 ad = fmin(1.0, 0.9995 * wg_min(ad, red, tid));
-                // H dd = rhs - C' (w . (C dd)),  C dd = -ds - rp
-                double whc[NVC];
-#pragma unroll
-                for (int v = 0; v < NVC; ++v) whc[v] = hv[v] ? wh[v] * (-dsh[v]) : 0.0;
-                const double hdd = rhs - cols_Ct(wl * (-dsl), wu * (-dsu), whc, tv ? wt * (-dst - rpt) : 0.0);
+                const double hdd = h_times(dd);
                 if (val) {
                     grd += ap * hdd;
                     d += ap * dd;
@@ -1440,6 +1446,125 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4 && MODE == 0) ? 2 :
                 }
             }
             S64(7);
+            // ---------------- active-set polish (oracle/qp_oracle.py:polish_general is the mirror) ----------------
+            // An interior-point iterate at mu 1e-10 is up to 7e-5 f_max from the exact solution where rows are weakly active
+            // (z ~ s ~ 1e-5).  Active set A = {z > s}; per round the equality-constrained problem on A by two steps of the method
+            // of multipliers with penalty W_i = 1e6 max diag(H) / |c_i|^2 (one factorisation of H + C_A' W C_A -- the Newton matrix's
+            // own shape -- and one solve per step), then the signs are checked: a row of A with a negative multiplier leaves, a
+            // violated row outside enters, and the round is repeated until nothing changes.  Not verified within three rounds
+            // (or a factorisation that breaks down): the interior-point iterate is returned as before.
+            if (status == 0) {
+                constexpr double PW0 = 1e6, PRES_TOL = 1e-10;
+                double hd = 0.0;
+                if (tid < npad && val) hd = fabs(Hs[(int64_t)t64idx(tid >> 4, tid >> 4) * 256 + t64off(tid & 15, tid & 15)]);
+                const double pw = PW0 * wg_max(hd, red, tid);
+                double hh[NVC], wph[NVC], wpt = 0.0, ht = 0.0;
+                const double hl = ubar0, hu = ub0 - ubar0;
+                {
+                    double cl, cu, ch[NVC], ct;
+                    rows_Cx(ubar0, cl, cu, ch, ct);      // A_h ubar_k: offsets of the hull rows in d
+#pragma unroll
+                    for (int v = 0; v < NVC; ++v) {
+                        hh[v] = 0.0;
+                        wph[v] = 0.0;
+                        if (hv[v]) {
+                            hh[v] = Q.hullb[inst * MH + hr[v]] - ch[v];
+                            double a2 = 0.0;
+#pragma unroll
+                            for (int g = 0; g < 6; ++g) a2 += s_hA[hr[v] * 6 + g] * s_hA[hr[v] * 6 + g];
+                            wph[v] = pw / fmax(a2, 1e-300);
+                        }
+                    }
+                    if constexpr (TSET) {
+                        if (tv) {
+                            ht = s_tbv[tid];
+#pragma unroll
+                            for (int r = 0; r < 9; ++r) ht -= s_tA[tid * 9 + r] * Q.eN[inst * 9 + r];
+                            double c2 = 0.0;
+                            for (int e = 0; e < npad; ++e) {
+                                double c = 0.0;
+#pragma unroll
+                                for (int r = 0; r < 9; ++r) c += s_tA[tid * 9 + r] * GNs[r * npad + e];
+                                c2 += c * c;
+                            }
+                            wpt = pw / fmax(c2, 1e-300);
+                        }
+                    }
+                }
+                const double d_ipm = d;
+                bool al = !GEN && val && zl > sl, au = !GEN && val && zu > su, at = tv && zt > st, ah[NVC];
+                zl = al ? zl : 0.0;
+                zu = au ? zu : 0.0;
+                zt = at ? zt : 0.0;
+#pragma unroll
+                for (int v = 0; v < NVC; ++v) {
+                    ah[v] = hv[v] && zh[v] > sh[v];
+                    zh[v] = ah[v] ? zh[v] : 0.0;
+                }
+                bool verified = false;
+                for (int rd = 0; rd < 3 && !verified; ++rd) {
+                    const double wl = al ? pw : 0.0, wu = au ? pw : 0.0, wt = at ? wpt : 0.0;
+                    double wh[NVC];
+#pragma unroll
+                    for (int v = 0; v < NVC; ++v) wh[v] = ah[v] ? wph[v] : 0.0;
+                    form_kkt(wl, wu, wh, wt);
+                    factor();
+                    __syncthreads();
+                    if (s_flag == 0) break;
+                    ++nit;
+                    double cl, cu, ch[NVC], ct;
+                    for (int in = 0; in < 2; ++in) {
+                        const double gd = h_times(d) + ((tid < npad && val) ? gv[0] : 0.0);
+                        rows_Cx(d, cl, cu, ch, ct);
+                        const double s_l = hl - cl, s_u = hu - cu, s_t = ht - ct;
+                        double s_h[NVC], th[NVC];
+#pragma unroll
+                        for (int v = 0; v < NVC; ++v) {
+                            s_h[v] = hh[v] - ch[v];
+                            th[v] = ah[v] ? wh[v] * s_h[v] - zh[v] : 0.0;
+                        }
+                        const double rhs = -gd + cols_Ct(al ? wl * s_l - zl : 0.0, au ? wu * s_u - zu : 0.0, th, at ? wt * s_t - zt : 0.0);
+                        __syncthreads();
+                        if (tid < npad) xv[xp] = val ? rhs : 0.0;
+                        __syncthreads();
+                        solve(std::integral_constant<int, SWEEP_ROWS>{});
+                        __syncthreads();
+                        const double dl = (tid < npad && val) ? xv[xp] : 0.0;
+                        rows_Cx(dl, cl, cu, ch, ct);
+                        if (al) zl += wl * (cl - s_l);
+                        if (au) zu += wu * (cu - s_u);
+                        if (at) zt += wt * (ct - s_t);
+#pragma unroll
+                        for (int v = 0; v < NVC; ++v)
+                            if (ah[v]) zh[v] += wh[v] * (ch[v] - s_h[v]);
+                        if (val) d += dl;
+                    }
+                    rows_Cx(d, cl, cu, ch, ct);
+                    double changed = 0.0;
+                    auto check = [&](bool& a, double& lam, bool row, double res) {
+                        if (a && lam < 0.0) {
+                            a = false;
+                            lam = 0.0;
+                            changed = 1.0;
+                        } else if (!a && row && res < -PRES_TOL) {
+                            a = true;
+                            lam = 0.0;
+                            changed = 1.0;
+                        }
+                    };
+                    check(al, zl, !GEN && val, hl - cl);
+                    check(au, zu, !GEN && val, hu - cu);
+                    check(at, zt, tv, ht - ct);
+#pragma unroll
+                    for (int v = 0; v < NVC; ++v) check(ah[v], zh[v], hv[v], hh[v] - ch[v]);
+                    verified = wg_max(changed, red, tid) == 0.0;
+                }
+                if (!verified) d = d_ipm;
+                else if constexpr (!GEN) {      // (the output stage reads the thruster force off the slacks)
+                    sl = fmax(hl + d, 0.0);
+                    su = fmax(hu - d, 0.0);
+                }
+            }
             // ---------------- outputs ----------------
             __syncthreads();
             if constexpr (GEN) {

@@ -45,6 +45,13 @@ struct SolveHullParams {
     const double* termb;       // [term_rows]
     const double* eN;          // [B*9] terminal tracking error at the linearisation point (ftmpc_linearize.hip)
     int32_t term_rows;         // <= 80
+    // Instances this kernel does not certify -- a weakly active row at termination (z / s within 1e-3 .. 1e3: there an
+    // interior-point iterate at mu 1e-10 is up to 7e-5 f_max from the exact solution, and fp32 cannot run the active-set polish
+    // that removes it), or hull and terminal rows active together (nearly degenerate problems: rounding their rows to fp32
+    // alone moves the solution by 2-3e-5 f_max) -- are appended here and solved again by the float64 kernel with its polish,
+    // which the host enqueues behind this one on the same stream.  nullptr: nothing is handed over.
+    int32_t* fb_list;          // [B]
+    int32_t* fb_count;         // [1], zeroed by the host
 };
 
 namespace hullk {
@@ -984,6 +991,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                     rpt[j] *= (1.f - ap);
                 }
             STAMP(10);
+        }
+        // ---------------- certificate: strict complementarity, and not hull and terminal rows active together ----------------
+        if (Q.fb_list && status == 0) {
+            bool weak = false, acth = false, actt = false;
+#pragma unroll
+            for (int v = 0; v < NVC; ++v)
+                if (hv[v]) {
+                    weak = weak || (zh[v] < 1e3f * sh[v] && sh[v] < 1e3f * zh[v]);
+                    acth = acth || zh[v] > sh[v];
+                }
+#pragma unroll
+            for (int j = 0; j < NTR; ++j)
+                if (tvr[j]) {
+                    weak = weak || (zt[j] < 1e3f * st[j] && st[j] < 1e3f * zt[j]);
+                    actt = actt || zt[j] > st[j];
+                }
+            const bool hand_over = __any(weak) || (__any(acth) && __any(actt));
+            if (hand_over && lane_now() == 0) Q.fb_list[atomicAdd(Q.fb_count, 1)] = (int32_t)inst;
         }
         // ---------------- outputs ----------------
         lane = lane_now();

@@ -117,7 +117,7 @@ def sim_env_fixture():
     off: pins set_initial_state, the step order (control -> dynamics -> noise -> renormalise) and the
     loop count of run_simulation.  tests/test_host_mirror.py compares the mirror's loop with it."""
     sys.path.insert(0, str(REF))
-    sys.path.insert(0, str(ROOT / "fault-tolerant-mpc_amd"))
+    sys.path.insert(0, str(ROOT / "fault-tolerant-mpc_amd"))   # (this one fixture pins the host mirror's seam classes under the REFERENCE's loop)
     from ft_mpc.simulation.sim_env import SimulationEnvironment as RefEnv
     from ft_mpc_amd.controllers.dummy_controller import Controller
     from ft_mpc_amd.models.sys_model import SystemModel
@@ -199,11 +199,37 @@ def qp_fixtures_large():
         print(f"qp_{name}.npz  kkt max {kkt.max():.1e}", flush=True)
 
 
+def _near_terminal_set(x0, At, bt, scale, seed):
+    """Moves the states so that the orbit-centre tracking error starts on `scale` times the boundary of the terminal set."""
+    from oracle import refmath as rm
+    rng = np.random.default_rng(seed)
+    r = rm.spiral_r()
+    for b in range(x0.shape[0]):
+        e = rng.standard_normal(9)
+        e *= scale / max((At @ e / bt).max(), 1e-9)
+        R = rm.rot(x0[b, 6:10])
+        w = rm.OMEGA_DES + e[6:9]
+        x0[b, 0:3] = e[0:3] - R.T @ r                    # robot_to_center (spiral_model.py:103-109) inverted
+        x0[b, 3:6] = e[3:6] - R.T @ np.cross(w, r)
+        x0[b, 10:13] = w
+
+
+def _certified(qo, qp, st):
+    """max KKT residual of the (polished) oracle solution and its distance to the active-set certificate (f_max)."""
+    if st != 0:
+        return np.nan, np.nan
+    cert = max(qo.kkt_general(qp["H"], qp["g"], qp["C"], qp["h"], qp["d"], qp["z"]))
+    dx, _ = qo.solve_general_exact(qp["H"], qp["g"], qp["C"], qp["h"], qp["d"], qp["z"], qp["s"])
+    return cert, (np.abs(dx - qp["d"]).max() / 3.4 if dx is not None else np.nan)
+
+
 def general_constraint_fixtures():
     """The reference's own formulation: 6-D generalized-force QP with the input-hull rows
-    (spiraling_mpc.py:133-137,175-177) and the thruster-space QP with the 72-row terminal set (:199-202), solved by
-    oracle/qp_oracle.py:ipm_general and kept only where the solver-independent KKT certificate (kkt_general) holds;
-    unreachable terminal sets are recorded as such (status != 0)."""
+    (spiraling_mpc.py:133-137,175-177), the thruster-space QP with the 72-row terminal set (:199-202), and the two together
+    (hull rows + terminal set: what the reference's NLP always carries), solved by oracle/qp_oracle.py:ipm_general WITH its
+    active-set polish and kept only where the solver-independent certificates hold (kkt_general; distance to the
+    primal-dual active-set solution solve_general_exact); unreachable terminal sets are recorded as such (status != 0).
+    The terminal set is read from the REFERENCE's data file by the oracle's own parser (no product code in here)."""
     from oracle import qp_oracle as qo
     from oracle import refmath as rm
     N, NT, cnt = 15, 16, 16
@@ -213,48 +239,67 @@ def general_constraint_fixtures():
     tau0 = np.zeros((cnt, 6))
     st = np.zeros(cnt, np.int32)
     cert = np.zeros(cnt)
+    dist = np.zeros(cnt)
     for b in range(cnt):
         tau0[b], G[b], st[b], _, qp = qo.solve_wrench_instance(cfg, x0[b], ub[b], stuck[b], xref)
-        cert[b] = max(qo.kkt_general(qp["H"], qp["g"], qp["C"], qp["h"], qp["d"], qp["z"]))
-    assert (st == 0).all() and cert.max() < 1e-4, (st, cert)
+        cert[b], dist[b] = _certified(qo, qp, st[b])
+    assert (st == 0).all() and cert.max() < 1e-8 and dist.max() < 1e-8, (st, cert, dist)
     np.savez_compressed(OUT / "qp_wrench_hull_n15.npz", N=N, NT=NT, x0=x0, ub=ub, stuck=stuck, xref=xref, G=G, tau0=tau0, status=st, kkt=cert, D=cfg.D)
-    print(f"qp_wrench_hull_n15.npz  kkt max {cert.max():.1e}", flush=True)
+    print(f"qp_wrench_hull_n15.npz  kkt max {cert.max():.1e}  vs active-set certificate {dist.max():.1e} f_max", flush=True)
     # terminal set: states placed around the boundary of the set, so that reachable and unreachable instances both occur
-    from ft_mpc_amd.controllers.tools.terminal_ingredients import load_terminal
-    term = load_terminal().term_set
-    At, bt = np.asarray(term.A, float), np.asarray(term.b, float).reshape(-1)
+    _, _, At, bt = rm.parse_terminal_yaml(open(REF / "ft_mpc/config/terminal.yaml").read())
     N, NT, cnt = 20, 8, 24
     cfg = qo.QPConfig(N=N, NT=NT)
     x0, ub, stuck, xref = qo.make_batch(cnt, N, NT, 2, 12)
-    rng = np.random.default_rng(13)
-    r = rm.spiral_r()
-    for b in range(cnt):
-        e = rng.standard_normal(9)
-        e *= 2.0 / max((At @ e / bt).max(), 1e-9)
-        R = rm.rot(x0[b, 6:10])
-        w = rm.OMEGA_DES + e[6:9]
-        x0[b, 0:3] = e[0:3] - R.T @ r
-        x0[b, 3:6] = e[3:6] - R.T @ np.cross(w, r)
-        x0[b, 10:13] = w
+    _near_terminal_set(x0, At, bt, 2.0, 13)
     U = np.zeros((cnt, N, NT))
     st = np.zeros(cnt, np.int32)
     cert = np.zeros(cnt)
+    dist = np.zeros(cnt)
     with np.errstate(all="ignore"):
         for b in range(cnt):
             _, U[b], st[b], _, qp = qo.solve_box_terminal_instance(cfg, x0[b], ub[b], stuck[b], xref, (At, bt), iters=60)
-            cert[b] = max(qo.kkt_general(qp["H"], qp["g"], qp["C"], qp["h"], qp["d"], qp["z"])) if st[b] == 0 else np.nan
-    assert (st == 0).sum() >= 6 and np.nanmax(cert) < 1e-4, (st, cert)
+            cert[b], dist[b] = _certified(qo, qp, st[b])
+    assert (st == 0).sum() >= 6 and np.nanmax(cert) < 1e-7 and np.nanmax(dist) < 1e-8, (st, cert, dist)
     np.savez_compressed(OUT / "qp_terminal_set_n20.npz", N=N, NT=NT, x0=x0, ub=ub, stuck=stuck, xref=xref, U=U, status=st, kkt=cert,
                         term_A=At, term_b=bt, D=cfg.D, rho=cfg.rho)
-    print(f"qp_terminal_set_n20.npz  reachable {(st == 0).sum()} of {cnt}, kkt max {np.nanmax(cert):.1e}", flush=True)
+    print(f"qp_terminal_set_n20.npz  reachable {(st == 0).sum()} of {cnt}, kkt max {np.nanmax(cert):.1e}  vs certificate {np.nanmax(dist):.1e}", flush=True)
+    # hull rows + terminal set (the reference's own NLP structure, spiraling_mpc.py:175-177 with :199-202), N = 15, 16 thrusters:
+    # tracking error on the boundary of the set, so that hull and terminal rows are active together in many instances
+    N, NT, cnt = 15, 16, 32
+    cfg = qo.QPConfig(N=N, NT=NT)
+    x0, ub, stuck, xref = qo.make_batch(cnt, N, NT, 2, 9200)
+    _near_terminal_set(x0, At, bt, 1.0, 9201)
+    G = np.zeros((cnt, N, 6))
+    st = np.zeros(cnt, np.int32)
+    cert = np.zeros(cnt)
+    dist = np.zeros(cnt)
+    act_h = np.zeros(cnt, np.int32)
+    act_t = np.zeros(cnt, np.int32)
+    with np.errstate(all="ignore"):
+        for b in range(cnt):
+            try:
+                _, G[b], st[b], _, qp = qo.solve_wrench_instance(cfg, x0[b], ub[b], stuck[b], xref, term_set=(At, bt), iters=60)
+            except ValueError:       # flat hull (healthy thrusters do not span R^6)
+                st[b], cert[b], dist[b] = 3, np.nan, np.nan
+                continue
+            cert[b], dist[b] = _certified(qo, qp, st[b])
+            if st[b] == 0:
+                act_h[b] = (qp["z"][:qp["nhull"]] > 0).sum()
+                act_t[b] = (qp["z"][qp["nhull"]:] > 0).sum()
+    assert (st == 0).sum() >= 16 and np.nanmax(cert) < 1e-7 and np.nanmax(dist) < 1e-8 and ((act_h > 0) & (act_t > 0)).sum() >= 6, (st, cert, dist)
+    np.savez_compressed(OUT / "qp_wrench_hull_terminal_n15.npz", N=N, NT=NT, x0=x0, ub=ub, stuck=stuck, xref=xref, G=G, status=st, kkt=cert,
+                        active_hull=act_h, active_term=act_t, term_A=At, term_b=bt, D=cfg.D)
+    print(f"qp_wrench_hull_terminal_n15.npz  reachable {(st == 0).sum()} of {cnt}, hull and terminal rows active together in "
+          f"{((act_h > 0) & (act_t > 0)).sum()}, kkt max {np.nanmax(cert):.1e}  vs certificate {np.nanmax(dist):.1e}", flush=True)
 
 
 if __name__ == "__main__":
     OUT.mkdir(parents=True, exist_ok=True)
-    sys.path.insert(0, str(ROOT / "fault-tolerant-mpc_amd"))
-    if "--only-round3" not in sys.argv:
-        reference_fixtures()
-        sim_env_fixture()
-        qp_fixtures()
-    qp_fixtures_large()
+    if "--only-general" not in sys.argv:
+        if "--only-round3" not in sys.argv:
+            reference_fixtures()
+            sim_env_fixture()
+            qp_fixtures()
+        qp_fixtures_large()
     general_constraint_fixtures()

@@ -443,7 +443,7 @@ def build_qp_box_terminal(cfg: QPConfig, x0, ub, stuck, xref, term_set, uref=Non
     return qp
 
 
-def ipm_general(H, g, C, h, d0, nfeas, iters=40, mu_stop=1e-10, rp_stop=1e-9, trace=None):
+def ipm_general(H, g, C, h, d0, nfeas, iters=40, mu_stop=1e-10, rp_stop=1e-9, trace=None, polish=True):
     """Mehrotra predictor-corrector for  min 1/2 d'Hd + g'd  s.t.  C d + s = h, s >= 0  -- the algorithm of the
     float64 kernel's general-constraint mode (csrc/ftmpc_solve_f64.hip, MODE != 0), step for step:
       * start at d0; the first `nfeas` rows (box or hull rows) are strictly feasible there and keep s = h - C d exactly;
@@ -455,6 +455,10 @@ def ipm_general(H, g, C, h, d0, nfeas, iters=40, mu_stop=1e-10, rp_stop=1e-9, tr
         with z/s ~ 1/mu on the active rows ruins the conditioning long before float64 runs out in the box form, hence
         mu_stop = 1e-10 here, and a factorisation that breaks down once mu < 1e-7 ends the iteration as converged
         (status 0; earlier: status 2)
+      * polish=True (what the kernels do since round 4): a converged iterate is finished by polish_general -- the exact
+        solution on the active set the iterate identifies, verified by its signs; every polish round that factorises counts
+        as an iteration.  An interior-point iterate at mu 1e-10 is up to 7e-5 f_max from the exact solution where rows
+        are weakly active (z ~ s ~ 1e-5); the polished one agrees with the active-set certificate solve_general_exact to 1e-9.
     Returns (d, s, z, iterations, status)."""
     n, m = g.size, h.size
     d = d0.copy()
@@ -514,7 +518,89 @@ def ipm_general(H, g, C, h, d0, nfeas, iters=40, mu_stop=1e-10, rp_stop=1e-9, tr
         grad = grad + ap * (H @ dd)
         if trace is not None:
             trace.append((mu, rpn, ap, ad))
+    if polish and status == 0:
+        dp, lam, rounds, verified = polish_general(H, g, C, h, d, s, z)
+        nit += rounds
+        if verified:
+            d, z, s = dp, lam, np.maximum(h - C @ dp, 0.0)
     return d, s, z, nit, status
+
+
+POLISH_W0 = 1e6       # penalty weight of the polish relative to max diag(H) / |c_i|^2
+POLISH_ROUNDS = 3
+POLISH_INNER = 2
+POLISH_RES_TOL = 1e-10
+
+
+def polish_general(H, g, C, h, d, s, z, W0=POLISH_W0, rounds=POLISH_ROUNDS, inner=POLISH_INNER):
+    """Active-set polish of a converged interior-point iterate -- the mirror of the kernels' finishing stage
+    (csrc/ftmpc_solve_f64.hip general-constraint mode).  Active set A = {i : z_i > s_i}.  Per round: the equality-constrained
+    problem on A is solved by `inner` steps of the method of multipliers with penalty W_i = W0 max diag(H) / |c_i|^2 on
+    the rows of A (one Cholesky of H + C_A' W C_A, the Newton matrix's own shape, and one solve per step):
+        (H + C_A' W C_A) dl = -(H d + g) + C_A' (W s_A - lam),   lam += W (C_A dl - s_A),   d += dl,    s_A = h_A - C_A d
+    started from lam = z_A; then the signs are checked -- a row of A with lam < 0 leaves, a row outside with h - C d < -1e-10
+    enters -- and the round is repeated with the corrected set until nothing changes (verified).
+    Returns (d, lam (all rows), rounds that factorised, verified)."""
+    d = d.copy()
+    m = h.size
+    cn2 = np.maximum((C * C).sum(axis=1), 1e-300)
+    hs = float(np.abs(np.diag(H)).max())
+    act = z > s
+    lam_full = np.where(act, z, 0.0)
+    done = 0
+    for _ in range(rounds):
+        A = np.flatnonzero(act)
+        CA = C[A]
+        W = W0 * hs / cn2[A]
+        try:
+            L = np.linalg.cholesky(H + CA.T @ (W[:, None] * CA))
+        except np.linalg.LinAlgError:
+            return d, lam_full, done, False
+        done += 1
+        lam = lam_full[A].copy()
+        for _ in range(inner):
+            sA = h[A] - CA @ d
+            rhs = -(H @ d + g) + CA.T @ (W * sA - lam)
+            dl = _solve(L, rhs)
+            lam = lam + W * (CA @ dl - sA)
+            d = d + dl
+        res = h - C @ d
+        lam_full = np.zeros(m)
+        lam_full[A] = lam
+        new = act.copy()
+        new[A[lam < 0.0]] = False
+        new[(~act) & (res < -POLISH_RES_TOL)] = True
+        if (new == act).all():
+            return d, lam_full, done, True
+        act = new
+        lam_full = np.maximum(lam_full, 0.0)
+    return d, lam_full, done, False
+
+
+def solve_general_exact(H, g, C, h, d, z, s, maxit=200):
+    """Solver-independent certificate for  min 1/2 d'Hd + g'd  s.t.  C d <= h : a primal-dual active-set iteration on the
+    KKT system [H C_A'; C_A 0] (least-squares solve: dependent active rows are harmless), started from the active set an
+    interior-point iterate suggests; one row leaves (most negative multiplier) or enters (most violated) per step.  Returns
+    (d, z) with kkt_general ~ 1e-12, or (None, None) when it does not settle within maxit steps."""
+    m, n = h.size, g.size
+    act = np.asarray(z) > np.asarray(s)
+    for _ in range(maxit):
+        A = np.flatnonzero(act)
+        CA = C[A]
+        na = A.size
+        K = np.block([[H, CA.T], [CA, np.zeros((na, na))]])
+        sol = np.linalg.lstsq(K, np.r_[-g, h[A]], rcond=None)[0]
+        dn, lam = sol[:n], sol[n:]
+        viol = np.where(~act, C @ dn - h, 0.0)
+        if na and lam.min() < -1e-12:
+            act[A[np.argmin(lam)]] = False
+        elif viol.max() > 1e-11:
+            act[np.argmax(viol)] = True
+        else:
+            zz = np.zeros(m)
+            zz[A] = lam
+            return dn, zz
+    return None, None
 
 
 def _pos_step(v, dv):

@@ -1,9 +1,11 @@
 """GPU parity of the generalized-force formulation (6-D QP with the input hull, then allocation) and of the terminal
 set, SURVEY.md section 8(f) ranks 2/3 -- the reference's own two-stage structure (spiraling_mpc.py:133-137,175-177,
 199-202; input_bounds.py:43-76; control_allocator.py:65-94).
-Checkers: oracle/qp_oracle.py:ipm_general (the same algorithm in NumPy, certified by its KKT residuals) and, for the hull
-form, the THRUSTER-SPACE exact solution (BVLS) with the allocation weight rho -> 0, whose optimal total wrench must
-coincide (the hull is the image of the thruster box).  Tolerance: 1e-6 f_max on wrenches / thruster forces."""
+Checkers: oracle/qp_oracle.py:ipm_general (the same algorithm in NumPy, finished by the same active-set polish: its
+solutions satisfy the KKT conditions to 1e-12 and agree with the primal-dual active-set certificate solve_general_exact to
+1e-9 f_max) and, for the hull form, the THRUSTER-SPACE exact solution (BVLS) with the allocation weight rho -> 0, whose
+optimal total wrench must coincide (the hull is the image of the thruster box).  Tolerance: 1e-6 f_max on wrenches /
+thruster forces for the float64 kernel, 1e-4 f_max (north_star) for fp32 handles (kernel 11 + hand-over)."""
 import numpy as np
 import pytest
 
@@ -11,6 +13,7 @@ import ft_mpc_amd
 from ft_mpc_amd.controllers.tools.input_bounds import hull_tables, zonotope_hrep
 from ft_mpc_amd.controllers.tools.terminal_ingredients import load_terminal
 from oracle import alloc_oracle as ao
+from oracle import batch as ob
 from oracle import qp_oracle as qo
 from oracle import refmath as rm
 
@@ -60,7 +63,7 @@ def test_wrench_step_against_the_oracle(gpu_mpc_factory, N, NT, nf, B):
             continue
         assert out["status"][b] == 0
         tau0, T, st, nit, qp = qo.solve_wrench_instance(cfg, x0[b], ub[b], stuck[b], xref)
-        assert st == 0 and max(qo.kkt_general(qp["H"], qp["g"], qp["C"], qp["h"], qp["d"], qp["z"])) < 1e-4
+        assert st == 0 and max(qo.kkt_general(qp["H"], qp["g"], qp["C"], qp["h"], qp["d"], qp["z"])) < 1e-8
         assert np.abs(out["G"][b] - T).max() / F_MAX <= TOL, (b, np.abs(out["G"][b] - T).max())
         assert abs(int(out["iters"][b]) - nit) <= 1
         # second stage: the allocated thruster forces realise tau0 - D stuck with minimum norm
@@ -82,7 +85,7 @@ def test_wrench_solution_is_the_thruster_space_solution_without_allocation_weigh
     for b in np.flatnonzero(out["status"] == 0):
         _, U, _ = qo.solve_instance(cfg0, x0[b], ub[b], stuck[b], xref, exact=True)
         diff = np.abs(out["G"][b] - (U + stuck[b]) @ cfg0.D.T).max()
-        assert diff / F_MAX <= 1e-5, (b, diff)      # two different stopping rules (mu 1e-10 there, active-set exact here)
+        assert diff / F_MAX <= 2e-6, (b, diff)      # (rho = 1e-9 there, none here; both exact on their active sets)
     assert (out["status"] == 0).sum() >= B - 2
 
 
@@ -159,7 +162,7 @@ def test_terminal_set_rows(gpu_mpc_factory, form):
             if st != 0:
                 continue
             solved += 1
-            assert max(qo.kkt_general(qp["H"], qp["g"], qp["C"], qp["h"], qp["d"], qp["z"])) < 1e-4
+            assert max(qo.kkt_general(qp["H"], qp["g"], qp["C"], qp["h"], qp["d"], qp["z"])) < 1e-7
             assert np.abs(out[key][b] - X).max() / F_MAX <= TOL, (b, np.abs(out[key][b] - X).max())
             assert (At @ (qp["eN"] + qp["GN"] @ qp["d"]) <= bt + 1e-7).all()
             active += int((qp["z"][qp["nhull"]:] > 1e-6).any())
@@ -207,7 +210,7 @@ def test_terminal_set_on_an_fp32_handle(gpu_mpc_factory):
     has = w64["status"] != 3
     ok64, ok32 = (w64["status"] == 0) & has, (w32["status"] == 0) & has
     assert ok64.sum() >= 12 and (has & ~ok64).sum() >= 4                     # reachable and unreachable both occur
-    assert (ok64 == ok32).mean() >= 0.95, (ok64.sum(), ok32.sum())           # (borderline instances may fall either way)
+    assert (ok64 != ok32).sum() <= 1, (ok64.sum(), ok32.sum())               # (a borderline instance may fall either way)
     both = ok64 & ok32
     err = np.abs(w32["G"][both] - w64["G"][both]).max(axis=(1, 2)) / F_MAX
     assert err.max() <= 1e-4, (err.max(), int(err.argmax()))
@@ -216,9 +219,35 @@ def test_terminal_set_on_an_fp32_handle(gpu_mpc_factory):
     assert (np.abs(free["G"][both] - w32["G"][both]).max(axis=(1, 2)) / F_MAX > 1e-3).sum() >= 4      # the rows matter
 
 
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-4), ("f64", 1e-6)])
+def test_two_stage_form_with_the_terminal_set_on_the_boundary_batch_against_the_oracle(gpu_mpc_factory, dtype, tol):
+    """The reference's NLP always carries hull rows AND the terminal set (spiraling_mpc.py:175-177,198-202).  2 048 vehicles with
+    the tracking error ON the boundary of the set (hull and terminal rows active together in ~40 % of them, weakly active rows
+    in many) against oracle/qp_oracle.py instance by instance: fp32 handle = ftmpc_solve_hull32_kernel<6, true> with its
+    hand-over to the float64 kernel, float64 handle = the float64 kernel (MODE 3), both finished by the active-set polish.
+    EVERY instance the oracle solves must be solved and lie within the tolerance (north_star: 1e-4 f_max for fp32), whole
+    horizon; reachable / unreachable verdicts may differ on borderline instances only (<= 0.1 %)."""
+    N, NT, B = 15, 16, 2048
+    term = load_terminal().term_set
+    At, bt = term.A, term.b.reshape(-1)
+    x0, ub, stuck, xref = _near_terminal_set(B, N, NT, 2, 9100, At, bt, scale=1.0)
+    ref = ob.solve_wrench_batch(N, NT, x0, ub, stuck, xref, term_set=(At, bt), iters=60)
+    out = gpu_mpc_factory(N=N, NT=NT, dtype=dtype, max_iters=60, terminal_set=term).solve_wrench(x0, ub, stuck, xref.reshape(-1, order="F"), return_G=True)
+    assert np.array_equal(ref["status"] == 3, out["status"] == 3)
+    ok_ref, ok = ref["status"] == 0, out["status"] == 0
+    assert ok_ref.sum() >= B // 2 and (ref["active"][ok_ref] > 0).all(axis=1).sum() >= B // 8
+    assert (ok_ref != ok).sum() <= B // 1000, ((ok_ref != ok).sum(), np.flatnonzero(ok_ref != ok)[:8])
+    both = ok_ref & ok
+    err = np.abs(out["G"][both] - ref["G"][both]).max(axis=(1, 2)) / F_MAX
+    assert err.max() <= tol, (err.max(), int(np.flatnonzero(both)[err.argmax()]), int((err > tol).sum()))
+    assert out["alloc_status"][both].max() == 0
+    assert np.isfinite(out["G"][out["status"] != 3]).all()
+
+
 def test_general_constraint_forms_against_golden(gpu_mpc_factory):
     """The committed fixtures of the reference's own formulation (tests/golden/qp_wrench_hull_n15.npz: hull rows per stage;
-    qp_terminal_set_n20.npz: 72-row terminal set, reachable and unreachable instances) against the HIP path."""
+    qp_terminal_set_n20.npz: 72-row terminal set, reachable and unreachable instances; qp_wrench_hull_terminal_n15.npz: both
+    together) against the HIP path."""
     from pathlib import Path
     g = Path(__file__).parent / "golden"
     d = np.load(g / "qp_wrench_hull_n15.npz")
@@ -232,18 +261,24 @@ def test_general_constraint_forms_against_golden(gpu_mpc_factory):
     ok = t["status"] == 0
     assert ((o2["status"] == 0) == ok).all() and ok.sum() >= 6
     assert np.abs(o2["U"][ok] - t["U"][ok]).max() / F_MAX <= TOL and np.isfinite(o2["U"]).all()
+    w = np.load(g / "qp_wrench_hull_terminal_n15.npz")
+    ok = w["status"] == 0
+    assert ok.sum() >= 16 and ((w["active_hull"] > 0) & (w["active_term"] > 0)).sum() >= 6
+    for dtype, tol in (("f64", TOL), ("f32", 1e-4)):
+        mw = gpu_mpc_factory(N=int(w["N"]), NT=int(w["NT"]), dtype=dtype, max_iters=60, terminal_set=(w["term_A"], w["term_b"]))
+        o3 = mw.solve_wrench(w["x0"], w["ub"], w["stuck"], w["xref"].reshape(-1, order="F"), return_G=True)
+        assert np.array_equal(o3["status"] == 0, ok) and np.array_equal(o3["status"] == 3, w["status"] == 3), (dtype, o3["status"], w["status"])
+        assert np.abs(o3["G"][ok] - w["G"][ok]).max() / F_MAX <= tol, (dtype, np.abs(o3["G"][ok] - w["G"][ok]).max() / F_MAX)
 
 
 # ---- kernel 11: the same formulation in fp32 on one wave per instance (N <= 16, up to 32 hull rows, no terminal set) ----
 TOL32 = 1e-4      # the fp32 kernels' specification: u0 / tau within 1e-4 f_max of the exact solution
 
 
-@pytest.mark.parametrize("N,NT,nf,B", [(15, 16, 2, 48), (15, 16, 0, 8), (16, 16, 1, 16), (10, 16, 3, 16), (12, 8, 0, 8)])
+@pytest.mark.parametrize("N,NT,nf,B", [(15, 16, 2, 48), (15, 16, 0, 8), (16, 16, 1, 16), (10, 16, 3, 16)])
 def test_fp32_wrench_step_against_the_oracle(gpu_mpc_factory, N, NT, nf, B):
     """ftmpc_solve_hull32_kernel against oracle/qp_oracle.py:ipm_general, instance by instance: whole-horizon wrenches within
     1e-4 f_max, every instance converged, allocation exact for the wrench the kernel hands over."""
-    if NT == 8:      # the synthetic generic 8-thruster matrix has 112 facets without a fault: take the reference's own matrix rows
-        pytest.skip("no 8-thruster vehicle with <= 32 facets in the synthetic set")
     mpc = gpu_mpc_factory(N=N, NT=NT, dtype="f32", max_iters=40)
     cfg = qo.QPConfig(N=N, NT=NT)
     x0, ub, stuck, xref = qo.make_batch(B, N, NT, nf, 7600 + N + NT)
@@ -256,7 +291,7 @@ def test_fp32_wrench_step_against_the_oracle(gpu_mpc_factory, N, NT, nf, B):
         tau0, T, st, nit, qp = qo.solve_wrench_instance(cfg, x0[b], ub[b], stuck[b], xref)
         assert st == 0
         worst = max(worst, np.abs(out["G"][b] - T).max() / F_MAX)
-        assert abs(int(out["iters"][b]) - nit) <= 2
+        assert abs(int(out["iters"][b]) - nit) <= 3      # (the oracle's count includes its polish round)
         want = out["tau0"][b] - cfg.D @ stuck[b]
         assert out["alloc_status"][b] == 0
         assert np.abs(cfg.D @ out["u0"][b] - want).max() <= 1e-6 * (1 + np.abs(want).max())
@@ -287,9 +322,9 @@ def test_fp32_wrench_warm_start_reference_window_and_persistent_grid(gpu_mpc_fac
     assert np.array_equal(ref["status"] == 3, out["status"] == 3)
     err = np.abs(out["G"][ok] - ref["G"][ok]).max(axis=(1, 2)) / F_MAX
     assert err.max() <= TOL32, (err.max(), int(err.argmax()))
-    assert np.abs(out["u0"][ok] - ref["u0"][ok]).max() / F_MAX <= 2 * TOL32
+    assert np.abs(out["u0"][ok] - ref["u0"][ok]).max() / F_MAX <= TOL32      # the thrust command AFTER allocation: north_star's 1e-4
     assert np.array_equal(W32[ok], out["G"][ok])       # warm buffer updated in place
-    assert np.abs(out["iters"][ok].astype(int) - ref["iters"][ok]).max() <= 3
+    assert np.abs(out["iters"][ok].astype(int) - ref["iters"][ok]).max() <= 4
 
 
 def test_fp32_wrench_kernel_select_dense_keeps_the_float64_kernel(gpu_mpc_factory):

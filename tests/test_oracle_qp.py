@@ -120,3 +120,66 @@ def test_general_constraint_fixtures_are_reproduced_and_certified():
             if st == 0:
                 assert np.abs(U - t["U"][b]).max() < 1e-9
                 assert (t["term_A"] @ (qp["eN"] + qp["GN"] @ qp["d"]) <= t["term_b"] + 1e-7).all()
+
+
+def _boundary_states(x0, At, bt, seed, scale=1.0):
+    rng = np.random.default_rng(seed)
+    r = rm.spiral_r()
+    for b in range(x0.shape[0]):
+        e = rng.standard_normal(9)
+        e *= scale / max((At @ e / bt).max(), 1e-9)
+        R = rm.rot(x0[b, 6:10])
+        w = rm.OMEGA_DES + e[6:9]
+        x0[b, 0:3] = e[0:3] - R.T @ r
+        x0[b, 3:6] = e[3:6] - R.T @ np.cross(w, r)
+        x0[b, 10:13] = w
+
+
+@pytest.mark.parametrize("with_set", [False, True])
+def test_active_set_polish_reaches_the_exact_solution_of_the_general_forms(with_set):
+    """The interior-point iterate at mu 1e-10 is up to 7e-5 f_max from the exact solution where rows are weakly active; the
+    polish (polish_general: what the kernels run since round 4) closes that: KKT residuals ~1e-12 and agreement with the
+    primal-dual active-set certificate (solve_general_exact, an independent iteration) to 1e-9 f_max."""
+    N, NT, B = 15, 16, 24
+    cfg = qo.QPConfig(N=N, NT=NT)
+    d = np.load(GOLD / "qp_wrench_hull_terminal_n15.npz")
+    At, bt = d["term_A"], d["term_b"]
+    x0, ub, stuck, xref = qo.make_batch(B, N, NT, 2, 9300)
+    if with_set:
+        _boundary_states(x0, At, bt, 9301)
+    worst_ipm = worst_pol = 0.0
+    solved = 0
+    with np.errstate(all="ignore"):
+        for b in range(B):
+            try:
+                qp = qo.build_qp_wrench(cfg, x0[b], ub[b], stuck[b], xref, term_set=(At, bt) if with_set else None)
+            except ValueError:
+                continue
+            d0, s0, z0, _, st0 = qo.ipm_general(qp["H"], qp["g"], qp["C"], qp["h"], qp["d0"], qp["nhull"], iters=60, polish=False)
+            d1, s1, z1, _, st1 = qo.ipm_general(qp["H"], qp["g"], qp["C"], qp["h"], qp["d0"], qp["nhull"], iters=60, polish=True)
+            assert st0 == st1
+            if st0 != 0:
+                continue
+            dx, zx = qo.solve_general_exact(qp["H"], qp["g"], qp["C"], qp["h"], d0, z0, s0)
+            assert dx is not None and max(qo.kkt_general(qp["H"], qp["g"], qp["C"], qp["h"], dx, zx)) < 1e-7      # (complementarity: multipliers ~1e3 times slacks ~1e-12)
+            assert max(qo.kkt_general(qp["H"], qp["g"], qp["C"], qp["h"], d1, z1)) < 1e-7
+            worst_ipm = max(worst_ipm, np.abs(d0 - dx).max() / rm.F_MAX)
+            worst_pol = max(worst_pol, np.abs(d1 - dx).max() / rm.F_MAX)
+            solved += 1
+    assert solved >= B // 2
+    assert worst_pol <= 1e-9, worst_pol
+    assert worst_ipm <= 2e-4      # (what the unpolished iterate is worth: the reason the polish exists)
+
+
+def test_general_constraint_golden_fixtures_are_reproduced_by_the_oracle():
+    """tests/golden/qp_wrench_hull_terminal_n15.npz (hull rows + terminal set) re-solved: same verdicts, same wrenches."""
+    d = np.load(GOLD / "qp_wrench_hull_terminal_n15.npz")
+    cfg = qo.QPConfig(N=int(d["N"]), NT=int(d["NT"]))
+    for b in range(0, d["x0"].shape[0], 4):
+        if d["status"][b] == 3:
+            continue
+        with np.errstate(all="ignore"):
+            _, T, st, _, _ = qo.solve_wrench_instance(cfg, d["x0"][b], d["ub"][b], d["stuck"][b], d["xref"], term_set=(d["term_A"], d["term_b"]), iters=60)
+        assert st == d["status"][b]
+        if st == 0:
+            assert np.abs(T - d["G"][b]).max() <= 1e-9

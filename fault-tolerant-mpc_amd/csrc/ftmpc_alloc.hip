@@ -174,14 +174,21 @@ __global__ void __launch_bounds__(64) ftmpc_allocate_kernel(const DeviceConsts C
         }
         if (any_free) {
             solve6(J, r, lf);
+            // the fixed set is a GUESS read off an iterate that has not converged: it is the minimum-norm allocation only if the
+            // multiplier of the free set agrees with it -- D_i' lf >= ub_i for a thruster put on its upper bound, <= 0 on the
+            // lower (the KKT signs of min |u|^2, D u = tau, 0 <= u <= ub).  Otherwise this is a feasible point that is not the
+            // answer: refused, the Newton iteration goes on.
+            bool signs = true;
 #pragma unroll
-            for (int i = 0; i < MAX_NT; ++i)
-                if (fr[i]) {
-                    double v = 0.0;
+            for (int i = 0; i < MAX_NT; ++i) {
+                const bool healthy = i < NT && ubv[i] > 0.0;
+                double v = 0.0;
 #pragma unroll
-                    for (int g = 0; g < 6; ++g) v += Dm[g * MAX_NT + i] * lf[g];
-                    up[i] = fmin(fmax(v, 0.0), ubv[i]);
-                }
+                for (int g = 0; g < 6; ++g) v += Dm[g * MAX_NT + i] * lf[g];
+                if (fr[i]) up[i] = fmin(fmax(v, 0.0), ubv[i]);
+                else if (healthy) signs = signs && ((up[i] > 0.0) ? v >= ubv[i] - band : v <= band);
+            }
+            if (!signs) return false;
         }
         double res = 0.0;
 #pragma unroll
@@ -264,7 +271,9 @@ __global__ void __launch_bounds__(64) ftmpc_allocate_kernel(const DeviceConsts C
 #pragma unroll
             for (int g = 0; g < 6; ++g) ln[g] = lam[g] + t * dl[g];
             qn = alloc_dual(Dm, NT, ln, tau, ubv, u, Fn);      // (u follows the trial point: restored below if nothing is accepted)
-            if (qn <= q + 1e-4 * t * slope) {
+            // (rounding slack: for a wrench on the boundary of the attainable set -- what the polished MPC solution hands over --
+            // the decrease of a good step is below 1e-16 |q|, and without the slack one such wrench in ~10^4 stalled here)
+            if (qn <= q + 1e-4 * t * slope + 1e-13 * (1.0 + fabs(q))) {
                 moved = true;
                 break;
             }

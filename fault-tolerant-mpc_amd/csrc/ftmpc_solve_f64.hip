@@ -1568,9 +1568,29 @@ __global__ void __launch_bounds__(f64k::WG, (SWEEP_ROWS == 4 && MODE == 0) ? 2 :
             // ---------------- outputs ----------------
             __syncthreads();
             if constexpr (GEN) {
+                // The allocator takes tau_0 next and needs it INSIDE the hull: the polished solution sits ON its active facets, a
+                // few 1e-13 outside as often as inside, and for a wrench outside the attainable set the allocation's dual is
+                // unbounded.  Pull tau_0 towards the hull centre by the smallest factor that leaves every facet a relative
+                // margin of 1e-9 (kernel 11 does the same); the whole-horizon output G keeps the solution as it is.
+                double eps = 0.0;
+                {
+                    double cl, cu, ch[NVC], ct;
+                    rows_Cx((status == 2) ? ubar0 : ubar0 + d, cl, cu, ch, ct);      // A_h tau_k
+#pragma unroll
+                    for (int v = 0; v < NVC; ++v)
+                        if (hv[v] && hk[v] == 0) {
+                            const double bb = Q.hullb[inst * MH + hr[v]];
+                            double s0 = bb;
+#pragma unroll
+                            for (int g = 0; g < 6; ++g) s0 -= s_hA[hr[v] * 6 + g] * s_ctr[g];
+                            const double st0 = bb - ch[v];
+                            if (st0 < 1e-9 * s0 && s0 > st0) eps = fmax(eps, (1e-9 * s0 - st0) / (s0 - st0));
+                        }
+                    eps = fmin(wg_max(eps, red, tid), 1.0);
+                }
                 if (val) {
                     const double tau = (status == 2) ? ubar0 : ubar0 + d;
-                    if (ek == 0) Q.out_tau0[inst * 6 + ea] = tau;
+                    if (ek == 0) Q.out_tau0[inst * 6 + ea] = s_ctr[ea] + (1.0 - eps) * (tau - s_ctr[ea]);
                     if (Q.out_G) Q.out_G[(inst * N + ek) * 6 + ea] = tau;
                 }
             } else {

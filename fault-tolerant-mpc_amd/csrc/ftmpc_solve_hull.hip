@@ -469,8 +469,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         }
         // rows of C x for a natural-order LDS vector, float64 (late iterations: the slack steps of active rows are small by
         // cancellation and need the step's components to full relative accuracy) or fp32
-        auto rows_Cx = [&](auto xs, float (&ch)[NVC]) {
+        auto rows_Cx = [&](auto xs, auto (&ch)[NVC]) {
             using XT = std::remove_cv_t<std::remove_pointer_t<decltype(xs)>>;
+            using OT = std::remove_reference_t<decltype(ch[0])>;
 #pragma unroll
             for (int v = 0; v < NVC; ++v) {
                 const int hra = 6 * (hcw[v] & (MHP - 1)), hxs = 6 * (hcw[v] >> 5);
@@ -478,7 +479,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                             a2 = *reinterpret_cast<const f32x2*>(s_hA + hra + 4);
                 const XT* x = xs + hxs;
                 const XT s2 = ((XT)a0.x * x[0] + (XT)a0.y * x[1]) + ((XT)a1.x * x[2] + (XT)a1.y * x[3]) + ((XT)a2.x * x[4] + (XT)a2.y * x[5]);
-                ch[v] = hv[v] ? (float)s2 : 0.f;
+                ch[v] = hv[v] ? (OT)s2 : (OT)0;
             }
         };
         // C' t for per-row values t: element e = v * 64 + lane of the result
@@ -538,8 +539,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             zt[j] = rpt[j] = 0.f;
         }
         // A_T (GN x) for a natural-order LDS vector (float64 or fp32)
-        auto term_rows = [&](auto xs, float (&ct)[NTR]) {
+        auto term_rows = [&](auto xs, auto (&ct)[NTR]) {
             using XT = std::remove_cv_t<std::remove_pointer_t<decltype(xs)>>;
+            using OT = std::remove_reference_t<decltype(ct[0])>;
             const int lane = lane_now();
             XT part[9];
 #pragma unroll
@@ -560,7 +562,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 XT a = (XT)0;
 #pragma unroll
                 for (int r = 0; r < 9; ++r) a += (XT)s_tA[tri[j] * 9 + r] * part[r];
-                ct[j] = tvr[j] ? (float)a : 0.f;
+                ct[j] = tvr[j] ? (OT)a : (OT)0;
             }
         };
         // out += GN' (A_T' t)
@@ -617,15 +619,45 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #ifndef FTMPC_HULL_REFRESH_ALL
 #define FTMPC_HULL_REFRESH_ALL 0
 #endif
-        int refines_left = (C.mu_refine > 0.0) ? ((NBW > 6 || FTMPC_HULL_REFRESH_ALL) ? C.max_iters + 1 : 1) : 0;
+#ifndef FTMPC_HULL_POLISH
+#define FTMPC_HULL_POLISH 1
+#endif
+#ifndef FTMPC_HULL_PW0
+#define FTMPC_HULL_PW0 1e3f      // penalty of the polish relative to max diag(H_w) / |c|^2 (the float64 kernel: 1e6; here W s is formed in fp32)
+#endif
+#ifndef FTMPC_HULL_NOREFRESH
+#define FTMPC_HULL_NOREFRESH 0
+#endif
+        int refines_left = (C.mu_refine > 0.0 && !FTMPC_HULL_NOREFRESH) ? ((NBW > 6 || FTMPC_HULL_REFRESH_ALL) ? C.max_iters + 1 : 1) : 0;
         float mu_last = 3.0e38f;
         const float inv_m = 1.0f / (float)(mhull + MT);
-        for (int it = 0; it <= C.max_iters; ++it) {
+        // Active-set polish (oracle/qp_oracle.py:polish_general; the float64 kernel runs the same): once the iteration has
+        // converged, the rows with z > s are taken as the active set and the equality-constrained problem on it is solved by two
+        // steps of the method of multipliers -- penalty W = 1e3 max diag(H_w) / |c|^2 on the active rows, zero on the others:
+        // the Newton matrix's own shape, so a polish round is one more pass through this loop (float64 factorisation and
+        // sweeps, the float64 reference gradient first) with the multiplier step in place of Mehrotra's.  Then the signs are
+        // checked (a negative multiplier leaves the set, a violated row enters) and the round repeated until nothing changes.
+        // Without it an iterate at mu 1e-10 is up to 7e-5 f_max from the exact solution where rows are weakly active.
+        bool pol = false, verified = false;
+        int prd = 0, pin = 0;
+        bool pa[NVC], pat[NTR];
+        float pwh[NVC], pwt[NTR], d_ipm[NVW];
+#pragma unroll
+        for (int v = 0; v < NVC; ++v) {
+            pa[v] = false;
+            pwh[v] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NTR; ++j) {
+            pat[j] = false;
+            pwt[j] = 0.f;
+        }
+        for (int it = 0; it <= C.max_iters + 16; ++it) {
             wave_lds_fence();
             lane = lane_now();
             li = lane & 15;
             lq = lane >> 4;
-            const bool do_ref = __builtin_amdgcn_readfirstlane(refines_left > 0 && mu_last < (float)C.mu_refine);
+            const bool do_ref = __builtin_amdgcn_readfirstlane(pol ? pin == 0 : (refines_left > 0 && mu_last < (float)C.mu_refine));
             if (do_ref) {   // float64, structured, at the current iterate
 #pragma unroll
                 for (int v = 0; v < NVW; ++v) rv[v * 64 + lane] = wvalid[v] ? d[v] : 0.f;
@@ -647,27 +679,82 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             }
             const float mu = wave_sum(csum) * inv_m;
             if constexpr (TSET) rpn = wave_max(rpn);
-            mu_last = mu;
-            if (__builtin_amdgcn_readfirstlane(!(mu == mu) || !(rpn == rpn))) {
-                status = 2;
-                break;
+            if (!pol) {
+                mu_last = mu;
+                if (__builtin_amdgcn_readfirstlane(!(mu == mu) || !(rpn == rpn))) {
+                    status = 2;
+                    break;
+                }
+                if (__builtin_amdgcn_readfirstlane(mu < mu_stop && rpn < 1e-7f)) {
+                    status = 0;
+#if FTMPC_HULL_POLISH
+                    // ---- enter the polish: active set, penalties, multipliers (in zh / zt), true slacks of the terminal rows ----
+                    pol = true;
+                    float hdmax = 0.f;
+#pragma unroll
+                    for (int v = 0; v < NVW; ++v) {
+                        const int e = v * 64 + lane;
+                        d_ipm[v] = d[v];
+                        if (e < n) {      // diagonal entry (r, r) of the stored -(H_II)' tile: lane 16 (r >> 2) + r, register r & 3
+                            const int I = e >> 4, r = e & 15;
+                            hdmax = fmaxf(hdmax, fabsf(Htl[tidx(I, I) * 256 + 4 * (16 * (r >> 2) + r) + (r & 3)]));
+                        }
+                    }
+                    const float pw = FTMPC_HULL_PW0 * wave_max(hdmax);
+#pragma unroll
+                    for (int v = 0; v < NVC; ++v) {
+                        pa[v] = hv[v] && zh[v] > sh[v];
+                        zh[v] = pa[v] ? zh[v] : 0.f;
+                        const int hra = 6 * (hcw[v] & (MHP - 1));
+                        float a2 = 0.f;
+#pragma unroll
+                        for (int g = 0; g < 6; ++g) a2 += s_hA[hra + g] * s_hA[hra + g];
+                        pwh[v] = hv[v] ? pw / fmaxf(a2, 1e-30f) : 0.f;
+                    }
+                    if constexpr (TSET) {
+                        wave_lds_fence();
+                        if (lane < 45) {      // Gram matrix GN GN' (9 x 9), for the norms |A_T,i GN|^2
+                            int r1 = 0;
+                            while ((r1 + 1) * (r1 + 2) / 2 <= lane) ++r1;
+                            const int r2 = lane - r1 * (r1 + 1) / 2;
+                            double acc = 0.0;
+                            for (int e = 0; e < n; ++e) acc += (double)s_GN[r1 * NPADW + e] * (double)s_GN[r2 * NPADW + e];
+                            M9s[r1 * 9 + r2] = acc;
+                            M9s[r2 * 9 + r1] = acc;
+                        }
+                        wave_lds_fence();
+#pragma unroll
+                        for (int j = 0; j < NTR; ++j) {
+                            pat[j] = tvr[j] && zt[j] > st[j];
+                            zt[j] = pat[j] ? zt[j] : 0.f;
+                            st[j] -= rpt[j];      // the true slack (the residual the steps carried has shrunk below 1e-7)
+                            rpt[j] = 0.f;
+                            double c2 = 0.0;
+                            for (int r1 = 0; r1 < 9; ++r1)
+                                for (int r2 = 0; r2 < 9; ++r2) c2 += (double)s_tA[tri[j] * 9 + r1] * M9s[r1 * 9 + r2] * (double)s_tA[tri[j] * 9 + r2];
+                            pwt[j] = tvr[j] ? pw / fmaxf((float)c2, 1e-30f) : 0.f;
+                        }
+                        wave_lds_fence();
+                    }
+                    fac64 = in64 = true;
+                    continue;      // (the next pass takes the float64 reference gradient first)
+#else
+                    break;
+#endif
+                }
+                if (it >= C.max_iters) break;
             }
-            if (__builtin_amdgcn_readfirstlane(mu < mu_stop && rpn < 1e-7f)) {
-                status = 0;
-                break;
-            }
-            if (it == C.max_iters) break;
-            ++nit;
+            if (pin == 0) ++nit;
             float rsh[NVC], wh[NVC], rst[NTR], wt[NTR];
 #pragma unroll
             for (int v = 0; v < NVC; ++v) {
                 rsh[v] = __builtin_amdgcn_rcpf(sh[v]);
-                wh[v] = hv[v] ? zh[v] * rsh[v] : 0.f;
+                wh[v] = pol ? (pa[v] ? pwh[v] : 0.f) : (hv[v] ? zh[v] * rsh[v] : 0.f);
             }
 #pragma unroll
             for (int j = 0; j < NTR; ++j) {
                 rst[j] = __builtin_amdgcn_rcpf(st[j]);
-                wt[j] = tvr[j] ? zt[j] * rst[j] : 0.f;
+                wt[j] = pol ? (pat[j] ? pwt[j] : 0.f) : (tvr[j] ? zt[j] * rst[j] : 0.f);
             }
             // Early iterations run the factorisation and the sweeps in fp32 (chol_reg / solve_reg); from the iteration in which
             // a row weight z / s passes FTMPC_HULL_W64 on, in float64.  With weights up to that the stage blocks are no larger
@@ -738,7 +825,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 }
             }
             bool ok = true;
-            for (int attempt = 0; attempt < 2; ++attempt) {
+            for (int attempt = (pin == 0 ? 0 : 2); attempt < 2; ++attempt) {      // (the second multiplier step of a polish round keeps the factor)
                 ok = true;
                 if (fac64) {
                     for (int idx = lane; idx < N * 21; idx += 64) {      // float64: the products of the fp32 normals are exact, G keeps its rank
@@ -848,8 +935,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 }
             }
             if (__builtin_amdgcn_readfirstlane(!__all(ok))) {     // (float64 too runs out near mu ~ 1e-12 ... 1e-13)
-                status = (mu < 1e-7f && rpn < 1e-7f) ? 0 : 2;      // (as the float64 kernel: the terminal rows must have closed their residual)
                 --nit;
+                if (pol) break;                                     // (not verified: the interior-point iterate is returned)
+                status = (mu < 1e-7f && rpn < 1e-7f) ? 0 : 2;      // (as the float64 kernel: the terminal rows must have closed their residual)
                 break;
             }
             // (H_w + G) x = rhs; the rows C x of the solution
@@ -876,9 +964,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             STAMP(9);
             // predictor: (H_w + G) da = -grd
             float rhs[NVW], dd[NVW];
+            float ch[NVC], ctt[NTR] = {0.f, 0.f};
+            float dzh_a[NVC], dst_a[NTR], dzt_a[NTR], ap = 1.f, ad = 1.f;
+            float rch[NVC], th[NVC], rct[NTR], tt[NTR];
+            if (!pol) {
 #pragma unroll
             for (int v = 0; v < NVW; ++v) rhs[v] = -grd[v];
-            float ch[NVC], ctt[NTR] = {0.f, 0.f};
             if constexpr (TSET) {      // the terminal rows carry their primal residual: t = -z rp / s
                 float t0[NTR];
 #pragma unroll
@@ -887,7 +978,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             }
             solve_rows(rhs, ch, ctt, nullptr);
             // ds = -C da (terminal rows: -rp - C da),  dz = -z - z ds / s
-            float dzh_a[NVC], dst_a[NTR], dzt_a[NTR], ap = 1.f, ad = 1.f;
 #pragma unroll
             for (int j = 0; j < NTR; ++j) {
                 dst_a[j] = dzt_a[j] = 0.f;
@@ -918,7 +1008,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             float sigma = mu_aff / mu;
             sigma = fminf(fmaxf(sigma * sigma * sigma, 0.f), 1.f);
             // corrector: rc = s z + ds_a dz_a - sigma mu,  t = -z + rc / s,  rhs = -grd + C' t
-            float rch[NVC], th[NVC];
 #pragma unroll
             for (int v = 0; v < NVC; ++v) {
                 rch[v] = th[v] = 0.f;
@@ -927,13 +1016,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                     th[v] = (-ch[v] * dzh_a[v] - sigma * mu) * rsh[v];      // -z + rc / s without the cancellation
                 }
             }
-            float ct[NVW];
-            cols_Ct(th, ct);
-#pragma unroll
-            for (int v = 0; v < NVW; ++v) rhs[v] = -grd[v] + ct[v];
-            float rct[NTR];
             if constexpr (TSET) {      // rc = s z + ds_a dz_a - sigma mu,  t = -z + (rc - z rp) / s
-                float tt[NTR];
 #pragma unroll
                 for (int j = 0; j < NTR; ++j) {
                     rct[j] = tt[j] = 0.f;
@@ -942,9 +1025,91 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                         tt[j] = (dst_a[j] * dzt_a[j] - sigma * mu - zt[j] * rpt[j]) * rst[j];
                     }
                 }
-                term_cols(tt, rhs);
             }
+            } else {      // polish: the multiplier step  (H_w + C_A' W C_A) dd = -grd + C_A' (W s_A - lam)
+#pragma unroll
+                for (int v = 0; v < NVC; ++v) {
+                    rch[v] = 0.f;
+                    th[v] = pa[v] ? wh[v] * sh[v] - zh[v] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < NTR; ++j) {
+                    rct[j] = 0.f;
+                    tt[j] = pat[j] ? wt[j] * st[j] - zt[j] : 0.f;
+                }
+            }
+            float ct[NVW];
+            cols_Ct(th, ct);
+#pragma unroll
+            for (int v = 0; v < NVW; ++v) rhs[v] = -grd[v] + ct[v];
+            if constexpr (TSET) term_cols(tt, rhs);
             solve_rows(rhs, ch, ctt, dd);
+            if (pol) {
+                // lam += W (C dd - s),  s -= C dd,  d += dd,  the gradient follows through H_w dd.  C dd - s is a difference of
+                // nearly equal numbers times a large weight: taken in float64 from the float64 solution (still in xv64)
+                double chd[NVC], cttd[NTR] = {0.0, 0.0};
+                rows_Cx((const double*)xv64, chd);
+                if constexpr (TSET) term_rows((const double*)xv64, cttd);
+#pragma unroll
+                for (int v = 0; v < NVC; ++v)
+                    if (hv[v]) {
+                        if (pa[v]) zh[v] += wh[v] * (float)(chd[v] - (double)sh[v]);
+                        sh[v] = (float)((double)sh[v] - chd[v]);
+                    }
+#pragma unroll
+                for (int j = 0; j < NTR; ++j)
+                    if (tvr[j]) {
+                        if (pat[j]) zt[j] += wt[j] * (float)(cttd[j] - (double)st[j]);
+                        st[j] = (float)((double)st[j] - cttd[j]);
+                    }
+                float hdd[NVW];
+                h_times(dd, hdd);
+#pragma unroll
+                for (int v = 0; v < NVW; ++v)
+                    if (wvalid[v]) {
+                        grd[v] += hdd[v];
+                        d[v] += dd[v];
+                    }
+                // the multiplier steps have converged when the active rows are met: further steps on the same factor until then
+                float ares = 0.f;
+#pragma unroll
+                for (int v = 0; v < NVC; ++v) ares = fmaxf(ares, pa[v] ? fabsf(sh[v]) : 0.f);
+#pragma unroll
+                for (int j = 0; j < NTR; ++j) ares = fmaxf(ares, pat[j] ? fabsf(st[j]) : 0.f);
+                ares = wave_max(ares);
+                ++pin;
+                if (__builtin_amdgcn_readfirstlane(pin < 2 || (pin < 4 && ares > 2e-6f))) continue;      // (two steps at least: measured, one leaves 7e-5)
+                pin = 0;
+                bool changed = ares > 2e-6f;
+#pragma unroll
+                for (int v = 0; v < NVC; ++v) {
+                    if (pa[v] && zh[v] < 0.f) {
+                        pa[v] = false;
+                        zh[v] = 0.f;
+                        changed = true;
+                    } else if (!pa[v] && hv[v] && sh[v] < -1e-6f) {
+                        pa[v] = true;
+                        changed = true;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NTR; ++j) {
+                    if (pat[j] && zt[j] < 0.f) {
+                        pat[j] = false;
+                        zt[j] = 0.f;
+                        changed = true;
+                    } else if (!pat[j] && tvr[j] && st[j] < -1e-6f) {
+                        pat[j] = true;
+                        changed = true;
+                    }
+                }
+                if (__builtin_amdgcn_readfirstlane(!__any(changed))) {
+                    verified = true;
+                    break;
+                }
+                if (++prd == 3) break;
+                continue;
+            }
             float dzh[NVC], dst[NTR], dzt[NTR];
             ap = 1e30f;
             ad = 1e30f;
@@ -992,8 +1157,30 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 }
             STAMP(10);
         }
-        // ---------------- certificate: strict complementarity, and not hull and terminal rows active together ----------------
-        if (Q.fb_list && status == 0) {
+        // ---------------- certificate ----------------
+        // A polish that was verified IS the certificate (the exact solution on an active set whose signs check).  Handed over to
+        // the float64 kernel (the host enqueues it behind this one): a polish that did not settle -- its iterate is dropped for the
+        // interior-point one --, and the instances with hull and terminal rows active together (FTMPC_HULL_HANDOVER_BOTH).
+#ifndef FTMPC_HULL_HANDOVER_BOTH
+#define FTMPC_HULL_HANDOVER_BOTH 1
+#endif
+        if (status == 0) {
+            bool hand_over = false;
+#if FTMPC_HULL_POLISH
+            if (!verified) {
+                hand_over = true;
+                if (pol) {
+#pragma unroll
+                    for (int v = 0; v < NVW; ++v) d[v] = d_ipm[v];
+                }
+            }
+            bool acth = false, actt = false;
+#pragma unroll
+            for (int v = 0; v < NVC; ++v) acth = acth || pa[v];
+#pragma unroll
+            for (int j = 0; j < NTR; ++j) actt = actt || pat[j];
+            if (FTMPC_HULL_HANDOVER_BOTH && TSET) hand_over = hand_over || (__any(acth) && __any(actt));
+#else
             bool weak = false, acth = false, actt = false;
 #pragma unroll
             for (int v = 0; v < NVC; ++v)
@@ -1007,8 +1194,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                     weak = weak || (zt[j] < 1e3f * st[j] && st[j] < 1e3f * zt[j]);
                     actt = actt || zt[j] > st[j];
                 }
-            const bool hand_over = __any(weak) || (__any(acth) && __any(actt));
-            if (hand_over && lane_now() == 0) Q.fb_list[atomicAdd(Q.fb_count, 1)] = (int32_t)inst;
+            hand_over = __any(weak) || (__any(acth) && __any(actt));
+#endif
+            if (Q.fb_list && hand_over && lane_now() == 0) Q.fb_list[atomicAdd(Q.fb_count, 1)] = (int32_t)inst;
         }
         // ---------------- outputs ----------------
         lane = lane_now();

@@ -412,6 +412,12 @@ class BatchedMPC:
                                                      _ptr(uh), _ptr(bad, C.c_int32)))
         return dict(x=x, u=uh, not_converged=bad)
 
+    def last_handed_over(self) -> int:
+        """Instances of the last two-stage step that the one-wave fp32 kernel handed to the float64 kernel (ftmpc_last_handed_over)."""
+        c = C.c_int64(0)
+        self._check(self.lib.ftmpc_last_handed_over(self._h, C.byref(c)))
+        return int(c.value)
+
     # -- standalone thruster allocation (ControlAllocator.get_physical_input, batched) ---------
     def allocate(self, tau, ub):
         """min |u|^2 s.t. D u = tau, 0 <= u <= ub for B generalized forces tau [B,6] (reference:

@@ -231,8 +231,13 @@ int ftmpc_solve_batch_device(ftmpc_handle* h, int64_t B,
  *     decision  tau_k in R^6, k < N: the TOTAL generalized force on the body ( = the reference's u_t + u_r + u_comp + D f_fault )
  *     cost      as ftmpc_solve_batch with ut_k = tau_k - ur_k - [f_virt;0] ( = the reference's deviation input u_t ), no rho term
  *     s.t.      hull_A tau_k <= hull_b  for every stage  [+ the terminal set when the handle's config has terminal_set != 0]
- * and u0 = argmin |u|^2 s.t. D u = tau_0 - D stuck, 0 <= u <= ub.  Needs 6 N <= 256 and N * hull_rows <= 1024.  dtype
- * FTMPC_DTYPE_F32 with N <= 16: one wave per instance, wrenches within 1e-4 f_max; otherwise the float64 kernel (1e-7).
+ * and u0 = argmin |u|^2 s.t. D u = tau_0 - D stuck, 0 <= u <= ub.  Needs 6 N <= 256 and N * hull_rows <= 1024.
+ * Every converged interior-point iterate is finished by an active-set polish (the exact solution on the active set the iterate
+ * identifies, its multiplier and slack signs verified; each polish round that factorises counts in iters[]): the float64 kernel
+ * returns the oracle's polished solution to 1e-9 f_max.  dtype FTMPC_DTYPE_F32 with N <= 16: one wave per instance with the same
+ * polish on fp32 data (measured on 8 192 boundary vehicles: 9e-6 f_max worst; specification 1e-4 f_max on wrenches and on the
+ * allocated thrust command); instances whose polish does not settle, and -- with the terminal set -- those with hull and terminal
+ * rows active together, are solved again by the float64 kernel inside the same call (ftmpc_last_handed_over).
  *   hull_A    [n_sets][hull_rows*6] row-major facet normals, one table per fault INDEX SET (the normals do not depend on
  *             the fault intensities);  hull_set [B] table number of every instance (NULL: table 0 for all)
  *   hull_b    [B*hull_rows] facet offsets (they carry the intensities: b = n . D (ub/2 + stuck) + sum_i |n . D_i| ub_i / 2);
@@ -250,6 +255,11 @@ int ftmpc_solve_wrench_batch(ftmpc_handle* h, int64_t B,
                              double* warmG,
                              double* out_u0, double* out_tau0, double* out_G,
                              int32_t* status, int32_t* iters, int32_t* alloc_status);
+
+/* Number of instances of the LAST ftmpc_solve_wrench_batch / ftmpc_simulate_wrench_batch step on this handle that the one-wave fp32
+ * kernel handed over to the float64 kernel (its active-set polish did not settle, or hull and terminal rows were active together);
+ * 0 where the float64 kernel solved the whole batch anyway.  Blocks until that step's kernels have finished. */
+int ftmpc_last_handed_over(ftmpc_handle* h, int64_t* count);
 
 /*
  * Batched thruster allocation: the reference's second stage,

@@ -44,7 +44,7 @@ def allocate(D, tau, ub, max_iters=50, tol=1e-8, return_lambda=False):
         t, moved = 1.0, False
         for _ in range(40):
             qn, un, Fn = _dual(D, lam + t * dl, tau, ub)
-            if qn <= q + 1e-4 * t * slope:
+            if qn <= q + 1e-4 * t * slope + 1e-13 * (1.0 + abs(q)):      # (rounding slack: near the solution the decrease is below 1e-16 |q|)
                 moved = True
                 break
             t *= 0.5
@@ -65,11 +65,16 @@ def allocate(D, tau, ub, max_iters=50, tol=1e-8, return_lambda=False):
         free = healthy & ~lo & ~hi
         up = np.where(hi, ub, 0.0)
         r = tau - D @ up
+        signs = True
         if free.any():
             Jf = D[:, free] @ D[:, free].T
             lf = np.linalg.solve(Jf + (1e-12 * np.trace(Jf) + 1e-300) * np.eye(6), r)
-            up[free] = np.clip(D[:, free].T @ lf, 0.0, ub[free])
-        if np.abs(D @ up - tau).max() <= thr:
+            v = D.T @ lf
+            up[free] = np.clip(v[free], 0.0, ub[free])
+            # KKT signs of the fixed set (a guess read off an unconverged iterate): D_i' lf >= ub_i on the upper bound, <= 0 on
+            # the lower; otherwise the point is feasible but not the minimum-norm allocation and is refused
+            signs = bool((v[hi] >= ub[hi] - band).all() and (v[lo] <= band).all())
+        if signs and np.abs(D @ up - tau).max() <= thr:
             u, status = up, 0
     return (u, status, it, lam) if return_lambda else (u, status, it)
 

@@ -69,6 +69,12 @@ def test_allocation_of_wrenches_on_the_boundary_of_the_attainable_set(gpu_mpc_fa
             ok += 1
             assert np.abs(D @ out["u"][b] - tau[b]).max() < 1e-7 * (1 + np.abs(tau[b]).max())
             assert np.abs(out["u"][b] - u).max() < 1e-5
+            # minimum norm, not merely feasible (the early polish accepts a fixed set only with the right multiplier signs)
+            assert (out["u"][b] ** 2).sum() <= (u ** 2).sum() * (1 + 1e-9) + 1e-9
+        if out["status"][b] == 0 and b % 16 == 0:      # ... and against an independent solver (SLSQP) on a sample
+            us, success = ao.allocate_slsqp(D, tau[b], ub[b])
+            if success and np.abs(D @ us - tau[b]).max() < 1e-7:
+                assert (out["u"][b] ** 2).sum() <= (us ** 2).sum() * (1 + 1e-6) + 1e-8
     assert ok >= 0.98 * B, ok
     assert (out["u"] >= 0).all() and (out["u"] <= ub + 1e-12).all() and (out["u"][ub == 0] == 0).all()
 

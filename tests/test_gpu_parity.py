@@ -2,6 +2,8 @@
 same seeded inputs.  Tolerances:
   * condensed QP data (H, g built in fp32 on the GPU):   rel-inf 2e-5 on H, 2e-5*scale on g
   * thrust command u0 vs the EXACT QP solution (BVLS):   <= 1e-4 * f_max  (north-star tolerance)
+  * the whole-horizon solution U vs the same:             <= 1e-4 * f_max  (TOL_U; measured on the full 65 536-instance
+    config-3 batch: 2.8e-5 -- rounds 1-3 accepted 2e-3 here, which would have hidden a real regression)
 """
 import numpy as np
 import pytest
@@ -12,6 +14,7 @@ from oracle import refmath as rm
 
 pytestmark = pytest.mark.gpu
 F_MAX = rm.F_MAX
+TOL_U = 1e-4
 
 
 def _cfg(N, NT, rho=0.05):
@@ -47,7 +50,7 @@ def test_u0_matches_exact_solution(gpu_mpc_factory, nfault, B):
     for b in range(B):
         u0, U, _ = qo.solve_instance(cfg, x0[b], ub[b], stuck[b], xref, exact=True)
         err[b] = np.abs(out["u0"][b] - u0).max() / F_MAX
-        assert np.abs(out["U"][b] - U).max() / F_MAX < 2e-3
+        assert np.abs(out["U"][b] - U).max() / F_MAX <= TOL_U
     assert err.max() <= 1e-4, err
     assert (out["u0"][ub == 0] == 0).all()
     assert out["iters"].max() <= 30
@@ -67,7 +70,7 @@ def test_large_batches_against_the_c_oracle(gpu_mpc_factory, nfault, B):
     ref = co.solve_batch(_cfg(N, NT), x0, ub, stuck, xref, nthreads=min(32, os.cpu_count() or 1), max_iters=60, mu_stop=1e-13)
     assert (ref["status"] == 0).all()
     assert np.abs(out["u0"] - ref["u0"]).max() / F_MAX <= 1e-4
-    assert np.abs(out["U"] - ref["U"]).max() / F_MAX <= 2e-3
+    assert np.abs(out["U"] - ref["U"]).max() / F_MAX <= TOL_U
 
 
 @pytest.mark.parametrize("N,nfault", [(3, 2), (6, 0), (18, 2), (23, 2), (26, 2)])
@@ -83,7 +86,7 @@ def test_horizons_not_multiple_of_four(gpu_mpc_factory, N, nfault):
     ref = co.solve_batch(_cfg(N, NT), x0, ub, stuck, xref, nthreads=4, max_iters=60, mu_stop=1e-13)
     assert (ref["status"] == 0).all()
     assert np.abs(out["u0"] - ref["u0"]).max() / F_MAX <= 1e-4
-    assert np.abs(out["U"] - ref["U"]).max() / F_MAX <= 2e-3
+    assert np.abs(out["U"] - ref["U"]).max() / F_MAX <= TOL_U
 
 
 @pytest.mark.parametrize("nfault", [0, 2])
@@ -98,7 +101,7 @@ def test_sixteen_thrusters_short_horizon_on_the_fp32_kernels(gpu_mpc_factory, nf
     ref = co.solve_batch(_cfg(N, NT), x0, ub, stuck, xref, nthreads=4, max_iters=60, mu_stop=1e-13)
     assert (ref["status"] == 0).all()
     assert np.abs(out["u0"] - ref["u0"]).max() / F_MAX <= 1e-4
-    assert np.abs(out["U"] - ref["U"]).max() / F_MAX <= 2e-3
+    assert np.abs(out["U"] - ref["U"]).max() / F_MAX <= TOL_U
     assert (out["u0"][ub == 0] == 0).all()
 
 
@@ -134,7 +137,7 @@ def test_wg_kernel_u0_against_the_c_oracle(gpu_mpc_factory, N, nfault, B, sel):
     ref = co.solve_batch(_cfg(N, NT), x0, ub, stuck, xref, nthreads=8, max_iters=60, mu_stop=1e-13)
     assert (ref["status"] == 0).all()
     assert np.abs(out["u0"] - ref["u0"]).max() / F_MAX <= 1e-4
-    assert np.abs(out["U"] - ref["U"]).max() / F_MAX <= 2e-3
+    assert np.abs(out["U"] - ref["U"]).max() / F_MAX <= TOL_U
     assert (out["u0"][ub == 0] == 0).all() and out["iters"].max() <= 30
 
 
@@ -261,7 +264,7 @@ def test_wg_kernel_whole_batch_mixed_fault_counts_warm_start_and_uref(gpu_mpc_fa
     ref2 = co.solve_batch_complete(_cfg(N, NT), x0, ub, stuck, xw, uref=uw, warmU=W0, nthreads=nt)
     assert (out2["status"] == 0).all(), np.bincount(out2["status"])
     assert np.abs(out2["u0"] - ref2["u0"]).max() / F_MAX <= 1e-4, np.bincount(ref2["how"])
-    assert np.abs(W - ref2["U"]).max() / F_MAX <= 2e-3
+    assert np.abs(W - ref2["U"]).max() / F_MAX <= TOL_U
 
 
 # ---------------------------------------------------------------------------------------------
@@ -386,7 +389,7 @@ def test_f32_kernels_against_golden(gpu_mpc_factory, name):
     out = mpc.solve(d["x0"], d["ub"], d["stuck"], d["xref"].reshape(-1, order="F"), uref=ur, warmU=W, return_U=True)
     assert (out["status"] == 0).all()
     assert np.abs(out["u0"] - d["u0"]).max() / F_MAX <= 1e-4
-    assert np.abs(out["U"] - d["U"]).max() / F_MAX <= 2e-3
+    assert np.abs(out["U"] - d["U"]).max() / F_MAX <= TOL_U
     assert (out["U"][np.repeat(d["ub"][:, None, :], N, 1) == 0] == 0).all()
 
 
@@ -454,4 +457,4 @@ def test_sixteen_thruster_kernels_against_golden(gpu_mpc_factory, name, dtype, s
     out = mpc.solve(d["x0"], d["ub"], d["stuck"], d["xref"].reshape(-1, order="F"), return_U=True)
     assert (out["status"] == 0).all(), out["status"]
     assert np.abs(out["u0"] - d["u0"]).max() / F_MAX <= tol
-    assert np.abs(out["U"] - d["U"]).max() / F_MAX <= (2e-3 if dtype == "f32" else 1e-6)
+    assert np.abs(out["U"] - d["U"]).max() / F_MAX <= (TOL_U if dtype == "f32" else 1e-6)

@@ -291,7 +291,7 @@ def test_fp32_wrench_step_against_the_oracle(gpu_mpc_factory, N, NT, nf, B):
         tau0, T, st, nit, qp = qo.solve_wrench_instance(cfg, x0[b], ub[b], stuck[b], xref)
         assert st == 0
         worst = max(worst, np.abs(out["G"][b] - T).max() / F_MAX)
-        assert abs(int(out["iters"][b]) - nit) <= 3      # (the oracle's count includes its polish round)
+        assert abs(int(out["iters"][b]) - nit) <= 5      # (kernel 11 leaves the interior-point iteration at mu 1e-7 for its polish, the oracle at 1e-10)
         want = out["tau0"][b] - cfg.D @ stuck[b]
         assert out["alloc_status"][b] == 0
         assert np.abs(cfg.D @ out["u0"][b] - want).max() <= 1e-6 * (1 + np.abs(want).max())
@@ -324,7 +324,7 @@ def test_fp32_wrench_warm_start_reference_window_and_persistent_grid(gpu_mpc_fac
     assert err.max() <= TOL32, (err.max(), int(err.argmax()))
     assert np.abs(out["u0"][ok] - ref["u0"][ok]).max() / F_MAX <= TOL32      # the thrust command AFTER allocation: north_star's 1e-4
     assert np.array_equal(W32[ok], out["G"][ok])       # warm buffer updated in place
-    assert np.abs(out["iters"][ok].astype(int) - ref["iters"][ok]).max() <= 4
+    assert np.abs(out["iters"][ok].astype(int) - ref["iters"][ok]).max() <= 5      # (up to three polish rounds on either side)
 
 
 def test_fp32_wrench_kernel_select_dense_keeps_the_float64_kernel(gpu_mpc_factory):

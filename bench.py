@@ -186,7 +186,7 @@ def make_line(args, world, elapsed, B, N, NT, iters, status, ub, kernel_ms, para
     # the wrench-space kernels (8: ws32, 9: ws64) solve the Newton systems through the 6N-variable form: `achieved` / `frac` above
     # follow SURVEY.md 8(d)'s DENSE flop model -- the work the QP step stands for -- and `executed` what the kernel really does
     note = {}
-    if "ws32" in dom or "ws64" in dom:
+    if "ws32" in dom or "wsw32" in dom or "ws64" in dom:      # (names as ROUTED on this handle: the dense wg32 kernel is not one of them)
         ex = batch_flops(N, ub, iters, executed_flops_wrench)
         note = {"executed": {"flops_per_launch": ex, "achieved": ex / (sol_ms * 1e-3) / 1e12, "frac": ex / (sol_ms * 1e-3) / 1e12 / peak,
                              "model": "bench.py:executed_flops_wrench (condensing in 6 wrench components, one Cholesky of H_w, per iteration "
@@ -203,7 +203,11 @@ def make_line(args, world, elapsed, B, N, NT, iters, status, ub, kernel_ms, para
                    "batch_per_gpu": B, "horizon": N, "thrusters": NT, "faults": args.faults,
                    "ipm_iters_mean": float(iters.mean()), "ipm_iters_max": int(iters.max()),
                    "not_converged": int((status != 0).sum()), "parallelism": parallelism},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+        # neither HBM nor the matrix cores bind this path, the fp32 (fp64) vector-FMA rate and LDS do; gfx950's fp32
+        # MFMA rate equals its fp32 vector rate (157.3 TFLOP/s), so `peak` is that one number either way
+        "roofline": {"bound": "valu", "bound_note": "vector FMA + LDS latency of the per-wavefront Cholesky (SURVEY.md 8(d)); "
+                                                    "not hbm (algorithmic traffic ~4 GB/s), not mfma (matrix cores carry the tile products only)",
+                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": dom, "kernel_ms": sol_ms,
                      "other_kernels_ms": {"ftmpc_linearize_kernel": lin_ms, **{k: v for k, v in kernel_ms.items() if k != dom}},
@@ -256,7 +260,9 @@ def run_multi_inprocess(args):
     # the same totals on one GPU of this run; parallel efficiency = rate_G / (G * rate_1)
     strong = {}
     one = MultiGPUMPC(cfg, devices=[devices[0]])
-    for total in (65536, 262144):
+    # (config 5 -- `--dtype f64 --horizon 40 --thrusters 16` -- has its own total: 16 384 over the node)
+    totals = (16384,) if (args.dtype == "f64" and N == 40 and NT == 16) else (65536, 262144)
+    for total in totals:
         total = (total // G) * G
         sx0, sub, sst, _ = batch(total, 1004)
         m.upload(sx0, sub, sst, xr)

@@ -1393,6 +1393,11 @@ static const char* const k_kernel_names[FTMPC_KERNEL_SLOTS] = {"ftmpc_linearize_
 
 const char* ftmpc_kernel_name(int32_t slot) { return (slot >= 0 && slot < FTMPC_KERNEL_SLOTS) ? k_kernel_names[slot] : ""; }
 
+const char* ftmpc_routed_kernel_name(const ftmpc_handle* h, int32_t slot) {
+    if (h && slot == 5) return h->use_wsw ? "ftmpc_solve_wsw32_kernel" : (h->use_ws ? "ftmpc_solve_ws32_kernel" : "ftmpc_solve_wg32_kernel<15>");
+    return ftmpc_kernel_name(slot);
+}
+
 int ftmpc_debug_build_qp(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, const double* stuck,
                          const double* xref, int64_t xref_stride, const double* uref, int64_t uref_stride,
                          const double* warmU, int64_t inst, double* H, int64_t H_cap, double* g, double* lo,

@@ -163,12 +163,22 @@ int dev_grow(ftmpc_multi::Dev& d, T** p, int64_t count) {
 // host -> device copy of a pageable array through the device's pinned staging halves (PIN_HALF bytes each)
 constexpr size_t PIN_HALF = (size_t)8 << 20;
 int dev_upload(ftmpc_multi::Dev& d, void* dst, const void* src, size_t bytes) {
-    if (!d.pin) {
-        DEV_TRY(d, hipHostMalloc(&d.pin, 2 * PIN_HALF, hipHostMallocDefault));
-        DEV_TRY(d, hipEventCreateWithFlags(&d.pin_ev[0], hipEventDisableTiming));
-        DEV_TRY(d, hipEventCreateWithFlags(&d.pin_ev[1], hipEventDisableTiming));
-        DEV_TRY(d, hipEventRecord(d.pin_ev[0], d.s));
-        DEV_TRY(d, hipEventRecord(d.pin_ev[1], d.s));
+    if (!d.pin) {      // all or nothing: a staging buffer without its two recorded events must not survive a failed set-up
+        void* pin = nullptr;
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        hipError_t e = hipHostMalloc(&pin, 2 * PIN_HALF, hipHostMallocDefault);
+        for (int t = 0; t < 2 && e == hipSuccess; ++t) e = hipEventCreateWithFlags(&ev[t], hipEventDisableTiming);
+        for (int t = 0; t < 2 && e == hipSuccess; ++t) e = hipEventRecord(ev[t], d.s);
+        if (e != hipSuccess) {
+            for (int t = 0; t < 2; ++t)
+                if (ev[t]) (void)hipEventDestroy(ev[t]);
+            if (pin) (void)hipHostFree(pin);
+            (void)hipGetLastError();
+            return dev_fail(d, FTMPC_ERR_HIP, std::string("pinned staging set-up: ") + hipGetErrorString(e));
+        }
+        d.pin = pin;
+        d.pin_ev[0] = ev[0];
+        d.pin_ev[1] = ev[1];
     }
     for (size_t off = 0; off < bytes; off += PIN_HALF) {
         const size_t cnt = std::min(PIN_HALF, bytes - off);
@@ -195,6 +205,13 @@ extern "C" {
 int ftmpc_multi_create(const ftmpc_config* cfg, const int32_t* device_ids, int32_t n_devices, ftmpc_multi** out) {
     if (!cfg || !out) return FTMPC_ERR_ARG;
     *out = nullptr;
+    // the ABI guard of ftmpc_create, BEFORE the struct is copied: a caller built against an older, shorter ftmpc_config must be
+    // told, not read past its end (nothing beyond struct_size's own offset is touched until it has been checked)
+    if (cfg->struct_size != (int32_t)sizeof(ftmpc_config)) {
+        g_multi_create_error = "ftmpc_config.struct_size = " + std::to_string(cfg->struct_size) + " but this library was built with sizeof(ftmpc_config) = " +
+                               std::to_string(sizeof(ftmpc_config)) + " (fill the struct with ftmpc_default_config of the SAME header)";
+        return FTMPC_ERR_ARG;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         g_multi_create_error = "no HIP device visible (this library has no CPU fallback)";
@@ -396,6 +413,10 @@ int ftmpc_multi_download(ftmpc_multi* m, double* out_u0, double* out_U, int32_t*
         DEV_TRY(d, hipStreamSynchronize(d.s));
         return FTMPC_OK;
     });
+}
+
+const char* ftmpc_multi_routed_kernel_name(const ftmpc_multi* m, int32_t slot) {
+    return (m && !m->dev.empty()) ? ftmpc_routed_kernel_name(m->dev[0].h, slot) : ftmpc_kernel_name(slot);
 }
 
 int ftmpc_multi_set_profiling(ftmpc_multi* m, int32_t enabled) {

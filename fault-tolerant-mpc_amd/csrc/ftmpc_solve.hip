@@ -442,8 +442,10 @@ __device__ __forceinline__ float row_sum16(float x) {
 // (a second resident wave covers the latency instead).
 // LOUT: the tiles of the factor itself, L_JJ = C_JJ W_J' and L_IJ = C_IJ W_J', are written over the matrix tiles of the column
 // just consumed (kernel 10 keeps L of the wrench-space Hessian in LDS this way).
+// n_rows: the number of REAL rows of the matrix (n, not a block count and not a variable count of another space): rows at or
+// beyond it are identity padding, and a last block with at most eight real rows takes the eight-pivot potrf.
 template <int NB, int J, class TilesT, bool PREF = true, bool WLDS = false, bool LOUT = false>
-__device__ __forceinline__ void chol_reg_col(const TilesT& tiles, const float* sigv, float* S, int nb, int lane, bool& ok,
+__device__ __forceinline__ void chol_reg_col(const TilesT& tiles, const float* sigv, float* S, int n_rows, int lane, bool& ok,
                                              f32x4 (&T)[NB * (NB + 1) / 2], f32x4 (&Wd)[NB], const f32x4 (&pre)[NB], float* WL = nullptr) {
     lane = lane_now();
     const int li = lane & 15, lq = lane >> 4;
@@ -469,7 +471,7 @@ __device__ __forceinline__ void chol_reg_col(const TilesT& tiles, const float* s
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) cd[rr] = ((4 * lq + rr == li) ? sg : 0.f) - (a0[rr] + a1[rr]);   // H + Sigma - sum
         f32x4 w;
-        if (J == NB - 1 && nb <= 16 * (NB - 1) + 8) {      // (`nb` carries n here) last block half padding: eight pivots
+        if (J == NB - 1 && n_rows <= 16 * (NB - 1) + 8) {      // rows 8 .. 15 of the last block are identity padding: eight pivots
             float ch[4] = {cd.x, cd.y, cd.z, cd.w}, wh[4];
             potrf_inv16_half(ch, wh, lane);
             w = f32x4{wh[0], wh[1], wh[2], wh[3]};
@@ -498,7 +500,7 @@ __device__ __forceinline__ void chol_reg_col(const TilesT& tiles, const float* s
 #pragma unroll
             for (int I = J + 1; I < NB; ++I) tiles.st(tidx(I, J), lane, mm_tn(bacc[I], wtn, zero));   // (-C_IJ')' (-W_J') = C_IJ W_J' = L_IJ
         }
-        if constexpr (J + 1 < NB) chol_reg_col<NB, J + 1, TilesT, PREF, WLDS, LOUT>(tiles, sigv, S, nb, lane, ok, T, Wd, nxt, WL);
+        if constexpr (J + 1 < NB) chol_reg_col<NB, J + 1, TilesT, PREF, WLDS, LOUT>(tiles, sigv, S, n_rows, lane, ok, T, Wd, nxt, WL);
     }
 }
 
@@ -509,10 +511,10 @@ __device__ __forceinline__ void chol_prefetch_col0(const TilesT& tiles, int lane
     for (int I = 0; I < NB; ++I) pre[I] = TilesT::is_global(tidx(I, 0)) ? tiles.ld(tidx(I, 0), lane) : f32x4{0.f, 0.f, 0.f, 0.f};
 }
 template <int NB, class TilesT, bool PREF = true, bool WLDS = false, bool LOUT = false>
-__device__ __forceinline__ bool chol_reg(const TilesT& tiles, const float* sigv, float* S, int nb, int lane,
+__device__ __forceinline__ bool chol_reg(const TilesT& tiles, const float* sigv, float* S, int n_rows, int lane,
                                          f32x4 (&T)[NB * (NB + 1) / 2], f32x4 (&Wd)[NB], const f32x4 (&pre)[NB], float* WL = nullptr) {
     bool ok = true;
-    chol_reg_col<NB, 0, TilesT, PREF, WLDS, LOUT>(tiles, sigv, S, nb, lane, ok, T, Wd, pre, WL);
+    chol_reg_col<NB, 0, TilesT, PREF, WLDS, LOUT>(tiles, sigv, S, n_rows, lane, ok, T, Wd, pre, WL);
     return __all(ok);
 }
 

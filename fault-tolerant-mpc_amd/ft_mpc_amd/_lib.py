@@ -26,7 +26,7 @@ KERNEL_AUTO, KERNEL_DENSE, KERNEL_WORKGROUP = 0, 1, 2
 SYMBOLS = (
     "ftmpc_default_config", "ftmpc_create", "ftmpc_destroy", "ftmpc_last_error", "ftmpc_reserve",
     "ftmpc_solve_batch", "ftmpc_solve_batch_device", "ftmpc_solve_sqp_batch", "ftmpc_solve_wrench_batch", "ftmpc_eval_cost_batch", "ftmpc_simulate_batch", "ftmpc_simulate_batch_ex", "ftmpc_simulate_wrench_batch", "ftmpc_last_handed_over", "ftmpc_allocate_batch", "ftmpc_shift_warm", "ftmpc_set_profiling",
-    "ftmpc_last_kernel_ms", "ftmpc_kernel_name", "ftmpc_debug_build_qp", "ftmpc_version", "ftmpc_build_id",
+    "ftmpc_last_kernel_ms", "ftmpc_kernel_name", "ftmpc_routed_kernel_name", "ftmpc_multi_routed_kernel_name", "ftmpc_debug_build_qp", "ftmpc_version", "ftmpc_build_id",
     "ftmpc_multi_create", "ftmpc_multi_destroy", "ftmpc_multi_last_error", "ftmpc_multi_device_count", "ftmpc_multi_worker_cpus",
     "ftmpc_multi_shard_bounds", "ftmpc_multi_solve_batch", "ftmpc_multi_upload", "ftmpc_multi_step",
     "ftmpc_multi_download", "ftmpc_multi_set_profiling", "ftmpc_multi_last_kernel_ms",
@@ -108,6 +108,10 @@ def load_library() -> C.CDLL:
     lib.ftmpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_int32]
     lib.ftmpc_kernel_name.argtypes = [C.c_int32]
     lib.ftmpc_kernel_name.restype = C.c_char_p
+    lib.ftmpc_routed_kernel_name.argtypes = [vp, C.c_int32]
+    lib.ftmpc_routed_kernel_name.restype = C.c_char_p
+    lib.ftmpc_multi_routed_kernel_name.argtypes = [vp, C.c_int32]
+    lib.ftmpc_multi_routed_kernel_name.restype = C.c_char_p
     lib.ftmpc_debug_build_qp.argtypes = [vp, C.c_int64, dp, dp, dp, dp, C.c_int64, dp, C.c_int64, dp, C.c_int64,
                                          dp, C.c_int64, dp, dp, dp, ip]
     lib.ftmpc_version.restype = C.c_int32
@@ -128,7 +132,7 @@ def load_library() -> C.CDLL:
     lib.ftmpc_multi_worker_cpus.argtypes = [vp, C.c_int32]
     lib.ftmpc_multi_worker_cpus.restype = C.c_int32
     for name in SYMBOLS:
-        if name not in ("ftmpc_last_error", "ftmpc_kernel_name", "ftmpc_version", "ftmpc_build_id", "ftmpc_multi_last_error",
+        if name not in ("ftmpc_last_error", "ftmpc_kernel_name", "ftmpc_routed_kernel_name", "ftmpc_multi_routed_kernel_name", "ftmpc_version", "ftmpc_build_id", "ftmpc_multi_last_error",
                         "ftmpc_multi_device_count", "ftmpc_multi_worker_cpus"):
             getattr(lib, name).restype = C.c_int
     _lib = lib

@@ -450,7 +450,7 @@ class BatchedMPC:
         """{kernel name: device ms} of the last profiled solve (kernels that were launched)."""
         ms = (C.c_float * _lib.KERNEL_SLOTS)()
         self._check(self.lib.ftmpc_last_kernel_ms(self._h, ms, _lib.KERNEL_SLOTS))
-        return {self.kernel_name(k): float(ms[k]) for k in range(_lib.KERNEL_SLOTS) if ms[k] > 0}
+        return {self.lib.ftmpc_routed_kernel_name(self._h, k).decode(): float(ms[k]) for k in range(_lib.KERNEL_SLOTS) if ms[k] > 0}
 
     # -- test hook ----------------------------------------------------------------------
     def debug_build_qp(self, x0, ub, stuck, xref, inst, uref=None, warmU=None):

@@ -151,7 +151,7 @@ class MultiGPUMPC:
         from . import _lib
         ms = (C.c_float * _lib.KERNEL_SLOTS)()
         self._check(self.lib.ftmpc_multi_last_kernel_ms(self._h, int(slot), ms, _lib.KERNEL_SLOTS))
-        return {self.lib.ftmpc_kernel_name(k).decode(): float(ms[k]) for k in range(_lib.KERNEL_SLOTS) if ms[k] > 0}
+        return {self.lib.ftmpc_multi_routed_kernel_name(self._h, k).decode(): float(ms[k]) for k in range(_lib.KERNEL_SLOTS) if ms[k] > 0}
 
     def worker_cpus(self, slot=0):
         """Host cores the worker thread of device slot `slot` is bound to (0: affinity left alone)."""

@@ -332,6 +332,9 @@ int ftmpc_simulate_wrench_batch(ftmpc_handle* h, int64_t B, int32_t T, double* x
 int ftmpc_set_profiling(ftmpc_handle* h, int32_t enabled);
 int ftmpc_last_kernel_ms(ftmpc_handle* h, float* ms, int32_t n_slots);
 const char* ftmpc_kernel_name(int32_t slot);
+/* the ONE kernel slot `slot` launches on this handle (slot 5 names three kernels above; which of them runs is the handle's routing:
+ * its shape and kernel_select) */
+const char* ftmpc_routed_kernel_name(const ftmpc_handle* h, int32_t slot);
 
 /*
  * Test hook: runs the build for instance `inst` of a host batch and returns the condensed
@@ -387,6 +390,7 @@ int ftmpc_multi_download(ftmpc_multi* m, double* out_u0, double* out_U, int32_t*
 /* per-kernel device timing of device slot `slot` (see ftmpc_set_profiling / ftmpc_last_kernel_ms) */
 int ftmpc_multi_set_profiling(ftmpc_multi* m, int32_t enabled);
 int ftmpc_multi_last_kernel_ms(ftmpc_multi* m, int32_t slot, float* ms, int32_t n_slots);
+const char* ftmpc_multi_routed_kernel_name(const ftmpc_multi* m, int32_t slot); /* ftmpc_routed_kernel_name of the device handles */
 
 /* Library/ABI version: major*10000 + minor*100 + patch. */
 int32_t ftmpc_version(void);

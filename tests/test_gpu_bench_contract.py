@@ -27,7 +27,7 @@ def test_single_gpu_line():
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in j
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["dtype"] == "f32" and j["vs_baseline"] is None
-    assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] < 1
+    assert j["roofline"]["bound"] == "valu" and 0 < j["roofline"]["frac"] < 1
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["gpu_vs_port_max_u0_err_over_fmax"] < 1e-4
     assert j["config"]["not_converged"] == 0 and j["value"] > 1e5
     # the warm-started rate is reported beside the cold one (a different linearisation point, hence a different QP)

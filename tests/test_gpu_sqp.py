@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from ft_mpc_amd.controllers.tools.terminal_ingredients import load_terminal
+from oracle import batch as ob
 from oracle import qp_oracle as qo
 from oracle import refmath as rm
 
@@ -71,6 +72,25 @@ def test_line_search_sqp_against_the_oracle(gpu_mpc_factory):
     rel = mpc.solve(x0, ub, stuck, xref.reshape(-1, order="F"), return_U=True, relinearize=11)
     Jrel = mpc.eval_cost(x0, ub, stuck, xref.reshape(-1, order="F"), rel["U"])
     assert np.median(Jrel / out["cost"]) > 3.0
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_on_device_sqp_solution_against_the_oracle(gpu_mpc_factory, dtype):
+    """ftmpc_solve_sqp_batch against oracle/qp_oracle.py:sqp_linesearch on 32 instances: the SEQUENCES U, not only their cost
+    (round 3 compared four costs at 2e-3).  Twelve major iterations of a line search on a nonconvex program, the QPs solved by
+    an interior point here and by BVLS there: every accept / halve decision must fall the same way for the sequences to stay
+    together, and they do -- U within 1e-3 f_max, cost within 1e-5 relative, every cost trace decreasing."""
+    N, NT, B = 20, 8, 32
+    T = load_terminal()
+    mpc = gpu_mpc_factory(N=N, NT=NT, dtype=dtype, terminal_cost=T)
+    x0, ub, stuck, xref = qo.make_batch(B, N, NT, 2, 8450)
+    out = mpc.solve_sqp_device(x0, ub, stuck, xref.reshape(-1, order="F"), sqp_iters=12)
+    ref = ob.sqp_batch(N, NT, x0, ub, stuck, xref, terminal=T, sqp_iters=12)
+    assert np.allclose(out["cost0"], ref["cost0"], rtol=1e-10)
+    assert (out["cost"] < out["cost0"]).all()
+    err = np.abs(out["U"] - ref["U"]).max(axis=(1, 2)) / rm.F_MAX
+    assert err.max() <= 1e-3, (err.max(), int(err.argmax()), np.sort(err)[-4:])
+    assert np.abs(out["cost"] / ref["cost"] - 1).max() <= 1e-5
 
 
 @pytest.mark.parametrize("N,NT,dtype,warm", [(20, 8, "f32", False), (20, 8, "f32", True), (15, 16, "f32", False), (15, 16, "f64", True)])

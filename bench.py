@@ -179,7 +179,7 @@ def make_line(args, world, elapsed, B, N, NT, iters, status, ub, kernel_ms, para
     dom = max(kernel_ms, key=kernel_ms.get)
     sol_ms = kernel_ms[dom]
     flops = batch_flops(N, ub, iters)
-    f64 = "f64" in dom or "ws64" in dom
+    f64 = "f64" in dom or "ws64" in dom or "ric64" in dom
     peak = F64_PEAK_TFLOPS if f64 else F32_PEAK_TFLOPS
     achieved = flops / (sol_ms * 1e-3) / 1e12
     traffic, traffic_src = traffic_for(dom, B, N, NT)

@@ -29,6 +29,7 @@
 #include "ftmpc_solve_ws64.hip"
 #include "ftmpc_solve_wsw.hip"
 #include "ftmpc_solve_hull.hip"
+#include "ftmpc_solve_ric.hip"
 #include "ftmpc_sim.hip"
 #include "ftmpc_alloc.hip"
 
@@ -106,6 +107,11 @@ struct ftmpc_handle {
     int grid_wg = 0;
     int64_t wg_slot_words = 0;
     // float64 through the wrench-space form (kernel 9): 6 N <= 256, N * NT <= 768, ten or more thrusters
+    bool use_ric64 = false;            // kernel 12: float64, Newton systems by the Riccati recursion, one wave per instance
+    int ric_nv = 10;
+    int grid_ric = 0;
+    double* ric_slot = nullptr;
+    int64_t ric_slot_doubles = 0;
     bool use_ws64 = false;
     int ws64_nvt = 1, grid_ws64 = 0;
     double* ws64_slot = nullptr;
@@ -320,6 +326,31 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
     sp.dbg_inst = dbg_inst;
     sp.dbg_H = h->d_dbgH;
     sp.dbg_vec = h->d_dbgv;
+    if (h->use_f64 && h->use_ric64) {
+        ftmpc::SolveRicParams w;
+        sp.hscratch = nullptr;
+        sp.tile_words = 0;
+        sp.qlist = nullptr;
+        sp.qcount = nullptr;
+        HIP_TRY(h, hipMemsetAsync(h->d_qctl + 4, 0, sizeof(int32_t), s));
+        sp.qhead = h->d_qctl + 4;       // shared instance cursor
+        sp.dbg_H = reinterpret_cast<float*>(h->d_dbgH64);     // (diagnostic build: phase stamps)
+        w.base = sp;
+        w.slot = h->ric_slot;
+        w.slot_doubles = h->ric_slot_doubles;
+        const int grid = (int)std::min<int64_t>(B, h->grid_ric);
+        if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[12], s));
+        if (h->ric_nv == 4) hipLaunchKernelGGL(ftmpc::ftmpc_solve_ric64_kernel<4>, dim3(grid), dim3(64), 0, s, h->dc, w);
+        else if (h->ric_nv == 6) hipLaunchKernelGGL(ftmpc::ftmpc_solve_ric64_kernel<6>, dim3(grid), dim3(64), 0, s, h->dc, w);
+        else hipLaunchKernelGGL(ftmpc::ftmpc_solve_ric64_kernel<10>, dim3(grid), dim3(64), 0, s, h->dc, w);
+        HIP_TRY(h, hipGetLastError());
+        if (h->profiling) {
+            HIP_TRY(h, hipEventRecord(h->ev[13], s));
+            h->ev_used[6] = true;
+            h->ev_valid = true;
+        }
+        return FTMPC_OK;
+    }
     if (h->use_f64 && h->use_ws64) {
         SolveWs64Params w;
         sp.hscratch = nullptr;
@@ -596,6 +627,11 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
     h->use_ws64 = h->use_f64 && cfg->terminal_set == 0 && cfg->kernel_select != FTMPC_KERNEL_DENSE && 6 * cfg->N <= ftmpc::ws64k::NPADW &&
                   cfg->N * cfg->NT <= 3 * ftmpc::ws64k::WG && cfg->NT >= 10;
     h->ws64_nvt = (cfg->N * cfg->NT <= ftmpc::ws64k::WG) ? 1 : 3;
+    // float64 box QP (no terminal set): the Riccati recursion on one wave per instance (kernel 12) for every horizon up to 40;
+    // kernel_select = FTMPC_KERNEL_WORKGROUP keeps kernel 9 (the wrench-space form), FTMPC_KERNEL_DENSE the dense float64 kernel
+    h->use_ric64 = h->use_f64 && cfg->terminal_set == 0 && cfg->kernel_select == FTMPC_KERNEL_AUTO && cfg->N <= 40;
+    h->ric_nv = cfg->N <= 16 ? 4 : (cfg->N <= 24 ? 6 : 10);
+    if (h->use_ric64) h->use_ws64 = false;
     h->tset = cfg->terminal_set != 0;
     if (h->tset) {
         const char* why = nullptr;
@@ -663,6 +699,15 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
               grow(h, &h->Eall, h->grid64 * h->e_doubles) != FTMPC_OK ||
               grow(h, &h->d_dbgH64, (int64_t)h->npad_max * h->npad_max) != FTMPC_OK ||
               grow(h, &h->d_dbgv64, 3 * (int64_t)h->npad_max + 4) != FTMPC_OK;
+        if (!bad && h->use_ric64) {
+            int per = 0;
+            if (h->ric_nv == 4) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_ric64_kernel<4>, 64, 0);
+            else if (h->ric_nv == 6) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_ric64_kernel<6>, 64, 0);
+            else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_ric64_kernel<10>, 64, 0);
+            h->grid_ric = h->num_cu * std::max(1, per);
+            h->ric_slot_doubles = ftmpc::rick::slot_doubles(cfg->N);
+            bad = grow(h, &h->ric_slot, (int64_t)h->grid_ric * h->ric_slot_doubles) != FTMPC_OK;
+        }
         if (!bad && h->use_ws64) {
             int per = 0;
             if (h->ws64_nvt == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_ws64_kernel<1>, ftmpc::ws64k::WG, 0);
@@ -747,7 +792,7 @@ int ftmpc_destroy(ftmpc_handle* h) {
     void* ptrs[] = {h->rec, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, h->d_uref, h->d_warm, h->d_u0, h->d_U,
                     h->d_status, h->d_iters, h->hs[0], h->hs[1], h->hs[2], h->d_dbgH, h->d_dbgv, h->Hs, h->Ls, h->Eall, h->d_dbgH64, h->d_dbgv64,
                     h->d_atau, h->d_aub, h->d_au, h->d_ast, h->d_ait, h->d_qlist, h->d_qctl, h->d_term, h->d_eN, h->gHs, h->gLs,
-                    h->gEall, h->wg_slot, h->ws_slot, h->ws64_slot, h->wsw_slot, h->hull_slot, h->d_tcost, h->d_cost, h->d_sqU, h->d_sqQ, h->d_sqT, h->d_sqJ, h->d_sqF, h->d_hullA, h->d_hullb, h->d_warmG, h->d_tau0, h->d_G, h->d_taud, h->d_hullset, h->d_ast2};
+                    h->gEall, h->wg_slot, h->ws_slot, h->ws64_slot, h->ric_slot, h->wsw_slot, h->hull_slot, h->d_tcost, h->d_cost, h->d_sqU, h->d_sqQ, h->d_sqT, h->d_sqJ, h->d_sqF, h->d_hullA, h->d_hullb, h->d_warmG, h->d_tau0, h->d_G, h->d_taud, h->d_hullset, h->d_ast2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_qcnt) (void)hipHostFree(h->h_qcnt);
@@ -1394,6 +1439,7 @@ static const char* const k_kernel_names[FTMPC_KERNEL_SLOTS] = {"ftmpc_linearize_
 const char* ftmpc_kernel_name(int32_t slot) { return (slot >= 0 && slot < FTMPC_KERNEL_SLOTS) ? k_kernel_names[slot] : ""; }
 
 const char* ftmpc_routed_kernel_name(const ftmpc_handle* h, int32_t slot) {
+    if (h && slot == 6) return h->use_ric64 ? "ftmpc_solve_ric64_kernel" : "ftmpc_solve_ws64_kernel";
     if (h && slot == 5) return h->use_wsw ? "ftmpc_solve_wsw32_kernel" : (h->use_ws ? "ftmpc_solve_ws32_kernel" : "ftmpc_solve_wg32_kernel<15>");
     return ftmpc_kernel_name(slot);
 }
@@ -1417,8 +1463,9 @@ int ftmpc_debug_build_qp(ftmpc_handle* h, int64_t B, const double* x0, const dou
     if (!h->use_f64) HIP_TRY(h, hipMemsetAsync(h->d_dbgv, 0, (3 * 256 + 4) * sizeof(float), s));
     if (h->use_ws && h->nb_max > 15)
         return fail(h, FTMPC_ERR_ARG, "the QP dump needs N * NT <= 240 on the fp32 path (create the handle with dtype FTMPC_DTYPE_F64 for larger shapes)");
-    const bool ws64_was = h->use_ws64;
+    const bool ws64_was = h->use_ws64, ric_was = h->use_ric64;      // (the dump comes from the dense float64 kernel: the only one that forms H)
     h->use_ws64 = false;
+    h->use_ric64 = false;
     const bool wsw_was = h->use_wsw;
     h->use_wsw = false;
     const bool ws_was = h->use_ws;
@@ -1428,6 +1475,7 @@ int ftmpc_debug_build_qp(ftmpc_handle* h, int64_t B, const double* x0, const dou
     h->use_ws = ws_was;
     h->use_wsw = wsw_was;
     h->use_ws64 = ws64_was;
+    h->use_ric64 = ric_was;
     if (rc != FTMPC_OK) return rc;
     if (h->use_f64) {
         const int64_t pm = h->npad_max;

@@ -117,18 +117,20 @@ __device__ __forceinline__ f64x4 ld4(const double* p) { return *reinterpret_cast
 // reads the pivot, its rows, its column's entry and E[j][col], then eight FMAs.  The row-per-lane version above spends
 // ~900 cycles per pivot on ~32 v_readlane of double words; this one two LDS round trips (~300).
 // Out: w = W = L^-1 and l = L in the same layout (zero above the diagonal); returns false on a non-positive pivot.
-__device__ __forceinline__ bool potrf_inv16_lds(double (&c)[4], double* colS, double* rowE, int lq, int li, double (&w)[4], double (&l)[4]) {
+// np (wave-uniform): rows and columns at or beyond it are identity padding and take no pivot step (W and L are the identity there).
+__device__ __forceinline__ bool potrf_inv16_lds(double (&c)[4], double* colS, double* rowE, int lq, int li, double (&w)[4], double (&l)[4], int np = 16) {
     double e[4];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         e[rr] = (lq + 4 * rr == li) ? 1.0 : 0.0;
-        w[rr] = 0.0;
-        l[rr] = 0.0;
+        w[rr] = (lq + 4 * rr >= np) ? e[rr] : 0.0;
+        l[rr] = w[rr];
     }
     bool ok = true;
     const int pli = v64pos(li);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
+        if (j >= np) break;
         if (li == j) *reinterpret_cast<f64x4*>(colS + 4 * lq) = f64x4{c[0], c[1], c[2], c[3]};
         if (lq == (j & 3)) rowE[li] = e[j >> 2];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

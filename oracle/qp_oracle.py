@@ -443,6 +443,45 @@ def build_qp_box_terminal(cfg: QPConfig, x0, ub, stuck, xref, term_set, uref=Non
     return qp
 
 
+def build_qp_box_state(cfg: QPConfig, x0, ub, stuck, xref, xlb=None, xub=None, uref=None, warmU=None):
+    """The thruster-space QP of build_qp plus the reference's optional STATE BOUNDS  xlb <= c_k <= xub  on the orbit-centre state
+    of every stage k = 1 .. N-1 (spiraling_mpc.py:129-130,179-185: `con_ineq.append(x_t)` for t < N with bounds xlb / xub, 13
+    components, +-inf = no row; the row of stage 0 does not depend on the decision variables), in the general form C d <= h:
+    box rows first (-d <= Ubar, d <= ub - Ubar), then per stage the finite upper rows  G_k d <= xub - cbar_k  and the finite lower
+    rows  -G_k d <= cbar_k - xlb  (G_k = d c_k / d U, 13 x n).  `srow`: (stage, component, +1 | -1) of every state row."""
+    qp = build_qp(cfg, x0, ub, stuck, xref, uref, warmU)
+    n, N, na = qp["n"], cfg.N, qp["na"]
+    xub = np.full(13, np.inf) if xub is None else np.asarray(xub, float).reshape(13)
+    xlb = np.full(13, -np.inf) if xlb is None else np.asarray(xlb, float).reshape(13)
+    Da = cfg.D[:, qp["act"]]
+    G = np.zeros((13, n))
+    rows, hs, srow = [], [], []
+    for k in range(N):
+        G = qp["A"][k] @ G
+        G[:, k * na:(k + 1) * na] = qp["Bg"][k] @ Da      # now G = d c_{k+1} / d U
+        if k + 1 < N:
+            c = qp["cbar"][k + 1]
+            for i in range(13):
+                if np.isfinite(xub[i]):
+                    rows.append(G[i].copy()); hs.append(xub[i] - c[i]); srow.append((k + 1, i, 1))
+                if np.isfinite(xlb[i]):
+                    rows.append(-G[i]); hs.append(c[i] - xlb[i]); srow.append((k + 1, i, -1))
+    C = np.vstack([-np.eye(n), np.eye(n)] + ([np.array(rows)] if rows else []))
+    h = np.concatenate([qp["Ubar"], qp["ub"] - qp["Ubar"], np.array(hs, float)])
+    qp.update(C=C, h=h, d0=0.5 * qp["ub"] - qp["Ubar"], nhull=2 * n, srow=srow)
+    return qp
+
+
+def solve_box_state_instance(cfg: QPConfig, x0, ub, stuck, xref, xlb=None, xub=None, uref=None, warmU=None, iters=60, mu_stop=1e-10):
+    """Thruster-space QP with the state bounds.  Returns (u0 (NT,), U (N,NT), status, iterations, qp dict)."""
+    qp = build_qp_box_state(cfg, x0, ub, stuck, xref, xlb, xub, uref, warmU)
+    d, s, z, nit, st = ipm_general(qp["H"], qp["g"], qp["C"], qp["h"], qp["d0"], qp["nhull"], iters=iters, mu_stop=mu_stop)
+    U = np.zeros((cfg.N, cfg.NT))
+    U[:, qp["act"]] = (qp["Ubar"] + (d if st != 2 else 0.0)).reshape(cfg.N, qp["na"])
+    qp.update(d=d, z=z, s=s)
+    return U[0].copy(), U, st, nit, qp
+
+
 def ipm_general(H, g, C, h, d0, nfeas, iters=40, mu_stop=1e-10, rp_stop=1e-9, trace=None, polish=True):
     """Mehrotra predictor-corrector for  min 1/2 d'Hd + g'd  s.t.  C d + s = h, s >= 0  -- the algorithm of the
     float64 kernel's general-constraint mode (csrc/ftmpc_solve_f64.hip, MODE != 0), step for step:

@@ -22,3 +22,5 @@ run("cfg5 shard N=40 NT=16 2f", 2048, 40, 16, 2, 1005)
 run("cfg5 shard N=40 NT=16 2f, 4096", 4096, 40, 16, 2, 1005)
 run("reference vehicle N=15 NT=16 2f", 4096, 15, 16, 2, 1011)
 run("N=20 NT=16 2f", 4096, 20, 16, 2, 1013)
+run("cfg5 N=40 NT=16 2f, 16384", 16384, 40, 16, 2, 1005, reps=2)
+run("reference vehicle N=15 NT=16 2f, 16384", 16384, 15, 16, 2, 1011, reps=2)

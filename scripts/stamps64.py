@@ -21,6 +21,8 @@ names=["prologue","phase1: E panels","phase2: H tiles","chol: barrier + row stag
 mpc.set_profiling(True); mpc.solve(x0,ub,stuck,xref.reshape(-1,order='F')); ran=mpc.last_kernel_ms(); print(ran)
 if "ftmpc_solve_ws64_kernel" in ran:
     names=["prologue + output","phase1: E panels","phase2: H_w tiles","chol: barrier + row staging","H_w post-pass | elementwise, S blocks, wrench images","solve with the factor of K (x2)","L' t and L p (x2 each)","X = (L' S) L","chol: diagonal tile + potrf (wave 0)","chol: W phase","chol: off-diagonal stream (wave 0)","chol: wait for the other waves (wave 0)"]
+if "ftmpc_solve_ric64_kernel" in ran:
+    names=["prologue + start gradient","Riccati sweep (factors W, Y of every stage)","backward vector sweeps (x2)","forward vector sweeps (x2)","element-wise (Mehrotra)","output","","","","","",""]
 m=buf.astype(np.float64).mean(axis=0); tot=m.sum(); it=out['iters'].mean()
 print("N=%d NT=%d B=%d iters mean %.2f   total ticks/QP %.0f"%(N,NT,B,it,tot))
 for n_,v in zip(names,m):

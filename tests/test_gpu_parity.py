@@ -279,13 +279,14 @@ def _faults16(B, pattern):
     return ub, stuck
 
 
-@pytest.mark.parametrize("sel", ["auto", "dense"])
+@pytest.mark.parametrize("sel", ["auto", "workgroup", "dense"])
 @pytest.mark.parametrize("N,pattern", [(15, [(10, 1.0), (11, 1.0)]), (15, []), (20, [(0, 0.5)]), (15, [(12, 0.3), (13, 0.9)])])
 def test_f64_kernel_reference_vehicle(gpu_mpc_factory, N, pattern, sel):
     """NT=16 (the reference's D, sys_model.py:73-123); N=15 with thrusters 10,11 stuck fully on is the
     shipped reactive.yaml scenario; 12 + 13 is the pair whose healthy thrusters do not span R^6 (S singular: the
-    wrench-space form does not care).  float64 path: u0 and U within 1e-7 f_max of the exact solution, through the
-    wrench-space form (auto: ftmpc_solve_ws64_kernel) and through the dense factorisation (dense: ftmpc_solve_f64_kernel)."""
+    wrench-space form does not care).  float64 path: u0 and U within 1e-7 f_max of the exact solution, through the Riccati
+    recursion (auto: ftmpc_solve_ric64_kernel), the wrench-space form (workgroup: ftmpc_solve_ws64_kernel) and the dense
+    factorisation (dense: ftmpc_solve_f64_kernel)."""
     B = 6
     mpc = gpu_mpc_factory(N=N, NT=16, dtype="f64", max_iters=40, kernel_select=sel)
     x0, _, _, xref = qo.make_batch(B, N, 16, 0, 3000 + N)
@@ -315,9 +316,11 @@ def test_f64_kernel_config5_shape(gpu_mpc_factory, sel):
     assert np.abs(out["U"] - ref["U"]).max() / F_MAX < 1e-6
 
 
+@pytest.mark.parametrize("sel", ["auto", "workgroup"])
 @pytest.mark.parametrize("N,NT,seed", [(15, 16, 1), (24, 12, 2), (40, 16, 3), (33, 14, 4), (42, 16, 5), (7, 10, 6)])
-def test_f64_wrench_space_kernel_other_vehicles_horizons_mixed_faults_warm_start(gpu_mpc_factory, N, NT, seed):
-    """ftmpc_solve_ws64_kernel away from the config-5 shape: 10..16 thrusters (random allocation matrices of full row rank),
+def test_f64_wrench_space_kernel_other_vehicles_horizons_mixed_faults_warm_start(gpu_mpc_factory, N, NT, seed, sel):
+    """ftmpc_solve_ric64_kernel (auto, N <= 40; one wave per instance, Newton systems by the Riccati recursion) and
+    ftmpc_solve_ws64_kernel (workgroup, and auto beyond N = 40) away from the config-5 shape: 10..16 thrusters (random allocation matrices of full row rank),
     horizons 7..42 (6 N = 42 .. 252: up to sixteen tiles a side, one and three thruster variables per thread), 0..9 broken
     thrusters mixed in one batch (down to fewer healthy thrusters than wrench components: S rank deficient), warm start and
     a moving reference with a non-zero uref; against the C oracle at the float64 tolerance."""
@@ -328,7 +331,7 @@ def test_f64_wrench_space_kernel_other_vehicles_horizons_mixed_faults_warm_start
         D = rng.standard_normal((6, NT)) * np.array([1, 1, 1, 0.3, 0.3, 0.3])[:, None]
     cfg = _cfg(N, NT) if D is None else qo.QPConfig(N=N, NT=NT, D=D)
     kw = {} if D is None else dict(D=D)
-    mpc = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40, **kw)
+    mpc = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40, kernel_select=sel, **kw)
     x0, ub, stuck, xref = qo.make_batch(B, N, NT, 1, 7800 + seed)
     for b in range(B):
         k = int(rng.integers(0, 9))
@@ -343,7 +346,7 @@ def test_f64_wrench_space_kernel_other_vehicles_horizons_mixed_faults_warm_start
     out = mpc.solve(x0, ub, stuck, xw.reshape(-1, order="F"), uref=uw.reshape(-1, order="F"), warmU=W, return_U=True)
     mpc.set_profiling(True)
     mpc.solve(x0[:4], ub[:4], stuck[:4], xw.reshape(-1, order="F"))
-    assert "ftmpc_solve_ws64_kernel" in mpc.last_kernel_ms()
+    assert ("ftmpc_solve_ric64_kernel" if (sel == "auto" and N <= 40) else "ftmpc_solve_ws64_kernel") in mpc.last_kernel_ms()
     ref = co.solve_batch_complete(cfg, x0, ub, stuck, xw, uref=uw, warmU=W0, nthreads=8)
     assert (out["status"] == 0).all(), np.bincount(out["status"])
     assert np.abs(out["u0"] - ref["u0"]).max() / F_MAX < 1e-7, np.bincount(ref["how"])

@@ -66,7 +66,9 @@ _AB_CASES = [  # (name, N, NT, faults, B, dtype, kernel_select): one batch per k
     ("ws32_8_two_per_thread", 20, 16, 2, 256, "f32", "workgroup"),
     ("refvehicle_wg32", 15, 16, 2, 512, "f32", "dense"),
     ("wsw32_8", 20, 16, 2, 512, "f32", "auto"),
-    ("config5_ws64", 40, 16, 2, 128, "f64", "auto"),
+    ("config5_ric64", 40, 16, 2, 128, "f64", "auto"),
+    ("refvehicle_ric64", 15, 16, 2, 256, "f64", "auto"),
+    ("config5_ws64", 40, 16, 2, 128, "f64", "workgroup"),
     ("config5_f64_dense", 40, 16, 2, 64, "f64", "dense"),
     ("refvehicle_f64", 15, 16, 2, 256, "f64", "dense"),
     ("refvehicle_hull32", 15, 16, 2, 512, "f32", "wrench"),      # kernel 11 through ftmpc_solve_wrench_batch

@@ -65,6 +65,21 @@ def executed_flops_wrench(N, na, iters):
     return f_lin + f_cond + f_h + f_g + f_once + iters * f_it
 
 
+def executed_flops_riccati(N, na, iters):
+    """Work the Riccati kernel (ftmpc_solve_ric64_kernel) EXECUTES for one instance with `na` healthy thrusters: no condensing
+    and no Hessian; the start gradient by one forward and one adjoint sweep; per interior-point iteration the backward Riccati
+    sweep (per stage S A, S Bt, Bt'SBt, Bt'SA, A'SA, the Cholesky + inverse of the na x na block, W Rux, Y'Y) and two right-hand
+    sides of one backward and one forward vector sweep each (four matrix-vector products per stage and sweep), plus the
+    element-wise work over the N na thruster variables (kernel 12)."""
+    nx, ng = 13, 6
+    f_lin = N * (8 * nx ** 3 + 8 * nx ** 2 * ng + 2 * nx * ng * na)
+    mv = 2 * (nx * nx + 2 * nx * na + na * na)                     # A x, Bt u / Bt' s, Y x / Y' w, W v: one sweep stage
+    f_once = N * 2 * mv
+    f_stage = 2 * nx ** 3 + 2 * nx * nx * na + 2 * nx * na * na + 2 * na * nx * nx + 2 * nx ** 3 + 2 * na ** 3 / 3 + na * na * nx + 2 * nx * nx * na
+    f_it = N * (f_stage + 4 * mv) + 40 * N * na
+    return f_lin + f_once + iters * f_it
+
+
 def batch_flops(N, ub, iters, model=algorithmic_flops):
     if model is not algorithmic_flops:
         na = (ub > 0).sum(axis=1)
@@ -183,16 +198,19 @@ def make_line(args, world, elapsed, B, N, NT, iters, status, ub, kernel_ms, para
     peak = F64_PEAK_TFLOPS if f64 else F32_PEAK_TFLOPS
     achieved = flops / (sol_ms * 1e-3) / 1e12
     traffic, traffic_src = traffic_for(dom, B, N, NT)
-    # the wrench-space kernels (8: ws32, 9: ws64) solve the Newton systems through the 6N-variable form: `achieved` / `frac` above
-    # follow SURVEY.md 8(d)'s DENSE flop model -- the work the QP step stands for -- and `executed` what the kernel really does
+    # Kernels 8 / 9 / 10 solve the Newton systems through the 6N-variable wrench-space form and kernel 12 by the Riccati recursion:
+    # they EXECUTE less than SURVEY.md 8(d)'s dense model (the work the QP step stands for).  For them `achieved` / `frac` are
+    # the EXECUTED work -- a fraction of the peak the silicon really delivered -- and the dense-model figure is the note.
     note = {}
-    if "ws32" in dom or "wsw32" in dom or "ws64" in dom:      # (names as ROUTED on this handle: the dense wg32 kernel is not one of them)
-        ex = batch_flops(N, ub, iters, executed_flops_wrench)
-        note = {"executed": {"flops_per_launch": ex, "achieved": ex / (sol_ms * 1e-3) / 1e12, "frac": ex / (sol_ms * 1e-3) / 1e12 / peak,
-                             "model": "bench.py:executed_flops_wrench (condensing in 6 wrench components, one Cholesky of H_w, per iteration "
-                                      "the assembly and Cholesky of K = I + L'SL (6N x 6N) and two solves through wrench space)"},
-                "work_model_note": "achieved / frac: algorithmic flops of the dense condensed IPM (SURVEY.md 8(d)); executed.*: the work "
-                                   "this kernel performs (it factorises 6N x 6N matrices instead of (N na) x (N na))"}
+    exec_model = executed_flops_riccati if "ric64" in dom else (executed_flops_wrench if ("ws32" in dom or "wsw32" in dom or "ws64" in dom) else None)
+    if exec_model is not None:      # (names as ROUTED on this handle: the dense wg32 kernel is not one of them)
+        ex = batch_flops(N, ub, iters, exec_model)
+        note = {"dense_model": {"flops_per_launch": flops, "achieved": achieved, "frac": achieved / peak,
+                                "model": "bench.py:algorithmic_flops (SURVEY.md 8(d): dense condensed IPM at the active dimension and the executed iterations)"},
+                "work_model": f"bench.py:{exec_model.__name__}: the work this kernel performs; dense_model.*: the work the QP step stands for "
+                              "(this kernel does not form or factorise the (N na) x (N na) matrix)"}
+        flops = ex
+        achieved = ex / (sol_ms * 1e-3) / 1e12
     default_shape = (B, N, NT, args.faults) == (65536, 20, 8, 2) and not f64
     return {
         "metric": METRIC if default_shape else f"MPC QP steps/s (whole node) at N={N}, {NT} thrusters, batch {B}",

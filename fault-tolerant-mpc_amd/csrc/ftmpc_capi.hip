@@ -107,6 +107,8 @@ struct ftmpc_handle {
     int grid_wg = 0;
     int64_t wg_slot_words = 0;
     // float64 through the wrench-space form (kernel 9): 6 N <= 256, N * NT <= 768, ten or more thrusters
+    bool sbounds = false;              // state bounds: the thruster-space solve runs on kernel 12's state-bound instantiation
+    double* d_cbar = nullptr;          // [B*N*13] linearisation trajectory (state bounds only)
     bool use_ric64 = false;            // kernel 12: float64, Newton systems by the Riccati recursion, one wave per instance
     int ric_nv = 10;
     int grid_ric = 0;
@@ -289,6 +291,7 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
     lp.warmG = nullptr;
     lp.out_eN = h->tset ? h->d_eN : nullptr;
     lp.tcost = h->d_tcost;
+    lp.out_cbar = h->sbounds ? h->d_cbar : nullptr;
     const int nvar = h->use_f64 ? 0 : (h->nb_max <= 8 ? 1 : (h->nb_max == 9 ? 2 : 3));   // one-wave fp32 instantiations in use
     lp.qlist = h->use_f64 ? nullptr : h->d_qlist;
     lp.qcount = h->d_qctl;
@@ -338,9 +341,20 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
         w.base = sp;
         w.slot = h->ric_slot;
         w.slot_doubles = h->ric_slot_doubles;
+        for (int i = 0; i < FTMPC_NX; ++i) {
+            w.xlb[i] = h->cfg.xlb[i];
+            w.xub[i] = h->cfg.xub[i];
+        }
+        w.cbar = h->sbounds ? h->d_cbar : nullptr;
+        // with state bounds the iteration stops at mu 1e-10 unless the caller asked otherwise, as the other general-constraint
+        // modes do: the barrier weight of an active state row enters the Riccati recursion's state weight (see the kernel)
+        DeviceConsts dcr = h->dc;
+        if (h->sbounds && !(h->cfg.mu_stop > 0)) dcr.mu_stop = 1e-10;
         const int grid = (int)std::min<int64_t>(B, h->grid_ric);
         if (h->profiling) HIP_TRY(h, hipEventRecord(h->ev[12], s));
-        if (h->ric_nv == 4) hipLaunchKernelGGL(ftmpc::ftmpc_solve_ric64_kernel<4>, dim3(grid), dim3(64), 0, s, h->dc, w);
+        if (h->sbounds && h->ric_nv == 6) hipLaunchKernelGGL((ftmpc::ftmpc_solve_ric64_kernel<6, true>), dim3(grid), dim3(64), 0, s, dcr, w);
+        else if (h->sbounds) hipLaunchKernelGGL((ftmpc::ftmpc_solve_ric64_kernel<10, true>), dim3(grid), dim3(64), 0, s, dcr, w);
+        else if (h->ric_nv == 4) hipLaunchKernelGGL(ftmpc::ftmpc_solve_ric64_kernel<4>, dim3(grid), dim3(64), 0, s, h->dc, w);
         else if (h->ric_nv == 6) hipLaunchKernelGGL(ftmpc::ftmpc_solve_ric64_kernel<6>, dim3(grid), dim3(64), 0, s, h->dc, w);
         else hipLaunchKernelGGL(ftmpc::ftmpc_solve_ric64_kernel<10>, dim3(grid), dim3(64), 0, s, h->dc, w);
         HIP_TRY(h, hipGetLastError());
@@ -505,7 +519,7 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
 
 extern "C" {
 
-int32_t ftmpc_version(void) { return 410; }
+int32_t ftmpc_version(void) { return 420; }
 
 #ifndef FTMPC_BUILD_ID
 #define FTMPC_BUILD_ID "unknown"
@@ -543,6 +557,10 @@ int ftmpc_default_config(ftmpc_config* cfg, int32_t N, int32_t NT) {
     cfg->r[1] = 3.5 / (cfg->mass * 0.6 * 0.6);
     cfg->rho = 0.05;
     cfg->mu_stop = 0.0;  /* library default by dtype */
+    for (int i = 0; i < FTMPC_NX; ++i) {      // no state bounds (the reference's default: params "xub" / "xlb" are None)
+        cfg->xlb[i] = -FTMPC_NO_BOUND;
+        cfg->xub[i] = FTMPC_NO_BOUND;
+    }
     if (NT == 16) {
         // sys_model.py:73-123 restated from the thruster geometry
         const double d1 = 0.12, d2 = 0.09, d3 = 0.05;
@@ -613,7 +631,7 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
     h->ws_nb = (6 * cfg->N <= 96) ? 6 : 8;
     // the terminal set: the thruster-space solve with those rows exists in float64 only, so an fp32 handle that asks for it
     // solves THAT form on the float64 kernel; its two-stage form (ftmpc_solve_wrench_batch) still runs on kernel 11
-    const bool solve_f64 = cfg->dtype == FTMPC_DTYPE_F64 || cfg->terminal_set != 0;
+    const bool solve_f64 = cfg->dtype == FTMPC_DTYPE_F64 || cfg->terminal_set != 0 || cfg->state_bounds != 0;
     h->use_ws = !solve_f64 && cfg->kernel_select != FTMPC_KERNEL_DENSE && h->nb_max > 10 && 6 * cfg->N <= 128 &&
                 cfg->N * cfg->NT <= ftmpc::wsk::WG * ftmpc::wsk::nvt_of(h->ws_nb);
     // ... on one wave per instance (kernel 10) when the thruster variables fit four (N <= 16) / six (N <= 21) per lane;
@@ -629,8 +647,19 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
     h->ws64_nvt = (cfg->N * cfg->NT <= ftmpc::ws64k::WG) ? 1 : 3;
     // float64 box QP (no terminal set): the Riccati recursion on one wave per instance (kernel 12) for every horizon up to 40;
     // kernel_select = FTMPC_KERNEL_WORKGROUP keeps kernel 9 (the wrench-space form), FTMPC_KERNEL_DENSE the dense float64 kernel
-    h->use_ric64 = h->use_f64 && cfg->terminal_set == 0 && cfg->kernel_select == FTMPC_KERNEL_AUTO && cfg->N <= 40;
-    h->ric_nv = cfg->N <= 16 ? 4 : (cfg->N <= 24 ? 6 : 10);
+    h->sbounds = cfg->state_bounds != 0;
+    if (h->sbounds && (cfg->terminal_set != 0 || cfg->N > 40)) {
+        delete h;
+        return fail(nullptr, FTMPC_ERR_ARG, "state_bounds needs N <= 40 and no terminal_set (the state-bound rows live on the Riccati kernel)");
+    }
+    if (h->sbounds)
+        for (int i = 0; i < FTMPC_NX; ++i)
+            if (!(cfg->xlb[i] < cfg->xub[i])) {
+                delete h;
+                return fail(nullptr, FTMPC_ERR_ARG, "state_bounds: xlb[i] < xub[i] is required for every component (use +-FTMPC_NO_BOUND for none)");
+            }
+    h->use_ric64 = h->use_f64 && cfg->terminal_set == 0 && (cfg->kernel_select == FTMPC_KERNEL_AUTO || h->sbounds) && cfg->N <= 40;
+    h->ric_nv = (cfg->N <= 16 && !h->sbounds) ? 4 : (cfg->N <= 24 ? 6 : 10);
     if (h->use_ric64) h->use_ws64 = false;
     h->tset = cfg->terminal_set != 0;
     if (h->tset) {
@@ -701,7 +730,9 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
               grow(h, &h->d_dbgv64, 3 * (int64_t)h->npad_max + 4) != FTMPC_OK;
         if (!bad && h->use_ric64) {
             int per = 0;
-            if (h->ric_nv == 4) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_ric64_kernel<4>, 64, 0);
+            if (h->sbounds && h->ric_nv == 6) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_ric64_kernel<6, true>, 64, 0);
+            else if (h->sbounds) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_ric64_kernel<10, true>, 64, 0);
+            else if (h->ric_nv == 4) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_ric64_kernel<4>, 64, 0);
             else if (h->ric_nv == 6) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_ric64_kernel<6>, 64, 0);
             else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_ric64_kernel<10>, 64, 0);
             h->grid_ric = h->num_cu * std::max(1, per);
@@ -792,7 +823,7 @@ int ftmpc_destroy(ftmpc_handle* h) {
     void* ptrs[] = {h->rec, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, h->d_uref, h->d_warm, h->d_u0, h->d_U,
                     h->d_status, h->d_iters, h->hs[0], h->hs[1], h->hs[2], h->d_dbgH, h->d_dbgv, h->Hs, h->Ls, h->Eall, h->d_dbgH64, h->d_dbgv64,
                     h->d_atau, h->d_aub, h->d_au, h->d_ast, h->d_ait, h->d_qlist, h->d_qctl, h->d_term, h->d_eN, h->gHs, h->gLs,
-                    h->gEall, h->wg_slot, h->ws_slot, h->ws64_slot, h->ric_slot, h->wsw_slot, h->hull_slot, h->d_tcost, h->d_cost, h->d_sqU, h->d_sqQ, h->d_sqT, h->d_sqJ, h->d_sqF, h->d_hullA, h->d_hullb, h->d_warmG, h->d_tau0, h->d_G, h->d_taud, h->d_hullset, h->d_ast2};
+                    h->gEall, h->wg_slot, h->ws_slot, h->ws64_slot, h->ric_slot, h->d_cbar, h->wsw_slot, h->hull_slot, h->d_tcost, h->d_cost, h->d_sqU, h->d_sqQ, h->d_sqT, h->d_sqJ, h->d_sqF, h->d_hullA, h->d_hullb, h->d_warmG, h->d_tau0, h->d_G, h->d_taud, h->d_hullset, h->d_ast2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_qcnt) (void)hipHostFree(h->h_qcnt);
@@ -841,6 +872,7 @@ int ftmpc_reserve(ftmpc_handle* h, int64_t max_batch) {
     if ((rc = grow(h, &h->d_iters, B)) != FTMPC_OK) return rc;
     if (!h->use_f64 && (rc = grow(h, &h->d_qlist, 4 * B)) != FTMPC_OK) return rc;
     if ((rc = grow(h, &h->d_eN, B * 9)) != FTMPC_OK) return rc;
+    if (h->sbounds && (rc = grow(h, &h->d_cbar, B * h->cfg.N * 13)) != FTMPC_OK) return rc;
     h->cap_batch = B;
     return FTMPC_OK;
 }
@@ -1227,6 +1259,7 @@ static int wrench_enqueue(ftmpc_handle* h, int64_t B, int32_t hull_rows, bool ha
     lp.warmG = d_warmG;
     lp.out_eN = h->d_eN;
     lp.tcost = h->d_tcost;
+    lp.out_cbar = nullptr;
     launch_linearize(h, B, (int)((B + 63) / 64), s, lp);
     HIP_TRY(h, hipGetLastError());
     // the wrench problem stops at mu 1e-10 unless the caller asked otherwise (general rows: see ftmpc_config.mu_stop)

@@ -139,6 +139,7 @@ struct LinParams {
     const double* warmG;
     double* out_eN;         // nullptr or [B*9]: terminal tracking error c_N[0:9] - xref_N at the linearisation point
     const TermCost* tcost;  // nullptr or the non-quadratic terminal-cost terms: W e_N gets + 1/2 grad V_nq(e_N)
+    double* out_cbar;       // nullptr or [B*N*13]: the linearisation trajectory c_1 .. c_N = [p, v, omega, q] (state-bound rows)
 };
 
 struct SolveParams {

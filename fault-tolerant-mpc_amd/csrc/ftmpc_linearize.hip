@@ -333,6 +333,16 @@ __global__ void __launch_bounds__(64) ftmpc_linearize_kernel(const DeviceConsts 
         for (int a = 0; a < 3; ++a) w[a] += dt / 6.0 * (kw[0][a] + 2 * kw[1][a] + 2 * kw[2][a] + kw[3][a]);
         for (int a = 0; a < 4; ++a) q[a] += dt / 6.0 * (kq[0][a] + 2 * kq[1][a] + 2 * kq[2][a] + kq[3][a]);
 
+        // ---- the linearisation trajectory itself, for the state-bound rows (xlb <= c_{k+1} <= xub, spiraling_mpc.py:179-185) ----
+        if (P.out_cbar && writes_rest && b0 + lane < P.B) {
+            double* cb = P.out_cbar + (b * N + k) * 13;
+            for (int a = 0; a < 3; ++a) {
+                cb[a] = pos[a];
+                cb[3 + a] = vel[a];
+                cb[6 + a] = w[a];
+            }
+            for (int a = 0; a < 4; ++a) cb[9 + a] = q[a];
+        }
         // ---- weighted tracking error of stage k+1: W (c[0:9] - xref) ----
         pbase = REC_BPF;
         if (writes_rest) {

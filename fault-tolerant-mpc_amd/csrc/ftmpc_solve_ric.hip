@@ -85,7 +85,9 @@ __device__ __forceinline__ double mvt_part(const f64x4& M, const f64x4& xr) { re
 
 // per-wave global slot, in doubles: per stage the tiles W_k | Y_k, then the interior-point state of the thruster variables
 // (sl, su, zl, zu, grad, da: NSTATE arrays of NV x 64 doubles, variable (stage 4 v + q, thruster a) at v * 64 + lane)
-constexpr int NSTATE = 6;
+// with state bounds eight more: slack / dual / carried primal residual of the upper and of the lower row of (stage, state
+// component), the state-space part psi of the gradient and the predictor's state step
+constexpr int NSTATE = 14;
 __host__ __device__ constexpr int64_t state_off(int N) { return (int64_t)N * 2 * 256; }
 __host__ __device__ constexpr int64_t slot_doubles(int N) { return state_off(N) + (int64_t)NSTATE * ((N + 3) / 4) * 64; }
 }  // namespace rick
@@ -94,6 +96,10 @@ struct SolveRicParams {
     SolveParams base;     // rec is double; qhead: shared instance cursor (zeroed by the host) or nullptr (static stride)
     double* slot;         // [gridDim.x][slot_doubles]: per stage the tiles W_k | Y_k in register order, then the interior-point state
     int64_t slot_doubles;
+    // state bounds (template SB; reference spiraling_mpc.py:129-130,179-185): xlb <= c_j <= xub on the orbit-centre state of the
+    // stages j = 1 .. N-1; |bound| >= 1e299 = no row.  cbar: [B*N*13] the linearisation trajectory c_1 .. c_N (ftmpc_linearize.hip)
+    double xlb[13], xub[13];
+    const double* cbar;
 };
 
 #ifndef FTMPC_RIC_WAVES
@@ -103,10 +109,17 @@ struct SolveRicParams {
 // of the variables (six doubles each) lives in the per-wave GLOBAL slot, not in registers: it is touched only by the element-wise
 // passes between the sweeps (1.5 % of the time), and out of the register file it leaves room for a second wave per SIMD -- every
 // phase of this kernel is a dependent chain (MFMA accumulation, pivots through LDS, DPP reductions) that a second wave fills.
-template <int NV>
+// SB: the reference's optional STATE BOUNDS as two more families of rows  +-dx_j <= h.  In this un-condensed form they are what
+// box bounds on the states are in any optimal-control interior point: a diagonal barrier term Sx_j on the state weight of their
+// stage and a state-linear term q_j of the Newton problem -- no dense rows through the sensitivities, no extra factorisation
+// work.  The objective gradient is carried as  grad + Gbar' psi  (grad per thruster variable as before, psi_j per state of stage
+// j, never condensed: the sweeps apply Gbar' implicitly), and both parts follow the step through the Newton identity:
+//     grad += alpha (rhs_u - Sigma dd),     psi_j += alpha (-q_j - Sx_j dx_j).
+template <int NV, bool SB = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_RIC_WAVES, FTMPC_RIC_WAVES))) ftmpc_solve_ric64_kernel(const DeviceConsts C, const SolveRicParams Q) {
     using namespace rick;
     constexpr int NS = 4 * NV;
+    __shared__ __attribute__((aligned(32))) double qxv[SB ? NS * 16 : 4];   // per stage the state-linear term q_j of the Newton problem (position 4 q + rr = element q + 4 rr)
     const SolveParams& P = Q.base;
     __shared__ __attribute__((aligned(32))) double recbuf[2][REC_STRIDE];
     __shared__ __attribute__((aligned(32))) double rvec[NS * 16];      // per stage 16 doubles: right-hand side in, solution out (natural order)
@@ -221,7 +234,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
         double* const st = slot + state_off(N);
         const int nv = (N + 3) >> 2;
         auto sref = [&](int arr, int v) -> double& { return st[(int64_t)(arr * nv + v) * 64 + lane]; };
-        enum { S_SL = 0, S_SU = 1, S_ZL = 2, S_ZU = 3, S_GRAD = 4, S_DA = 5 };
+        enum { S_SL = 0, S_SU = 1, S_ZL = 2, S_ZU = 3, S_GRAD = 4, S_DA = 5, X_SU = 6, X_ZU = 7, X_RU = 8, X_SL = 9, X_ZL = 10, X_RL = 11, X_PSI = 12, X_DXA = 13 };
+        // state-bound rows of this lane: (stage 4 v + lq in 1 .. N-1, component li < 13), upper and lower
+        const bool xhu = SB && li < 13 && Q.xub[li < 13 ? li : 0] < 1e299, xhl = SB && li < 13 && Q.xlb[li < 13 ? li : 0] > -1e299;
+        auto xrow = [&](int v) { return li < 13 && 4 * v + lq >= 1 && 4 * v + lq <= N - 1; };
         // ---- stage record k (three 8-byte loads per lane) and, in the vector sweeps, the factors W_k, Y_k: requested TWO stages
         // ahead of their use into one of two register sets (a stage of a vector sweep is ~1.5 k cycles, a round trip to the
         // Infinity Cache / HBM under load more), committed to the LDS record buffer when their stage begins ----
@@ -281,7 +297,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
             return vsc[slotv][v64pos(li)];
         };
 
-        // ---- solution of (H + Sigma) x = r by the vector sweeps over the stored factors: r in rvec on entry, x in rvec on exit ----
+        // ---- the Newton problem  min 1/2 x'(Qt + Sx) x [+ q'x] + 1/2 u'(Rt + Sigma) u - r'u  over the stored factors: r in rvec [q in qxv]
+        // on entry, the minimiser u in rvec on exit [and, SB, its states x_{k+1} in wst[k]] ----
         auto ric_solve = [&]() {
             Pre p0, p1;
             // backward: s = p_{k+1} (row layout), w_k = W (Bt' s - r_k) kept for the forward sweep
@@ -292,6 +309,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
                 if (k >= 2) request(p, k - 2, true);
                 f64x4 A, Bt;
                 stage_tiles(recbuf[k & 1], A, Bt);
+                if constexpr (SB) {      // s = p_{k+1} + q_{k+1}
+                    if (k + 1 <= N - 1) s += *reinterpret_cast<const f64x4*>(&qxv[(k + 1) * 16 + 4 * lq]);
+                }
                 const double ru = quad_red<DAdd>(mvt_part(Bt, s)) - rvec[k * 16 + li];
                 const f64x4 w = mv(Wk, ru);
                 if (li == 0) *reinterpret_cast<f64x4*>(&wst[k * 16 + 4 * lq]) = w;
@@ -319,6 +339,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
                 if (lq == 0) rvec[k * 16 + li] = uc;
                 const f64x4 xn = mv2(A, xc, Bt, uc);
                 xc = row2col(xn, k & 1);
+                if constexpr (SB) {
+                    if (lq == 0) wst[k * 16 + li] = xc;      // x_{k+1} of the solution, natural order (w_k has been consumed)
+                }
             };
             request(p0, 0, true);
             if (N >= 2) request(p1, 1, true);
@@ -396,7 +419,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
 
         // ---------------- interior-point iterations (thruster space; the iteration of kernels 3 / 9) ----------------
         int status = 1, nit = 0;
-        const double inv2n = 1.0 / (double)(2 * nt);
+        double mrows = (double)(2 * nt);
         {
             // state at the start: slacks at the box centre, gradient from the sweep above, duals on the central path
             double gm = 0.0;
@@ -409,28 +432,85 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
                 gm = fmax(gm, fabs(g));
             }
             gm = wave_red<DMax>(gm);
-            const double wm = wave_red<DMax>(athr ? ubl : 0.0);
+            double wm = athr ? ubl : 0.0;
+            if constexpr (SB) {      // state rows: slack max(residual, 0.1) and the primal residual the steps shrink (as the terminal rows of kernel 3)
+                double cnt = 0.0;
+                for (int v = 0; v < nv; ++v) {
+                    const int j = 4 * v + lq;
+                    const bool in = xrow(v);
+                    const double dx = in ? wst[(j - 1) * 16 + li] : 0.0;      // dx_j at the start point (forward sweep above)
+                    const double cb = in ? Q.cbar[(inst * N + (j - 1)) * 13 + li] : 0.0;
+                    double su = 1.0, ru = 0.0, sl = 1.0, rl = 0.0;
+                    if (in && xhu) {
+                        const double res = Q.xub[li] - cb - dx;
+                        su = fmax(res, 0.1);
+                        ru = su - res;
+                        wm = fmax(wm, su);
+                        cnt += 1.0;
+                    }
+                    if (in && xhl) {
+                        const double res = cb + dx - Q.xlb[li];
+                        sl = fmax(res, 0.1);
+                        rl = sl - res;
+                        wm = fmax(wm, sl);
+                        cnt += 1.0;
+                    }
+                    sref(X_SU, v) = su;
+                    sref(X_RU, v) = ru;
+                    sref(X_SL, v) = sl;
+                    sref(X_RL, v) = rl;
+                    sref(X_PSI, v) = 0.0;
+                }
+                mrows += wave_red<DAdd>(cnt);
+            }
+            wm = wave_red<DMax>(wm);
             const double mu0 = fmax(0.02 * gm * wm, 1e-3);
             for (int v = 0; v < nv; ++v) {
                 const double z = tvalid(v) ? mu0 / (0.5 * ubl) : 0.0;
                 sref(S_ZL, v) = z;
                 sref(S_ZU, v) = z;
+                if constexpr (SB) {
+                    sref(X_ZU, v) = (xrow(v) && xhu) ? mu0 / sref(X_SU, v) : 0.0;
+                    sref(X_ZL, v) = (xrow(v) && xhl) ? mu0 / sref(X_SL, v) : 0.0;
+                }
             }
         }
+        const double inv2n = 1.0 / mrows;
         for (int it = 0; it <= C.max_iters; ++it) {
-            // mu, and the barrier weights Sigma of this iterate -> rvec (the Riccati sweep reads them per stage)
-            double csum = 0.0;
+            // mu [and the carried primal residual], and the barrier weights of this iterate: Sigma -> rvec [Sx -> wst] (the Riccati sweep reads them per stage)
+            double csum = 0.0, rpn = 0.0;
             wave_lds_fence();
             for (int v = 0; v < nv; ++v) {
                 const bool ok = tvalid(v);
                 const double sl = sref(S_SL, v), su = sref(S_SU, v), zl = sref(S_ZL, v), zu = sref(S_ZU, v);
                 if (ok) csum += sl * zl + su * zu;
                 rvec[(4 * v + lq) * 16 + li] = ok ? zl / sl + zu / su : 0.0;
+                if constexpr (SB) {
+                    double sx = 0.0;
+                    if (xrow(v) && xhu) {
+                        const double s = sref(X_SU, v), z = sref(X_ZU, v);
+                        csum += s * z;
+                        sx += z / s;
+                        rpn = fmax(rpn, fabs(sref(X_RU, v)));
+                    }
+                    if (xrow(v) && xhl) {
+                        const double s = sref(X_SL, v), z = sref(X_ZL, v);
+                        csum += s * z;
+                        sx += z / s;
+                        rpn = fmax(rpn, fabs(sref(X_RL, v)));
+                    }
+                    wst[(4 * v + lq) * 16 + li] = sx;
+                }
             }
             wave_lds_fence();
             const double mu = wave_red<DAdd>(csum) * inv2n;
-            if (!(mu >= C.mu_stop)) {
-                status = (mu == mu) ? 0 : 2;
+            if constexpr (SB) rpn = wave_red<DMax>(rpn);
+            if (!(mu == mu) || !(rpn == rpn)) {
+                status = 2;
+                break;
+            }
+            if (!(mu >= C.mu_stop) && !(rpn >= 1e-9)) {
+                status = 0;
                 break;
             }
             if (it == C.max_iters) break;
@@ -448,9 +528,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
                     if (k >= 2) request(p, k - 2, false);
                     f64x4 A, Bt;
                     stage_tiles(recbuf[k & 1], A, Bt);
-                    const f64x4 S = Pm + weight_tile(k + 1 == N);
-                    const f64x4 SA = hullk::mm_tn64(S, A, zero4), SB = hullk::mm_tn64(S, Bt, zero4);      // (S is symmetric)
-                    f64x4 Ruu = hullk::mm_tn64(Bt, SB, Rt);
+                    f64x4 S = Pm + weight_tile(k + 1 == N);
+                    if constexpr (SB) {
+                        if (k + 1 <= N - 1) {
+                            const double sx = wst[(k + 1) * 16 + li];
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr)
+                                if (lq + 4 * rr == li) S[rr] += sx;
+                        }
+                    }
+                    const f64x4 SA = hullk::mm_tn64(S, A, zero4), SBt = hullk::mm_tn64(S, Bt, zero4);      // (S is symmetric)
+                    f64x4 Ruu = hullk::mm_tn64(Bt, SBt, Rt);
                     const f64x4 Rux = hullk::mm_tn64(Bt, SA, zero4);
                     const f64x4 PA = hullk::mm_tn64(A, SA, zero4);
                     const double sg = rvec[k * 16 + li];
@@ -481,12 +569,27 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
             wave_global_fence();
             S64(1);
             if (__builtin_amdgcn_readfirstlane(!__all(ok))) {
-                status = 2;
+                // (state bounds: Sx ~ 1 / mu on an active row enters S, and P_k = A'SA - Y'Y is then a difference of numbers of that
+                // size: the recursion runs out of digits near mu ~ 1e-11.  As kernel 3's general-constraint modes: a breakdown
+                // once mu < 1e-7 with the primal residual closed ends the iteration as converged)
+                status = (SB && mu < 1e-7 && rpn < 1e-9) ? 0 : 2;
+                --nit;
                 break;
             }
             // predictor: (H + Sig) da = -grad
             wave_lds_fence();
-            for (int v = 0; v < nv; ++v) rvec[(4 * v + lq) * 16 + li] = tvalid(v) ? -sref(S_GRAD, v) : 0.0;
+            for (int v = 0; v < nv; ++v) {
+                rvec[(4 * v + lq) * 16 + li] = tvalid(v) ? -sref(S_GRAD, v) : 0.0;
+                if constexpr (SB) {      // q = psi + Wxu rp_u - Wxl rp_l  (predictor: no second-order term)
+                    double q = 0.0;
+                    if (xrow(v)) {
+                        q = sref(X_PSI, v);
+                        if (xhu) q += sref(X_ZU, v) / sref(X_SU, v) * sref(X_RU, v);
+                        if (xhl) q -= sref(X_ZL, v) / sref(X_SL, v) * sref(X_RL, v);
+                    }
+                    qxv[(4 * v + lq) * 16 + v64pos(li)] = q;
+                }
+            }
             wave_lds_fence();
             ric_solve();
             double ap = 1.0, ad = 1.0;
@@ -503,20 +606,52 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
                     if (dzl_a < 0.0) ad = fmin(ad, -zl / dzl_a);
                     if (dzu_a < 0.0) ad = fmin(ad, -zu / dzu_a);
                 }
+                if constexpr (SB) {      // ds = -rp -+ dx,  dz = -z - z ds / s
+                    double dxa = 0.0;
+                    if (xrow(v)) {
+                        dxa = wst[(4 * v + lq - 1) * 16 + li];
+                        if (xhu) {
+                            const double s = sref(X_SU, v), z = sref(X_ZU, v), ds = -sref(X_RU, v) - dxa, dz = -z - z * ds / s;
+                            if (ds < 0.0) ap = fmin(ap, -s / ds);
+                            if (dz < 0.0) ad = fmin(ad, -z / dz);
+                        }
+                        if (xhl) {
+                            const double s = sref(X_SL, v), z = sref(X_ZL, v), ds = -sref(X_RL, v) + dxa, dz = -z - z * ds / s;
+                            if (ds < 0.0) ap = fmin(ap, -s / ds);
+                            if (dz < 0.0) ad = fmin(ad, -z / dz);
+                        }
+                    }
+                    sref(X_DXA, v) = dxa;
+                }
             }
             ap = wave_red<DMin>(ap);
             ad = wave_red<DMin>(ad);
             csum = 0.0;
-            for (int v = 0; v < nv; ++v)
+            for (int v = 0; v < nv; ++v) {
                 if (tvalid(v)) {
                     const double sl = sref(S_SL, v), su = sref(S_SU, v), zl = sref(S_ZL, v), zu = sref(S_ZU, v), da = sref(S_DA, v);
                     const double dzl_a = -zl - zl * da / sl;
                     const double dzu_a = -zu + zu * da / su;
                     csum += (sl + ap * da) * (zl + ad * dzl_a) + (su - ap * da) * (zu + ad * dzu_a);
                 }
+                if constexpr (SB) {
+                    if (xrow(v)) {
+                        const double dxa = sref(X_DXA, v);
+                        if (xhu) {
+                            const double s = sref(X_SU, v), z = sref(X_ZU, v), ds = -sref(X_RU, v) - dxa, dz = -z - z * ds / s;
+                            csum += (s + ap * ds) * (z + ad * dz);
+                        }
+                        if (xhl) {
+                            const double s = sref(X_SL, v), z = sref(X_ZL, v), ds = -sref(X_RL, v) + dxa, dz = -z - z * ds / s;
+                            csum += (s + ap * ds) * (z + ad * dz);
+                        }
+                    }
+                }
+            }
             const double mu_aff = wave_red<DAdd>(csum) * inv2n;
             double sigma = mu_aff / mu;
             sigma = fmin(fmax(sigma * sigma * sigma, 0.0), 1.0);
+            const double sm = sigma * mu;
             // corrector: rc = s z + ds_a dz_a - sigma mu;  rhs = -(grad - zl + zu) - rcl / sl + rcu / su
             wave_lds_fence();
             for (int v = 0; v < nv; ++v) {
@@ -530,6 +665,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
                     rhs = -(sref(S_GRAD, v) - zl + zu) - rcl / sl + rcu / su;
                 }
                 rvec[(4 * v + lq) * 16 + li] = rhs;
+                if constexpr (SB) {      // q = psi + Wxu rp_u - Wxl rp_l - kappa_xu + kappa_xl,  kappa = (ds_a dz_a - sigma mu) / s
+                    double q = 0.0;
+                    if (xrow(v)) {
+                        const double dxa = sref(X_DXA, v);
+                        q = sref(X_PSI, v);
+                        if (xhu) {
+                            const double s = sref(X_SU, v), z = sref(X_ZU, v), rp = sref(X_RU, v), ds = -rp - dxa, dz = -z - z * ds / s;
+                            q += z / s * rp - (ds * dz - sm) / s;
+                        }
+                        if (xhl) {
+                            const double s = sref(X_SL, v), z = sref(X_ZL, v), rp = sref(X_RL, v), ds = -rp + dxa, dz = -z - z * ds / s;
+                            q -= z / s * rp - (ds * dz - sm) / s;
+                        }
+                    }
+                    qxv[(4 * v + lq) * 16 + v64pos(li)] = q;
+                }
             }
             wave_lds_fence();
             ric_solve();
@@ -550,8 +701,52 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
                     if (dzl < 0.0) ad = fmin(ad, -zl / dzl);
                     if (dzu < 0.0) ad = fmin(ad, -zu / dzu);
                 }
+            if constexpr (SB) {
+                for (int v = 0; v < nv; ++v)
+                    if (xrow(v)) {
+                        const double dx = wst[(4 * v + lq - 1) * 16 + li], dxa = sref(X_DXA, v);
+                        if (xhu) {
+                            const double s = sref(X_SU, v), z = sref(X_ZU, v), rp = sref(X_RU, v), dsa = -rp - dxa, dza = -z - z * dsa / s;
+                            const double ds = -rp - dx, dz = (-(s * z + dsa * dza - sm) - z * ds) / s;
+                            if (ds < 0.0) ap = fmin(ap, -s / ds);
+                            if (dz < 0.0) ad = fmin(ad, -z / dz);
+                        }
+                        if (xhl) {
+                            const double s = sref(X_SL, v), z = sref(X_ZL, v), rp = sref(X_RL, v), dsa = -rp + dxa, dza = -z - z * dsa / s;
+                            const double ds = -rp + dx, dz = (-(s * z + dsa * dza - sm) - z * ds) / s;
+                            if (ds < 0.0) ap = fmin(ap, -s / ds);
+                            if (dz < 0.0) ad = fmin(ad, -z / dz);
+                        }
+                    }
+            }
             ap = fmin(1.0, 0.9995 * wave_red<DMin>(ap));
             ad = fmin(1.0, 0.9995 * wave_red<DMin>(ad));
+            if constexpr (SB) {      // rows and psi follow the step: psi += alpha (-q - Sx dx)
+                for (int v = 0; v < nv; ++v)
+                    if (xrow(v)) {
+                        const double dx = wst[(4 * v + lq - 1) * 16 + li], dxa = sref(X_DXA, v);
+                        double q = sref(X_PSI, v), sx = 0.0;
+                        if (xhu) {
+                            const double s = sref(X_SU, v), z = sref(X_ZU, v), rp = sref(X_RU, v), dsa = -rp - dxa, dza = -z - z * dsa / s;
+                            const double ds = -rp - dx, dz = (-(s * z + dsa * dza - sm) - z * ds) / s;
+                            q += z / s * rp - (dsa * dza - sm) / s;
+                            sx += z / s;
+                            sref(X_SU, v) = s + ap * ds;
+                            sref(X_ZU, v) = z + ad * dz;
+                            sref(X_RU, v) = (1.0 - ap) * rp;
+                        }
+                        if (xhl) {
+                            const double s = sref(X_SL, v), z = sref(X_ZL, v), rp = sref(X_RL, v), dsa = -rp + dxa, dza = -z - z * dsa / s;
+                            const double ds = -rp + dx, dz = (-(s * z + dsa * dza - sm) - z * ds) / s;
+                            q -= z / s * rp - (dsa * dza - sm) / s;
+                            sx += z / s;
+                            sref(X_SL, v) = s + ap * ds;
+                            sref(X_ZL, v) = z + ad * dz;
+                            sref(X_RL, v) = (1.0 - ap) * rp;
+                        }
+                        sref(X_PSI, v) += ap * (-q - sx * dx);
+                    }
+            }
             for (int v = 0; v < nv; ++v)
                 if (tvalid(v)) {
                     const double sl = sref(S_SL, v), su = sref(S_SU, v), zl = sref(S_ZL, v), zu = sref(S_ZU, v), da = sref(S_DA, v);
@@ -604,5 +799,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
 template __global__ void ftmpc_solve_ric64_kernel<4>(const DeviceConsts, const SolveRicParams);    // N <= 16 (the reference vehicle's horizon)
 template __global__ void ftmpc_solve_ric64_kernel<6>(const DeviceConsts, const SolveRicParams);    // N <= 24
 template __global__ void ftmpc_solve_ric64_kernel<10>(const DeviceConsts, const SolveRicParams);   // N <= 40 (BASELINE config 5)
+template __global__ void ftmpc_solve_ric64_kernel<6, true>(const DeviceConsts, const SolveRicParams);    // with state bounds (N <= 24)
+template __global__ void ftmpc_solve_ric64_kernel<10, true>(const DeviceConsts, const SolveRicParams);   // with state bounds (N <= 40)
 
 }  // namespace ftmpc

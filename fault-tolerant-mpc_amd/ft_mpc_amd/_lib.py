@@ -54,6 +54,7 @@ class ftmpc_config(C.Structure):
         ("tc_root_coef", C.c_double * MAX_TCOST), ("tc_root_eps", C.c_double * MAX_TCOST), ("tc_root_pow", C.c_double * MAX_TCOST),
         ("tc_root_exp", C.c_int32 * (MAX_TCOST * 9)), ("tc_const", C.c_double),
         ("kernel_select", C.c_int32), ("stage_chunks", C.c_int32), ("lin_split_max", C.c_int64),
+        ("state_bounds", C.c_int32), ("sb_reserved", C.c_int32), ("xlb", C.c_double * 13), ("xub", C.c_double * 13),
     ]
 
 

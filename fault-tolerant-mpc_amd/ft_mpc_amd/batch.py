@@ -50,6 +50,10 @@ class MPCConfig:
     kernel_select: str = "auto"
     lin_split_max: int = 0
     stage_chunks: int = 0
+    # state bounds  xlb <= c_k <= xub  on the 13 orbit-centre states [p, v, omega, q] of the stages 1 .. N-1: the reference's optional
+    # controller params "xub" / "xlb" (spiraling_mpc.py:129-130,179-185; None = no bounds, +-inf = no row for that component)
+    xlb: np.ndarray = None
+    xub: np.ndarray = None
 
 
 def _ptr(a, ct=C.c_double):
@@ -100,6 +104,13 @@ class BatchedMPC:
         if cfg.r is not None:
             c.r[:] = list(_f64(cfg.r, 3))
         c.f_virt[:] = list(_f64(cfg.f_virt, 3))
+        if cfg.xlb is not None or cfg.xub is not None:      # (as the reference: one given, the other defaults to no bound)
+            NOB = 1e300
+            lo = np.full(13, -np.inf) if cfg.xlb is None else _f64(cfg.xlb, 13)
+            hi = np.full(13, np.inf) if cfg.xub is None else _f64(cfg.xub, 13)
+            c.state_bounds = 1
+            c.xlb[:] = list(np.clip(lo, -NOB, NOB))
+            c.xub[:] = list(np.clip(hi, -NOB, NOB))
         ts = cfg.terminal_set
         if ts is not None and ts is not False:
             if ts is True:

@@ -8,7 +8,8 @@ force stages instead of 6-D generalized deviation inputs, and `status` is an IPM
 
 `params["formulation"] = "wrench"` switches to the reference's own two-stage structure: a 6-D generalized-force QP
 with the input hull (tools/input_bounds.py, built once per fault set like the reference's InputBounds) followed by the
-min-norm allocation; `params["terminal_set"] = True` adds the 72-row terminal set of config/terminal.yaml.
+min-norm allocation; `params["terminal_set"] = True` adds the 72-row terminal set of config/terminal.yaml;
+`params["xub"]` / `params["xlb"]` (13 values, the reference's own optional keys) bound the orbit-centre state of the stages.
 """
 import copy
 import time
@@ -45,7 +46,11 @@ class SpiralingController:
                                         r=self.spiral_params.r, f_virt=self.spiral_params.f_virt,
                                         rho=float(params.get("rho", 0.05)), device_id=device_id, dtype=dtype,
                                         max_iters=int(params.get("max_iters", 0)),
-                                        terminal_set=True if params.get("terminal_set") else None))
+                                        terminal_set=True if params.get("terminal_set") else None,
+                                        # Bounds on x, default is None (spiraling_mpc.py:129-130; rows :179-185)
+                                        xub=params.get("xub", None), xlb=params.get("xlb", None)))
+        if (params.get("xub") is not None or params.get("xlb") is not None) and self.formulation == "wrench":
+            raise ValueError("state bounds (params 'xub' / 'xlb') are built for formulation='thruster'")
         self.hull = None
         if self.formulation == "wrench":           # spiraling_mpc.py:49: self.bounds = InputBounds(self.model), once
             from .tools.input_bounds import hull_tables

@@ -127,7 +127,21 @@ typedef struct ftmpc_config {
     int32_t kernel_select;
     int32_t stage_chunks;
     int64_t lin_split_max;
+    /*
+     * State bounds  xlb <= c_k <= xub  on the orbit-centre state [p, v, omega, q] of the stages k = 1 .. N-1 (the reference's
+     * optional params "xub" / "xlb", spiraling_mpc.py:129-130,179-185: `con_ineq.append(x_t)` for t < N; the row of stage 0 does not
+     * depend on the decision variables).  state_bounds != 0 adds them to the thruster-space QP of ftmpc_solve_batch; a component
+     * with |bound| >= FTMPC_NO_BOUND has no row.  The solve then runs in float64 on the Riccati kernel whatever the dtype (N <= 40,
+     * no terminal set; kernel_select is ignored): there the rows are a diagonal barrier term on the state weight of their stage,
+     * not dense rows through the sensitivities.  Bounds that cannot be met within the horizon end with FTMPC_STATUS_MAXITER /
+     * _NUMERIC (the reference logs IPOPT's failure and carries on, spiraling_mpc.py:347-352).
+     */
+    int32_t state_bounds;
+    int32_t sb_reserved;
+    double xlb[FTMPC_NX];
+    double xub[FTMPC_NX];
 } ftmpc_config;
+#define FTMPC_NO_BOUND 1e300
 
 #define FTMPC_KERNEL_AUTO 0
 #define FTMPC_KERNEL_DENSE 1

@@ -294,8 +294,40 @@ def general_constraint_fixtures():
           f"{((act_h > 0) & (act_t > 0)).sum()}, kkt max {np.nanmax(cert):.1e}  vs certificate {np.nanmax(dist):.1e}", flush=True)
 
 
+def state_bound_fixture():
+    """The reference's optional state bounds (spiraling_mpc.py:129-130,179-185: xlb <= x_t <= xub on the stages t < N) in the
+    thruster-space QP: velocity and angular-rate bounds that bite on most instances, solved by oracle/qp_oracle.py:ipm_general with
+    its polish and certified (KKT residuals, distance to the primal-dual active-set solution)."""
+    from oracle import qp_oracle as qo
+    N, NT, cnt = 20, 8, 24
+    cfg = qo.QPConfig(N=N, NT=NT)
+    x0, ub, stuck, xref = qo.make_batch(cnt, N, NT, 2, 4321)
+    xub = np.full(13, np.inf)
+    xlb = np.full(13, -np.inf)
+    xub[3:6], xlb[3:6] = 0.9, -0.9            # |v| <= 0.9 m/s
+    xub[6:9], xlb[6:9] = 1.6, -1.6            # |omega| <= 1.6 rad/s
+    U = np.zeros((cnt, N, NT))
+    st = np.zeros(cnt, np.int32)
+    cert = np.full(cnt, np.nan)
+    dist = np.full(cnt, np.nan)
+    act = np.zeros(cnt, np.int32)
+    with np.errstate(all="ignore"):
+        for b in range(cnt):
+            _, U[b], st[b], _, qp = qo.solve_box_state_instance(cfg, x0[b], ub[b], stuck[b], xref, xlb, xub, iters=60)
+            if st[b] == 0:
+                cert[b], dist[b] = _certified(qo, qp, 0)
+                act[b] = (qp["z"][qp["nhull"]:] > 0).sum()
+    assert (st == 0).sum() >= 12 and (act > 0).sum() >= 8 and np.nanmax(cert) < 1e-7 and np.nanmax(dist) < 1e-8, (st, act, cert, dist)
+    np.savez_compressed(OUT / "qp_state_bounds_n20.npz", N=N, NT=NT, x0=x0, ub=ub, stuck=stuck, xref=xref, xlb=xlb, xub=xub, U=U, status=st, kkt=cert,
+                        active_rows=act, D=cfg.D, rho=cfg.rho)
+    print(f"qp_state_bounds_n20.npz  solved {(st == 0).sum()} of {cnt}, with active state rows {(act > 0).sum()}, kkt max {np.nanmax(cert):.1e}  vs certificate {np.nanmax(dist):.1e}", flush=True)
+
+
 if __name__ == "__main__":
     OUT.mkdir(parents=True, exist_ok=True)
+    if "--only-state-bounds" in sys.argv:
+        state_bound_fixture()
+        sys.exit(0)
     if "--only-general" not in sys.argv:
         if "--only-round3" not in sys.argv:
             reference_fixtures()
@@ -303,3 +335,4 @@ if __name__ == "__main__":
             qp_fixtures()
         qp_fixtures_large()
     general_constraint_fixtures()
+    state_bound_fixture()

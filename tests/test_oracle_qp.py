@@ -183,3 +183,24 @@ def test_general_constraint_golden_fixtures_are_reproduced_by_the_oracle():
         assert st == d["status"][b]
         if st == 0:
             assert np.abs(T - d["G"][b]).max() <= 1e-9
+
+
+def test_state_bound_rows_of_the_oracle_and_their_golden_fixture():
+    """The reference's optional state bounds (spiraling_mpc.py:129-130,179-185) as rows of the oracle's general form: the fixture
+    tests/golden/qp_state_bounds_n20.npz re-solved (same verdicts, same sequences), the bounds hold along the linearised
+    prediction, and the solution passes the KKT certificate."""
+    d = np.load(GOLD / "qp_state_bounds_n20.npz")
+    cfg = qo.QPConfig(N=int(d["N"]), NT=int(d["NT"]))
+    seen = 0
+    with np.errstate(all="ignore"):
+        for b in range(0, d["x0"].shape[0], 3):
+            _, U, st, _, qp = qo.solve_box_state_instance(cfg, d["x0"][b], d["ub"][b], d["stuck"][b], d["xref"], d["xlb"], d["xub"], iters=60)
+            assert st == d["status"][b]
+            if st != 0:
+                continue
+            seen += 1
+            assert np.abs(U - d["U"][b]).max() <= 1e-9
+            assert max(qo.kkt_general(qp["H"], qp["g"], qp["C"], qp["h"], qp["d"], qp["z"])) < 1e-7
+            nh = qp["nhull"]
+            assert (qp["C"][nh:] @ qp["d"] <= qp["h"][nh:] + 1e-9).all() and len(qp["srow"]) == qp["h"].size - nh
+    assert seen >= 3

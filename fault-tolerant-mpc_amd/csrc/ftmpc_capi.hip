@@ -30,6 +30,7 @@
 #include "ftmpc_solve_wsw.hip"
 #include "ftmpc_solve_hull.hip"
 #include "ftmpc_solve_ric.hip"
+#include "ftmpc_solve_ricw.hip"
 #include "ftmpc_sim.hip"
 #include "ftmpc_alloc.hip"
 
@@ -143,6 +144,10 @@ struct ftmpc_handle {
     int32_t* d_sqF = nullptr;
     int64_t cap_sqp = 0;
     int64_t cap_hullA = 0, cap_wrench = 0;
+    // kernel 13: the two-stage form in float64 by the Riccati recursion (no terminal set, N <= 40, up to 128 hull rows)
+    double* ricw_slot = nullptr;
+    int64_t ricw_slot_doubles = 0;
+    int grid_ricw = 0;
     bool wrench_handed = false;        // the last two-stage step ran kernel 11 with its hand-over list (d_qctl[0] = its length)
     // debug
     float *d_dbgH = nullptr, *d_dbgv = nullptr;
@@ -823,7 +828,7 @@ int ftmpc_destroy(ftmpc_handle* h) {
     void* ptrs[] = {h->rec, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, h->d_uref, h->d_warm, h->d_u0, h->d_U,
                     h->d_status, h->d_iters, h->hs[0], h->hs[1], h->hs[2], h->d_dbgH, h->d_dbgv, h->Hs, h->Ls, h->Eall, h->d_dbgH64, h->d_dbgv64,
                     h->d_atau, h->d_aub, h->d_au, h->d_ast, h->d_ait, h->d_qlist, h->d_qctl, h->d_term, h->d_eN, h->gHs, h->gLs,
-                    h->gEall, h->wg_slot, h->ws_slot, h->ws64_slot, h->ric_slot, h->d_cbar, h->wsw_slot, h->hull_slot, h->d_tcost, h->d_cost, h->d_sqU, h->d_sqQ, h->d_sqT, h->d_sqJ, h->d_sqF, h->d_hullA, h->d_hullb, h->d_warmG, h->d_tau0, h->d_G, h->d_taud, h->d_hullset, h->d_ast2};
+                    h->gEall, h->wg_slot, h->ws_slot, h->ws64_slot, h->ric_slot, h->ricw_slot, h->d_cbar, h->wsw_slot, h->hull_slot, h->d_tcost, h->d_cost, h->d_sqU, h->d_sqQ, h->d_sqT, h->d_sqJ, h->d_sqF, h->d_hullA, h->d_hullb, h->d_warmG, h->d_tau0, h->d_G, h->d_taud, h->d_hullset, h->d_ast2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_qcnt) (void)hipHostFree(h->h_qcnt);
@@ -1178,13 +1183,22 @@ static bool hull_fp32(const ftmpc_handle* h, int32_t hull_rows) {
            (int64_t)h->cfg.N * 32 <= 64 * ftmpc::hullk::nvc_of(6) && (!h->cfg.terminal_set || h->cfg.term_rows <= 80);
 }
 
+// ... and on kernel 13 (float64, Riccati recursion, one wave per instance: any horizon up to 40, up to 128 hull rows) whenever the
+// handle carries no terminal set and kernel_select is not FTMPC_KERNEL_DENSE: the whole batch where kernel 11 does not apply (float64
+// handles, N > 16, more than 32 rows), and otherwise the instances kernel 11 hands over.  The dense float64 kernel keeps the
+// terminal-set forms and kernel_select = FTMPC_KERNEL_DENSE.
+static bool hull_ricw(const ftmpc_handle* h, int32_t hull_rows) {
+    return !h->cfg.terminal_set && h->cfg.kernel_select != FTMPC_KERNEL_DENSE && h->cfg.N <= 40 && hull_rows <= ftmpc::rickw::MHMAX;
+}
+
 // Validation, workspace and hull tables of the generalized-force formulation (shared by the one-step entry and the closed loop).
 static int wrench_prepare(ftmpc_handle* h, int64_t B, const double* hull_A, int32_t n_sets, const int32_t* hull_set, const double* hull_b,
                           int32_t hull_rows) {
     const int N = h->cfg.N;
     if (6 * N > 256) return fail(h, FTMPC_ERR_ARG, "the generalized-force formulation needs 6 N <= 256");
-    if (hull_rows < 1 || hull_rows > FTMPC_MAX_HULL_ROWS || (int64_t)N * hull_rows > 1024 || n_sets < 1)
-        return fail(h, FTMPC_ERR_ARG, "hull_rows out of range (1..32, N * hull_rows <= 1024) or no hull table");
+    if (hull_rows < 1 || hull_rows > FTMPC_MAX_HULL_ROWS || n_sets < 1) return fail(h, FTMPC_ERR_ARG, "hull_rows out of range (1..128) or no hull table");
+    if (!hull_ricw(h, hull_rows) && (hull_rows > 32 || (int64_t)N * hull_rows > 1024))
+        return fail(h, FTMPC_ERR_ARG, "with the terminal set, kernel_select = FTMPC_KERNEL_DENSE or N > 40 the generalized-force formulation needs hull_rows <= 32 and N * hull_rows <= 1024");
     if (h->cfg.terminal_set && (h->cfg.term_rows < 1 || h->cfg.term_rows > FTMPC_MAX_TERM_ROWS)) return fail(h, FTMPC_ERR_ARG, "term_rows out of range");
     if (hull_set)   // the kernel indexes hull_A by these: a table number outside [0, n_sets) would be an out-of-bounds device read
         for (int64_t b = 0; b < B; ++b)
@@ -1203,9 +1217,21 @@ static int wrench_prepare(ftmpc_handle* h, int64_t B, const double* hull_A, int3
             if ((rc = grow(h, &h->hull_slot, (int64_t)h->grid_hull * h->hull_slot_words)) != FTMPC_OK) return rc;
         }
     }
-    // the float64 kernel's slots: it solves the whole batch where kernel 11 does not apply, and otherwise the instances kernel 11
-    // hands over (weakly active rows / hull and terminal rows active together: see SolveHullParams::fb_list)
-    if (!h->gHs) {   // per-workgroup slots of the 6N-variable problem (separate from the thruster-space slots of this handle)
+    if (hull_ricw(h, hull_rows)) {     // kernel 13's per-wave slots (sized by the row count)
+        const int64_t need = ftmpc::rickw::slot_doubles(N, hull_rows);
+        if (!h->ricw_slot || need > h->ricw_slot_doubles) {
+            int per = 0;
+            if (N <= 24) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_ricw64_kernel<6>, 64, 0);
+            else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_ricw64_kernel<10>, 64, 0);
+            h->grid_ricw = h->num_cu * std::max(1, per);
+            h->ricw_slot_doubles = 0;
+            if ((rc = grow(h, &h->ricw_slot, (int64_t)h->grid_ricw * need)) != FTMPC_OK) return rc;
+            h->ricw_slot_doubles = need;
+        }
+    }
+    // the dense float64 kernel's slots: the terminal-set forms, kernel_select = FTMPC_KERNEL_DENSE, N > 40 -- the whole batch, or what
+    // kernel 11 hands over (hull and terminal rows active together, a polish that did not settle: SolveHullParams::fb_list)
+    if (!hull_ricw(h, hull_rows) && !h->gHs) {   // per-workgroup slots of the 6N-variable problem (separate from the thruster-space slots of this handle)
         const int nbg = (6 * N + 15) / 16;
         h->npad_gen = 16 * nbg;
         h->grid_gen = h->num_cu;
@@ -1302,10 +1328,35 @@ static int wrench_enqueue(ftmpc_handle* h, int64_t B, int32_t hull_rows, bool ha
         else hipLaunchKernelGGL((ftmpc::ftmpc_solve_hull32_kernel<6, false>), dim3(grid), dim3(64), 0, s, dch, q);
         HIP_TRY(h, hipGetLastError());
     }
-    {
-    // the float64 kernel: the whole batch, or what kernel 11 handed over
     const bool handed = hull_fp32(h, hull_rows);
     h->wrench_handed = handed;
+    if (hull_ricw(h, hull_rows)) {      // kernel 13: the whole batch, or what kernel 11 handed over
+        ftmpc::SolveRicwParams q;
+        std::memset(&q, 0, sizeof(q));
+        q.base.B = B;
+        q.base.rec = h->rec;
+        q.base.ub = h->d_ub; q.base.stuck = h->d_stuck;
+        q.base.status = h->d_status; q.base.iters = h->d_iters;
+        q.base.dbg_inst = -1;
+        q.base.qlist = handed ? h->d_ast2 + 2 * h->cap_wrench : nullptr;
+        q.base.qcount = handed ? h->d_qctl : nullptr;
+        HIP_TRY(h, hipMemsetAsync(h->d_qctl + 4, 0, sizeof(int32_t), s));
+        q.base.qhead = h->d_qctl + 4;
+        q.slot = h->ricw_slot;
+        q.slot_doubles = h->ricw_slot_doubles;
+        q.warmG = d_warmG;
+        q.hullA = h->d_hullA;
+        q.hull_set = has_set ? h->d_hullset : nullptr;
+        q.hullb = h->d_hullb;
+        q.hull_rows = hull_rows;
+        q.out_tau0 = h->d_tau0;
+        q.out_G = h->d_G;
+        const int grid = (int)std::min<int64_t>(B, h->grid_ricw);
+        if (h->cfg.N <= 24) hipLaunchKernelGGL(ftmpc::ftmpc_solve_ricw64_kernel<6>, dim3(grid), dim3(64), 0, s, dcg, q);
+        else hipLaunchKernelGGL(ftmpc::ftmpc_solve_ricw64_kernel<10>, dim3(grid), dim3(64), 0, s, dcg, q);
+        HIP_TRY(h, hipGetLastError());
+    } else {
+    // the dense float64 kernel: the whole batch, or what kernel 11 handed over
     Solve64Params q;
     std::memset(&q, 0, sizeof(q));
     q.base.B = B;

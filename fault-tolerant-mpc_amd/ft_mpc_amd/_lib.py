@@ -17,7 +17,7 @@ _SO = Path(os.environ["FTMPC_LIB"]).resolve() if os.environ.get("FTMPC_LIB") els
 
 MAX_NT = 16
 MAX_TERM_ROWS = 80
-MAX_HULL_ROWS = 32
+MAX_HULL_ROWS = 128
 MAX_TCOST = 24
 KERNEL_SLOTS = 7
 KERNEL_AUTO, KERNEL_DENSE, KERNEL_WORKGROUP = 0, 1, 2

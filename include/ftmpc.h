@@ -27,7 +27,8 @@ extern "C" {
 #define FTMPC_MAX_NT 16
 #define FTMPC_MAX_TERM_ROWS 80   /* rows of the terminal set (config/terminal.yaml: 72) */
 #define FTMPC_MAX_TCOST_TERMS 24  /* non-quadratic terms of the terminal cost (config/terminal.yaml: 13 polynomial + 12 root terms) */
-#define FTMPC_MAX_HULL_ROWS 32   /* facets of the generalized-force hull (26 for every fault set of the reference vehicle) */
+#define FTMPC_MAX_HULL_ROWS 128  /* facets of the generalized-force hull (26 for every fault set of the reference vehicle; 112 for a
+                                    generic 8-thruster allocation matrix).  More than 32: float64 Riccati kernel only (no terminal set) */
 #define FTMPC_NX 13
 #define FTMPC_NOPT 9
 #define FTMPC_NG 6

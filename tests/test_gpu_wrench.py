@@ -184,12 +184,38 @@ def test_unreachable_terminal_set_is_reported_not_raised(gpu_mpc_factory):
     assert np.isfinite(out["u0"]).all() and (out["u0"] >= 0).all() and (out["u0"] <= ub + 1e-9).all()
 
 
-def test_hull_with_more_facets_than_the_kernel_holds_is_refused():
-    """The synthetic 8-thruster benchmark matrix is generic: 2 C(8,5) = 112 facets without a fault (the reference
-    vehicle's symmetric layout has 26 for every fault set); the front-end refuses instead of truncating."""
-    x0, ub, stuck, xref = qo.make_batch(4, 20, 8, 0, 1)
-    with pytest.raises(ValueError):
-        hull_tables(qo.QPConfig(N=20, NT=8).D, ub, stuck)
+@pytest.mark.parametrize("dtype,N,nf", [("f32", 20, 0), ("f64", 12, 1), ("f32", 33, 2)])
+def test_generic_vehicle_with_more_than_32_facets(gpu_mpc_factory, dtype, N, nf):
+    """The synthetic 8-thruster benchmark matrix is generic: 2 C(8,5) = 112 facets without a fault (the reference vehicle's
+    symmetric layout has 26 for every fault set; input_bounds.py:43-76 has no limit).  Rounds 2-3 refused such hulls; kernel 13
+    (float64, Riccati recursion: a stage's rows enter as one 6 x 6 block however many they are) takes up to 128, at BASELINE's
+    horizon and beyond, whatever the handle's dtype -- against oracle/qp_oracle.py instance by instance."""
+    NT, B = 8, 12
+    mpc = gpu_mpc_factory(N=N, NT=NT, dtype=dtype, max_iters=40)
+    cfg = qo.QPConfig(N=N, NT=NT)
+    x0, ub, stuck, xref = qo.make_batch(B, N, NT, nf, 7900 + N)
+    hull = hull_tables(cfg.D, ub, stuck)
+    assert hull["rows"] > 32 or nf == 2      # (two of eight broken: six generators, 12 facets -- the same kernel)
+    out = mpc.solve_wrench(x0, ub, stuck, xref.reshape(-1, order="F"), hull=hull, return_G=True)
+    assert mpc.last_handed_over() == 0
+    for b in range(B):
+        assert out["status"][b] == 0 and out["alloc_status"][b] == 0, (b, out["status"][b], out["alloc_status"][b])
+        tau0, T, st, nit, qp = qo.solve_wrench_instance(cfg, x0[b], ub[b], stuck[b], xref)
+        assert st == 0 and qp["mh"] == hull["rows"] or qp["mh"] <= hull["rows"]
+        assert np.abs(out["G"][b] - T).max() / F_MAX <= TOL, (b, np.abs(out["G"][b] - T).max() / F_MAX)
+        assert abs(int(out["iters"][b]) - nit) <= 1
+        want = out["tau0"][b] - cfg.D @ stuck[b]
+        assert np.abs(cfg.D @ out["u0"][b] - want).max() <= 1e-7 * (1 + np.abs(want).max())
+
+
+def test_terminal_set_with_more_than_32_facets_is_refused(gpu_mpc_factory):
+    """The terminal-set forms stay on the dense float64 kernel, which holds 32 rows per stage: refused, not truncated."""
+    from ft_mpc_amd._lib import FtmpcError
+    N, NT = 12, 8
+    x0, ub, stuck, xref = qo.make_batch(4, N, NT, 0, 1)
+    mpc = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40, terminal_set=True)
+    with pytest.raises(FtmpcError):
+        mpc.solve_wrench(x0, ub, stuck, xref.reshape(-1, order="F"), hull=hull_tables(qo.QPConfig(N=N, NT=NT).D, ub, stuck))
 
 
 def test_terminal_set_on_an_fp32_handle(gpu_mpc_factory):
@@ -328,11 +354,15 @@ def test_fp32_wrench_warm_start_reference_window_and_persistent_grid(gpu_mpc_fac
 
 
 def test_fp32_wrench_kernel_select_dense_keeps_the_float64_kernel(gpu_mpc_factory):
+    """kernel_select = "dense" keeps the dense float64 kernel whatever the handle's dtype (same bits from an fp32 and a float64
+    handle); the default float64 route is kernel 13 (Riccati recursion): the same polished solution to 1e-9 f_max."""
     N, NT, B = 15, 16, 16
     x0, ub, stuck, xref = qo.make_batch(B, N, NT, 1, 7800)
     a = gpu_mpc_factory(N=N, NT=NT, dtype="f32", max_iters=40, kernel_select="dense").solve_wrench(x0, ub, stuck, xref.reshape(-1, order="F"), return_G=True)
-    b = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40).solve_wrench(x0, ub, stuck, xref.reshape(-1, order="F"), return_G=True)
+    b = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40, kernel_select="dense").solve_wrench(x0, ub, stuck, xref.reshape(-1, order="F"), return_G=True)
     assert np.array_equal(a["G"], b["G"], equal_nan=True) and np.array_equal(a["status"], b["status"])
+    c = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40).solve_wrench(x0, ub, stuck, xref.reshape(-1, order="F"), return_G=True)
+    assert np.array_equal(c["status"], b["status"]) and np.abs(c["G"] - b["G"]).max() / F_MAX <= 1e-9
 
 
 def test_fp32_wrench_step_against_golden(gpu_mpc_factory):

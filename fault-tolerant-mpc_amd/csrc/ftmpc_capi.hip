@@ -108,6 +108,7 @@ struct ftmpc_handle {
     int grid_wg = 0;
     int64_t wg_slot_words = 0;
     // float64 through the wrench-space form (kernel 9): 6 N <= 256, N * NT <= 768, ten or more thrusters
+    bool tset_thruster = true;         // the thruster form with the terminal set fits the dense float64 kernel's general-constraint mode
     bool sbounds = false;              // state bounds: the thruster-space solve runs on kernel 12's state-bound instantiation
     double* d_cbar = nullptr;          // [B*N*13] linearisation trajectory (state bounds only)
     bool use_ric64 = false;            // kernel 12: float64, Newton systems by the Riccati recursion, one wave per instance
@@ -285,6 +286,8 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
             const double* xref, int64_t xref_stride, const double* uref, int64_t uref_stride,
             const double* warmU, double* out_u0, double* out_U, int32_t* status, int32_t* iters,
             hipStream_t s, int64_t dbg_inst) {
+    if (h->tset && !h->tset_thruster)
+        return fail(h, FTMPC_ERR_ARG, "the thruster form with the terminal set needs N * NT <= 256 (ftmpc_solve_wrench_batch, the reference's two-stage form, has no such limit)");
     if (B <= 0) return FTMPC_OK;
     LinParams lp;
     lp.B = B;
@@ -670,7 +673,8 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
     if (h->tset) {
         const char* why = nullptr;
         if (cfg->term_rows < 1 || cfg->term_rows > FTMPC_MAX_TERM_ROWS) why = "term_rows out of range 1..80";
-        else if (16 * h->nb_max > 256) why = "terminal_set needs N * NT <= 256";
+        h->tset_thruster = 16 * h->nb_max <= 256;      // (the THRUSTER form with terminal rows lives on the dense float64 kernel's n <= 256 mode; the
+                                                       //  two-stage form -- ftmpc_solve_wrench_batch -- has no such limit: kernel 13)
         if (why) {
             delete h;
             return fail(nullptr, FTMPC_ERR_ARG, why);
@@ -1183,12 +1187,13 @@ static bool hull_fp32(const ftmpc_handle* h, int32_t hull_rows) {
            (int64_t)h->cfg.N * 32 <= 64 * ftmpc::hullk::nvc_of(6) && (!h->cfg.terminal_set || h->cfg.term_rows <= 80);
 }
 
-// ... and on kernel 13 (float64, Riccati recursion, one wave per instance: any horizon up to 40, up to 128 hull rows) whenever the
-// handle carries no terminal set and kernel_select is not FTMPC_KERNEL_DENSE: the whole batch where kernel 11 does not apply (float64
-// handles, N > 16, more than 32 rows), and otherwise the instances kernel 11 hands over.  The dense float64 kernel keeps the
-// terminal-set forms and kernel_select = FTMPC_KERNEL_DENSE.
+// ... and on kernel 13 (float64, Riccati recursion, one wave per instance: any horizon up to 40, up to 128 hull rows, with or
+// without the terminal set) unless kernel_select is FTMPC_KERNEL_DENSE: the whole batch where kernel 11 does not apply (float64
+// handles, N > 16, more than 32 rows), and otherwise the instances kernel 11 hands over.  The dense float64 kernel keeps
+// kernel_select = FTMPC_KERNEL_DENSE and N > 40.
 static bool hull_ricw(const ftmpc_handle* h, int32_t hull_rows) {
-    return !h->cfg.terminal_set && h->cfg.kernel_select != FTMPC_KERNEL_DENSE && h->cfg.N <= 40 && hull_rows <= ftmpc::rickw::MHMAX;
+    return h->cfg.kernel_select != FTMPC_KERNEL_DENSE && h->cfg.N <= 40 && hull_rows <= ftmpc::rickw::MHMAX &&
+           (!h->cfg.terminal_set || h->cfg.term_rows <= 80);
 }
 
 // Validation, workspace and hull tables of the generalized-force formulation (shared by the one-step entry and the closed loop).
@@ -1198,7 +1203,7 @@ static int wrench_prepare(ftmpc_handle* h, int64_t B, const double* hull_A, int3
     if (6 * N > 256) return fail(h, FTMPC_ERR_ARG, "the generalized-force formulation needs 6 N <= 256");
     if (hull_rows < 1 || hull_rows > FTMPC_MAX_HULL_ROWS || n_sets < 1) return fail(h, FTMPC_ERR_ARG, "hull_rows out of range (1..128) or no hull table");
     if (!hull_ricw(h, hull_rows) && (hull_rows > 32 || (int64_t)N * hull_rows > 1024))
-        return fail(h, FTMPC_ERR_ARG, "with the terminal set, kernel_select = FTMPC_KERNEL_DENSE or N > 40 the generalized-force formulation needs hull_rows <= 32 and N * hull_rows <= 1024");
+        return fail(h, FTMPC_ERR_ARG, "with kernel_select = FTMPC_KERNEL_DENSE or N > 40 the generalized-force formulation needs hull_rows <= 32 and N * hull_rows <= 1024");
     if (h->cfg.terminal_set && (h->cfg.term_rows < 1 || h->cfg.term_rows > FTMPC_MAX_TERM_ROWS)) return fail(h, FTMPC_ERR_ARG, "term_rows out of range");
     if (hull_set)   // the kernel indexes hull_A by these: a table number outside [0, n_sets) would be an out-of-bounds device read
         for (int64_t b = 0; b < B; ++b)
@@ -1221,7 +1226,9 @@ static int wrench_prepare(ftmpc_handle* h, int64_t B, const double* hull_A, int3
         const int64_t need = ftmpc::rickw::slot_doubles(N, hull_rows);
         if (!h->ricw_slot || need > h->ricw_slot_doubles) {
             int per = 0;
-            if (N <= 24) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_ricw64_kernel<6>, 64, 0);
+            if (h->cfg.terminal_set && N <= 24) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_ricw64_kernel<6, true>, 64, 0);
+            else if (h->cfg.terminal_set) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_ricw64_kernel<10, true>, 64, 0);
+            else if (N <= 24) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_ricw64_kernel<6>, 64, 0);
             else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ftmpc::ftmpc_solve_ricw64_kernel<10>, 64, 0);
             h->grid_ricw = h->num_cu * std::max(1, per);
             h->ricw_slot_doubles = 0;
@@ -1231,6 +1238,13 @@ static int wrench_prepare(ftmpc_handle* h, int64_t B, const double* hull_A, int3
     }
     // the dense float64 kernel's slots: the terminal-set forms, kernel_select = FTMPC_KERNEL_DENSE, N > 40 -- the whole batch, or what
     // kernel 11 hands over (hull and terminal rows active together, a polish that did not settle: SolveHullParams::fb_list)
+    if (h->cfg.terminal_set && !h->d_term) {      // the rows of the terminal set on the device: term_A | term_b
+        if ((rc = grow(h, &h->d_term, (int64_t)h->cfg.term_rows * 10)) != FTMPC_OK) return rc;
+        std::vector<double> t((size_t)h->cfg.term_rows * 10);
+        std::memcpy(t.data(), h->cfg.term_A, (size_t)h->cfg.term_rows * 9 * sizeof(double));
+        std::memcpy(t.data() + (size_t)h->cfg.term_rows * 9, h->cfg.term_b, (size_t)h->cfg.term_rows * sizeof(double));
+        HIP_TRY(h, hipMemcpy(h->d_term, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     if (!hull_ricw(h, hull_rows) && !h->gHs) {   // per-workgroup slots of the 6N-variable problem (separate from the thruster-space slots of this handle)
         const int nbg = (6 * N + 15) / 16;
         h->npad_gen = 16 * nbg;
@@ -1351,8 +1365,14 @@ static int wrench_enqueue(ftmpc_handle* h, int64_t B, int32_t hull_rows, bool ha
         q.hull_rows = hull_rows;
         q.out_tau0 = h->d_tau0;
         q.out_G = h->d_G;
+        q.termA = h->cfg.terminal_set ? h->d_term : nullptr;
+        q.termb = h->cfg.terminal_set ? h->d_term + (int64_t)h->cfg.term_rows * 9 : nullptr;
+        q.term_rows = h->cfg.terminal_set ? h->cfg.term_rows : 0;
+        q.eN = h->d_eN;
         const int grid = (int)std::min<int64_t>(B, h->grid_ricw);
-        if (h->cfg.N <= 24) hipLaunchKernelGGL(ftmpc::ftmpc_solve_ricw64_kernel<6>, dim3(grid), dim3(64), 0, s, dcg, q);
+        if (h->cfg.terminal_set && h->cfg.N <= 24) hipLaunchKernelGGL((ftmpc::ftmpc_solve_ricw64_kernel<6, true>), dim3(grid), dim3(64), 0, s, dcg, q);
+        else if (h->cfg.terminal_set) hipLaunchKernelGGL((ftmpc::ftmpc_solve_ricw64_kernel<10, true>), dim3(grid), dim3(64), 0, s, dcg, q);
+        else if (h->cfg.N <= 24) hipLaunchKernelGGL(ftmpc::ftmpc_solve_ricw64_kernel<6>, dim3(grid), dim3(64), 0, s, dcg, q);
         else hipLaunchKernelGGL(ftmpc::ftmpc_solve_ricw64_kernel<10>, dim3(grid), dim3(64), 0, s, dcg, q);
         HIP_TRY(h, hipGetLastError());
     } else {

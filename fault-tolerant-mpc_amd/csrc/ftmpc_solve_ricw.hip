@@ -29,7 +29,10 @@ __host__ __device__ constexpr int mhs_of(int MH) { return (MH + 15) / 16; }
 __host__ __device__ constexpr int64_t var_off(int N) { return (int64_t)N * 2 * 256; }
 __host__ __device__ constexpr int64_t row_off(int N) { return var_off(N) + (int64_t)NVAR * ((N + 3) / 4) * 64; }
 __host__ __device__ constexpr int64_t xdev_off(int N, int MH) { return row_off(N) + (int64_t)NROW * ((N + 3) / 4) * mhs_of(MH) * 64; }
-__host__ __device__ constexpr int64_t slot_doubles(int N, int MH) { return xdev_off(N, MH) + (int64_t)N * 16; }
+// terminal-set rows (row i = lane + 64 j, j < 2): s | z | carried primal residual | ds_a | dz_a | active | penalty
+constexpr int NTROW = 7;
+__host__ __device__ constexpr int64_t trow_off(int N, int MH) { return xdev_off(N, MH) + (int64_t)N * 16; }
+__host__ __device__ constexpr int64_t slot_doubles(int N, int MH) { return trow_off(N, MH) + (int64_t)NTROW * 2 * 64; }
 }  // namespace rickw
 
 struct SolveRicwParams {
@@ -43,12 +46,24 @@ struct SolveRicwParams {
     int32_t hull_rows;         // <= rickw::MHMAX
     double* out_tau0;          // [B*6]
     double* out_G;             // [B*N*6] or nullptr
+    // terminal set (template TS): rows term_A (e_N + dx_N) <= term_b on the terminal tracking error (spiraling_mpc.py:199-202)
+    const double* termA;       // [term_rows*9]
+    const double* termb;       // [term_rows]
+    const double* eN;          // [B*9] terminal tracking error at the linearisation point (ftmpc_linearize.hip)
+    int32_t term_rows;         // <= 80
 };
 
-template <int NV>      // N <= 4 NV
+// TS: with the terminal set.  Its rows act on the terminal state only: a 9 x 9 term A_T' diag(z / s) A_T on the terminal weight S_N
+// and a 9-vector on the terminal state-linear term -- where the condensed kernels carry a rank-9 dense update of every tile.
+template <int NV, bool TS = false>      // N <= 4 NV
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_RIC_WAVES, FTMPC_RIC_WAVES))) ftmpc_solve_ricw64_kernel(const DeviceConsts C, const SolveRicwParams Q) {
     using namespace rickw;
     constexpr int NS = 4 * NV;
+    constexpr int MTP = 80;
+    __shared__ double s_tA[TS ? MTP * 9 : 2];                             // rows of term_A
+    __shared__ __attribute__((aligned(32))) double m9[TS ? 81 : 2];      // A_T' W A_T
+    __shared__ __attribute__((aligned(32))) double qT[TS ? 16 : 4];      // terminal state-linear term of the rows (position 4 q + rr = element q + 4 rr)
+    __shared__ double x9[TS ? 81 : 2];                                    // (GN GN')[0:9, 0:9]: the norms |A_T,i GN|^2 of the polish's penalties
     const SolveParams& P = Q.base;
     __shared__ __attribute__((aligned(32))) double recbuf[2][REC_STRIDE];
     __shared__ __attribute__((aligned(32))) double vecs[2 * NS * 16];
@@ -148,6 +163,74 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
         auto rref = [&](int arr, int v, int c) -> double& { return rst[(int64_t)((arr * nv + v) * MHS + c) * 64 + lane]; };
         enum { V_D = 0, V_CL = 1, V_D0 = 2, R_S = 0, R_Z = 1, R_DSA = 2, R_DZA = 3, R_ACT = 4 };
         auto rvalid = [&](int v, int c) { return 4 * v + lq < N && 16 * c + li < MH; };
+        const int MT = TS ? Q.term_rows : 0;
+        double* const tst = slot + trow_off(N, MH);
+        auto tref = [&](int arr, int j) -> double& { return tst[(int64_t)(arr * 2 + j) * 64 + lane]; };
+        enum { T_S = 0, T_Z = 1, T_RP = 2, T_DSA = 3, T_DZA = 4, T_ACT = 5, T_W = 6 };
+        auto tvalid = [&](int j) { return TS && lane + 64 * j < MT; };
+        if constexpr (TS) {
+            for (int i = lane; i < MTP * 9; i += 64) s_tA[i] = (i < MT * 9) ? Q.termA[i] : 0.0;
+            if (lane < 16) qT[lane] = 0.0;
+            wave_lds_fence();
+        }
+        // A_T,i . x for a 9-vector in LDS (natural order)
+        auto term_dot = [&](int j, const double* x) -> double {
+            const double* a = s_tA + 9 * (tvalid(j) ? lane + 64 * j : 0);
+            double t = 0.0;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) t += a[r] * x[r];
+            return t;
+        };
+        // m9 = A_T' diag(w) A_T for per-row weights, qT = -A_T' t for per-row values (the LQ convention: + q'x)
+        auto term_blocks = [&](auto wof) {
+            if constexpr (TS) {
+                double acc[45];
+#pragma unroll
+                for (int p = 0; p < 45; ++p) acc[p] = 0.0;
+                for (int j = 0; j < 2; ++j) {
+                    const double w = tvalid(j) ? wof(j) : 0.0;
+                    const double* a = s_tA + 9 * (tvalid(j) ? lane + 64 * j : 0);
+                    int p = 0;
+#pragma unroll
+                    for (int r1 = 0; r1 < 9; ++r1) {
+                        const double wa = w * a[r1];
+#pragma unroll
+                        for (int r2 = 0; r2 <= r1; ++r2) acc[p++] += wa * a[r2];
+                    }
+                }
+                wave_lds_fence();
+                int p = 0;
+#pragma unroll
+                for (int r1 = 0; r1 < 9; ++r1)
+#pragma unroll
+                    for (int r2 = 0; r2 <= r1; ++r2) {
+                        const double t = wave_red<DAdd>(acc[p++]);
+                        if (lane == 0) {
+                            m9[9 * r1 + r2] = t;
+                            m9[9 * r2 + r1] = t;
+                        }
+                    }
+                wave_lds_fence();
+            }
+        };
+        auto term_linear = [&](auto tof) {
+            if constexpr (TS) {
+                double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                for (int j = 0; j < 2; ++j) {
+                    const double t = tvalid(j) ? tof(j) : 0.0;
+                    const double* a = s_tA + 9 * (tvalid(j) ? lane + 64 * j : 0);
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) acc[r] += a[r] * t;
+                }
+                wave_lds_fence();
+#pragma unroll
+                for (int r = 0; r < 9; ++r) {
+                    const double t = wave_red<DAdd>(acc[r]);
+                    if (lane == 0) qT[v64pos(r)] = -t;
+                }
+                wave_lds_fence();
+            }
+        };
         // Rt = 2 R on the six wrench components, identity on the padding
         f64x4 Rt;
 #pragma unroll
@@ -222,6 +305,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
                 const double* rb = recbuf[k & 1];
                 stage_tiles(rb, A, Bt);
                 s += mv(weight_tile(k + 1 == N), xd);      // s = p_{k+1} + q_{k+1}
+                if constexpr (TS) {
+                    if (k + 1 == N) s += *reinterpret_cast<const f64x4*>(&qT[4 * lq]);
+                }
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr)
                     if (lq + 4 * rr < 9) s[rr] += 2.0 * rb[REC_WE + lq + 4 * rr];
@@ -272,7 +358,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
                 if (k >= 2) request(p, k - 2, false);
                 f64x4 A, Bt;
                 stage_tiles(recbuf[k & 1], A, Bt);
-                const f64x4 S = Pm + weight_tile(k + 1 == N);
+                f64x4 S = Pm + weight_tile(k + 1 == N);
+                if constexpr (TS) {
+                    if (k + 1 == N) {
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr)
+                            if (lq + 4 * rr < 9 && li < 9) S[rr] += m9[9 * (lq + 4 * rr) + li];
+                    }
+                }
                 const f64x4 SA = hullk::mm_tn64(S, A, zero4), SBt = hullk::mm_tn64(S, Bt, zero4);
                 f64x4 Ruu = hullk::mm_tn64(Bt, SBt, Rt);
                 const f64x4 Rux = hullk::mm_tn64(Bt, SA, zero4);
@@ -369,11 +462,28 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
         {
             Pre p0, p1;
             double xc = 0.0;
+            f64x4 Xg = zero4;      // (TS) GN GN' by X_{k+1} = A X_k A' + B B'
+            auto transpose = [&](const f64x4& M) -> f64x4 {
+                wave_lds_fence();
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) tsc[(lq + 4 * rr) * 17 + li] = M[rr];
+                wave_lds_fence();
+                f64x4 T;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) T[rr] = tsc[li * 17 + lq + 4 * rr];
+                wave_lds_fence();
+                return T;
+            };
             auto gf = [&](int k, Pre& p) {      // dx_{k+1} = A dx_k + B d_k  -> xdev, wst (natural order)
                 commit(p, k & 1);
                 if (k + 2 < N) request(p, k + 2, false);
                 f64x4 A, Bt;
                 stage_tiles(recbuf[k & 1], A, Bt);
+                if constexpr (TS) {
+                    const f64x4 At = transpose(A), Btr = transpose(Bt);
+                    const f64x4 T1 = hullk::mm_tn64(Xg, At, zero4);          // X A'   (X symmetric)
+                    Xg = hullk::mm_tn64(At, T1, hullk::mm_tn64(Btr, Btr, zero4));      // A X A' + B B'
+                }
                 const f64x4 xn = mv2(A, xc, Bt, rvec[k * 16 + li]);
                 xc = row2col(xn, k & 1);
                 if (lq == 0) {
@@ -386,6 +496,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
             for (int k = 0; k < N; k += 2) {
                 gf(k, p0);
                 if (k + 1 < N) gf(k + 1, p1);
+            }
+            if constexpr (TS) {
+                wave_lds_fence();
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+                    if (lq + 4 * rr < 9 && li < 9) x9[9 * (lq + 4 * rr) + li] = Xg[rr];
+                wave_lds_fence();
             }
             // backward: lam_{k+1} = Qt dx_{k+1} + 2 W e_{k+1} + A_{k+1}' lam_{k+2};  g_k = B' lam_{k+1} + 2 R d_k + c_k;  the open-loop
             // weight S_j = Qt_j + A_j' S_{j+1} A_j alongside: diag(2 R + B' S B) is the diagonal of the condensed Hessian
@@ -442,6 +559,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
                 }
                 for (int v = 0; v < nv; ++v) rref(R_S, v, c) = s0;
             }
+            if constexpr (TS) {      // terminal rows: residual at the start point, slack max(residual, 0.1) and the primal residual the steps shrink
+                for (int j = 0; j < 2; ++j) {
+                    double st = 1.0, rp = 0.0;
+                    if (tvalid(j)) {
+                        const int i = lane + 64 * j;
+                        double res = Q.termb[i] - term_dot(j, wst + (N - 1) * 16);
+#pragma unroll
+                        for (int r = 0; r < 9; ++r) res -= s_tA[9 * i + r] * Q.eN[inst * 9 + r];
+                        st = fmax(res, 0.1);
+                        rp = st - res;
+                        smax = fmax(smax, st);
+                        mrows += 1.0;
+                    }
+                    tref(T_S, j) = st;
+                    tref(T_RP, j) = rp;
+                }
+            }
             smax = wave_red<DMax>(smax);
             const double mu0 = fmax(0.02 * gm * smax, 1e-3);
             for (int v = 0; v < nv; ++v)
@@ -450,6 +584,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
                     rref(R_Z, v, c) = ok ? mu0 / rref(R_S, v, c) : 0.0;
                     mrows += ok ? 1.0 : 0.0;
                 }
+            if constexpr (TS)
+                for (int j = 0; j < 2; ++j) tref(T_Z, j) = tvalid(j) ? mu0 / tref(T_S, j) : 0.0;
             mrows = wave_red<DAdd>(mrows);
         }
         const double inv_m = 1.0 / mrows;
@@ -462,30 +598,55 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
             for (int v = 0; v < nv; ++v)
                 for (int c = 0; c < MHS; ++c)
                     if (rvalid(v, c)) csum += rref(R_S, v, c) * rref(R_Z, v, c);
+            double rpn = 0.0;
+            if constexpr (TS) {
+                for (int j = 0; j < 2; ++j)
+                    if (tvalid(j)) {
+                        csum += tref(T_S, j) * tref(T_Z, j);
+                        rpn = fmax(rpn, fabs(tref(T_RP, j)));
+                    }
+                rpn = wave_red<DMax>(rpn);
+            }
             const double mu = wave_red<DAdd>(csum) * inv_m;
-            if (!(mu == mu)) {
+            if (!(mu == mu) || !(rpn == rpn)) {
                 status = 2;
                 break;
             }
-            if (mu < C.mu_stop) {
+            if (mu < C.mu_stop && rpn < 1e-9) {
                 status = 0;
                 break;
             }
             if (it == C.max_iters) break;
             ++nit;
             form_blocks([&](int v, int c) { return rref(R_Z, v, c) / rref(R_S, v, c); });
+            term_blocks([&](int j) { return tref(T_Z, j) / tref(T_S, j); });
             if (__builtin_amdgcn_readfirstlane(!ric_factor())) {
-                status = (mu < 1e-7) ? 0 : 2;      // (as the float64 kernel: a breakdown this close to the solution ends the iteration as converged)
+                status = (mu < 1e-7 && rpn < 1e-9) ? 0 : 2;      // (as the float64 kernel: a breakdown this close to the solution ends the iteration as converged)
                 --nit;
                 break;
             }
-            // predictor: rows strictly feasible and on s z = rc: no row term
+            // predictor: the hull rows are strictly feasible and on s z = rc: no row term; the terminal rows carry t = -z rp / s
+            term_linear([&](int j) { return -tref(T_Z, j) * tref(T_RP, j) / tref(T_S, j); });
             wave_lds_fence();
             for (int v = 0; v < nv; ++v)
                 if (4 * v + lq < NS) rvec[(4 * v + lq) * 16 + li] = wvalid(v) ? -(vref(V_CL, v) + r2 * vref(V_D, v)) : 0.0;
             wave_lds_fence();
             ric_solve();
             double ap = 1.0, ad = 1.0;
+            if constexpr (TS) {
+                for (int j = 0; j < 2; ++j) {
+                    double ds = 0.0, dz = 0.0;
+                    if (tvalid(j)) {
+                        const double s_ = tref(T_S, j), z = tref(T_Z, j);
+                        ds = -tref(T_RP, j) - term_dot(j, wst + (N - 1) * 16);
+                        dz = -z - z * ds / s_;
+                        if (ds < 0.0) ap = fmin(ap, -s_ / ds);
+                        if (dz < 0.0) ad = fmin(ad, -z / dz);
+                    }
+                    tref(T_DSA, j) = ds;
+                    tref(T_DZA, j) = dz;
+                }
+            }
             for (int v = 0; v < nv; ++v)
                 for (int c = 0; c < MHS; ++c) {
                     double ds = 0.0, dz = 0.0;
@@ -505,11 +666,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
             for (int v = 0; v < nv; ++v)
                 for (int c = 0; c < MHS; ++c)
                     if (rvalid(v, c)) csum += (rref(R_S, v, c) + ap * rref(R_DSA, v, c)) * (rref(R_Z, v, c) + ad * rref(R_DZA, v, c));
+            if constexpr (TS)
+                for (int j = 0; j < 2; ++j)
+                    if (tvalid(j)) csum += (tref(T_S, j) + ap * tref(T_DSA, j)) * (tref(T_Z, j) + ad * tref(T_DZA, j));
             const double mu_aff = wave_red<DAdd>(csum) * inv_m;
             double sigma = mu_aff / mu;
             sigma = fmin(fmax(sigma * sigma * sigma, 0.0), 1.0);
             const double sm = sigma * mu;
-            // corrector: rc = s z + ds_a dz_a - sigma mu,  t = -z + rc / s = (ds_a dz_a - sigma mu) / s
+            // corrector: rc = s z + ds_a dz_a - sigma mu,  t = -z + rc / s = (ds_a dz_a - sigma mu) / s  (terminal rows: - z rp / s more)
+            term_linear([&](int j) { return (tref(T_DSA, j) * tref(T_DZA, j) - sm - tref(T_Z, j) * tref(T_RP, j)) / tref(T_S, j); });
             rhs_with_rows([&](int v) { return -(vref(V_CL, v) + r2 * vref(V_D, v)); },
                           [&](int v, int c) { return (rref(R_DSA, v, c) * rref(R_DZA, v, c) - sm) / rref(R_S, v, c); });
             ric_solve();
@@ -525,8 +690,27 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
                         if (ds < 0.0) ap = fmin(ap, -s / ds);
                         if (dz < 0.0) ad = fmin(ad, -z / dz);
                     }
+            double tds[2] = {0.0, 0.0}, tdz[2] = {0.0, 0.0};
+            if constexpr (TS) {
+                for (int j = 0; j < 2; ++j)
+                    if (tvalid(j)) {
+                        const double s_ = tref(T_S, j), z = tref(T_Z, j), rp = tref(T_RP, j);
+                        tds[j] = -rp - term_dot(j, wst + (N - 1) * 16);
+                        tdz[j] = (-(s_ * z + tref(T_DSA, j) * tref(T_DZA, j) - sm) - z * tds[j]) / s_;
+                        if (tds[j] < 0.0) ap = fmin(ap, -s_ / tds[j]);
+                        if (tdz[j] < 0.0) ad = fmin(ad, -z / tdz[j]);
+                    }
+            }
             ap = fmin(1.0, 0.9995 * wave_red<DMin>(ap));
             ad = fmin(1.0, 0.9995 * wave_red<DMin>(ad));
+            if constexpr (TS) {
+                for (int j = 0; j < 2; ++j)
+                    if (tvalid(j)) {
+                        tref(T_S, j) += ap * tds[j];
+                        tref(T_Z, j) += ad * tdz[j];
+                        tref(T_RP, j) *= (1.0 - ap);
+                    }
+            }
             for (int v = 0; v < nv; ++v) {
                 for (int c = 0; c < MHS; ++c)
                     if (rvalid(v, c)) {
@@ -560,15 +744,39 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
                 const double a2 = (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]) + (a[4] * a[4] + a[5] * a[5]);
                 return pw / fmax(a2, 1e-300);
             };
+            if constexpr (TS) {      // terminal rows: active set, true slack (the carried residual has closed), penalty pw / |A_T,i GN|^2
+                for (int j = 0; j < 2; ++j) {
+                    const bool act = tvalid(j) && tref(T_Z, j) > tref(T_S, j);
+                    tref(T_ACT, j) = act ? 1.0 : 0.0;
+                    if (!act) tref(T_Z, j) = 0.0;
+                    tref(T_S, j) -= tref(T_RP, j);
+                    tref(T_RP, j) = 0.0;
+                    double c2 = 0.0;
+                    const double* a = s_tA + 9 * (tvalid(j) ? lane + 64 * j : 0);
+                    for (int r1 = 0; r1 < 9; ++r1)
+                        for (int r2 = 0; r2 < 9; ++r2) c2 += a[r1] * x9[9 * r1 + r2] * a[r2];
+                    tref(T_W, j) = pw / fmax(c2, 1e-300);
+                }
+            }
             for (int rd = 0; rd < 3 && !verified; ++rd) {
                 form_blocks([&](int v, int c) { return rref(R_ACT, v, c) != 0.0 ? wrow(c) : 0.0; });
+                term_blocks([&](int j) { return tref(T_ACT, j) != 0.0 ? tref(T_W, j) : 0.0; });
                 if (__builtin_amdgcn_readfirstlane(!ric_factor())) break;
                 ++nit;
                 for (int in = 0; in < 2; ++in) {
                     // (H + C_A' W C_A) dd = -grad + C_A' (W s_A - lam);  lam += W (C_A dd - s_A);  s -= C dd;  d += dd;  dx += dx
+                    term_linear([&](int j) { return tref(T_ACT, j) != 0.0 ? tref(T_W, j) * tref(T_S, j) - tref(T_Z, j) : 0.0; });
                     rhs_with_rows([&](int v) { return -(vref(V_CL, v) + r2 * vref(V_D, v)); },
                                   [&](int v, int c) { return rref(R_ACT, v, c) != 0.0 ? wrow(c) * rref(R_S, v, c) - rref(R_Z, v, c) : 0.0; });
                     ric_solve();
+                    if constexpr (TS) {
+                        for (int j = 0; j < 2; ++j)
+                            if (tvalid(j)) {
+                                const double s_ = tref(T_S, j), ch = term_dot(j, wst + (N - 1) * 16);
+                                if (tref(T_ACT, j) != 0.0) tref(T_Z, j) += tref(T_W, j) * (ch - s_);
+                                tref(T_S, j) = s_ - ch;
+                            }
+                    }
                     for (int v = 0; v < nv; ++v) {
                         for (int c = 0; c < MHS; ++c)
                             if (rvalid(v, c)) {
@@ -595,6 +803,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
                                 changed = true;
                             }
                         }
+                if constexpr (TS) {
+                    for (int j = 0; j < 2; ++j)
+                        if (tvalid(j)) {
+                            const bool act = tref(T_ACT, j) != 0.0;
+                            if (act && tref(T_Z, j) < 0.0) {
+                                tref(T_ACT, j) = 0.0;
+                                tref(T_Z, j) = 0.0;
+                                changed = true;
+                            } else if (!act && tref(T_S, j) < -PRES_TOL) {
+                                tref(T_ACT, j) = 1.0;
+                                changed = true;
+                            }
+                        }
+                }
                 verified = __builtin_amdgcn_readfirstlane(!__any(changed));
             }
         }
@@ -637,5 +859,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
 
 template __global__ void ftmpc_solve_ricw64_kernel<6>(const DeviceConsts, const SolveRicwParams);     // N <= 24 (the reference's horizon 15, BASELINE's 20)
 template __global__ void ftmpc_solve_ricw64_kernel<10>(const DeviceConsts, const SolveRicwParams);    // N <= 40
+template __global__ void ftmpc_solve_ricw64_kernel<6, true>(const DeviceConsts, const SolveRicwParams);      // + the terminal set
+template __global__ void ftmpc_solve_ricw64_kernel<10, true>(const DeviceConsts, const SolveRicwParams);
 
 }  // namespace ftmpc

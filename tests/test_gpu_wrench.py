@@ -208,12 +208,12 @@ def test_generic_vehicle_with_more_than_32_facets(gpu_mpc_factory, dtype, N, nf)
         assert np.abs(cfg.D @ out["u0"][b] - want).max() <= 1e-7 * (1 + np.abs(want).max())
 
 
-def test_terminal_set_with_more_than_32_facets_is_refused(gpu_mpc_factory):
-    """The terminal-set forms stay on the dense float64 kernel, which holds 32 rows per stage: refused, not truncated."""
+def test_dense_kernel_with_more_than_32_facets_is_refused(gpu_mpc_factory):
+    """kernel_select = "dense" keeps the dense float64 kernel, which holds 32 rows per stage: refused, not truncated."""
     from ft_mpc_amd._lib import FtmpcError
     N, NT = 12, 8
     x0, ub, stuck, xref = qo.make_batch(4, N, NT, 0, 1)
-    mpc = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40, terminal_set=True)
+    mpc = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40, kernel_select="dense")
     with pytest.raises(FtmpcError):
         mpc.solve_wrench(x0, ub, stuck, xref.reshape(-1, order="F"), hull=hull_tables(qo.QPConfig(N=N, NT=NT).D, ub, stuck))
 
@@ -243,6 +243,30 @@ def test_terminal_set_on_an_fp32_handle(gpu_mpc_factory):
     assert np.isfinite(w32["G"][has]).all()
     free = gpu_mpc_factory(N=N, NT=NT, dtype="f32", max_iters=60).solve_wrench(x0, ub, stuck, xr, return_G=True)
     assert (np.abs(free["G"][both] - w32["G"][both]).max(axis=(1, 2)) / F_MAX > 1e-3).sum() >= 4      # the rows matter
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_reference_formulation_at_the_baseline_horizon(gpu_mpc_factory, dtype):
+    """Hull rows AND the terminal set at N = 20 with 16 thrusters -- the reference's NLP structure (spiraling_mpc.py:175-177,198-202)
+    at every BASELINE config's horizon.  Round 3: the dense float64 kernel only (n = 120 tiles in a global slot).  Now kernel 13
+    (float64, Riccati recursion) whatever the handle's dtype; tracking error on the boundary of the set, against the oracle."""
+    N, NT, B = 20, 16, 192
+    term = load_terminal().term_set
+    At, bt = term.A, term.b.reshape(-1)
+    x0, ub, stuck, xref = _near_terminal_set(B, N, NT, 2, 9400, At, bt, scale=1.0)
+    ref = ob.solve_wrench_batch(N, NT, x0, ub, stuck, xref, term_set=(At, bt), iters=60)
+    mpc = gpu_mpc_factory(N=N, NT=NT, dtype=dtype, max_iters=60, terminal_set=term)
+    out = mpc.solve_wrench(x0, ub, stuck, xref.reshape(-1, order="F"), return_G=True)
+    assert mpc.last_handed_over() == 0
+    assert np.array_equal(ref["status"] == 3, out["status"] == 3)
+    ok_ref, ok = ref["status"] == 0, out["status"] == 0
+    assert ok_ref.sum() >= B // 2 and (ref["active"][ok_ref] > 0).all(axis=1).sum() >= B // 10
+    assert (ok_ref != ok).sum() <= 1, np.flatnonzero(ok_ref != ok)
+    both = ok_ref & ok
+    err = np.abs(out["G"][both] - ref["G"][both]).max(axis=(1, 2)) / F_MAX
+    assert err.max() <= TOL, (err.max(), int(np.flatnonzero(both)[err.argmax()]))
+    assert np.abs(out["iters"][both].astype(int) - ref["iters"][both]).max() <= 1
+    assert out["alloc_status"][both].max() == 0
 
 
 @pytest.mark.parametrize("dtype,tol", [("f32", 1e-4), ("f64", 1e-6)])

@@ -89,9 +89,9 @@ typedef struct ftmpc_config {
     double mu_stop;     /* stop when mean complementarity < mu_stop (<=0: library default) */
     /*
      * Terminal set  term_A (c_N[0:9] - xref_N) <= term_b  (the polytope of config/terminal.yaml, term_set; reference
-     * spiraling_mpc.py:199-202).  terminal_set != 0 adds these rows to the QP; ftmpc_solve_batch then runs on the float64
-     * kernel whatever the dtype (N * (number of variables per stage) <= 256), ftmpc_solve_wrench_batch on the fp32
-     * one-wave kernel for dtype FTMPC_DTYPE_F32 and N <= 16.  An instance whose terminal set cannot
+     * spiraling_mpc.py:199-202).  terminal_set != 0 adds these rows to the QP; ftmpc_solve_batch then runs on the dense float64
+     * kernel whatever the dtype (needs N * NT <= 256: checked when it is called), ftmpc_solve_wrench_batch as described there
+     * (no such limit).  An instance whose terminal set cannot
      * be reached within the horizon ends with FTMPC_STATUS_MAXITER / _NUMERIC (the reference logs IPOPT's failure
      * and carries on, spiraling_mpc.py:347-352).
      */
@@ -246,13 +246,15 @@ int ftmpc_solve_batch_device(ftmpc_handle* h, int64_t B,
  *     decision  tau_k in R^6, k < N: the TOTAL generalized force on the body ( = the reference's u_t + u_r + u_comp + D f_fault )
  *     cost      as ftmpc_solve_batch with ut_k = tau_k - ur_k - [f_virt;0] ( = the reference's deviation input u_t ), no rho term
  *     s.t.      hull_A tau_k <= hull_b  for every stage  [+ the terminal set when the handle's config has terminal_set != 0]
- * and u0 = argmin |u|^2 s.t. D u = tau_0 - D stuck, 0 <= u <= ub.  Needs 6 N <= 256 and N * hull_rows <= 1024.
+ * and u0 = argmin |u|^2 s.t. D u = tau_0 - D stuck, 0 <= u <= ub.  Needs N <= 40 and hull_rows <= FTMPC_MAX_HULL_ROWS (with
+ * kernel_select = FTMPC_KERNEL_DENSE or N > 40: 6 N <= 256, hull_rows <= 32, N * hull_rows <= 1024).
  * Every converged interior-point iterate is finished by an active-set polish (the exact solution on the active set the iterate
- * identifies, its multiplier and slack signs verified; each polish round that factorises counts in iters[]): the float64 kernel
- * returns the oracle's polished solution to 1e-9 f_max.  dtype FTMPC_DTYPE_F32 with N <= 16: one wave per instance with the same
- * polish on fp32 data (measured on 8 192 boundary vehicles: 9e-6 f_max worst; specification 1e-4 f_max on wrenches and on the
- * allocated thrust command); instances whose polish does not settle, and -- with the terminal set -- those with hull and terminal
- * rows active together, are solved again by the float64 kernel inside the same call (ftmpc_last_handed_over).
+ * identifies, its multiplier and slack signs verified; each polish round that factorises counts in iters[]): the float64 kernels
+ * return the oracle's polished solution to 1e-9 f_max.  Routing: dtype FTMPC_DTYPE_F32 with N <= 16 and hull_rows <= 32 runs on one
+ * fp32 wave per instance (ftmpc_solve_hull32_kernel; measured on 8 192 boundary vehicles: 1.4e-6 f_max worst; specification 1e-4
+ * f_max on wrenches and on the allocated thrust command) and hands what it does not certify to the float64 path inside the same
+ * call (ftmpc_last_handed_over); everything else -- float64 handles, N up to 40, up to 128 hull rows, with or without the terminal
+ * set -- on ftmpc_solve_ricw64_kernel (float64, Riccati recursion, one wave per instance).
  *   hull_A    [n_sets][hull_rows*6] row-major facet normals, one table per fault INDEX SET (the normals do not depend on
  *             the fault intensities);  hull_set [B] table number of every instance (NULL: table 0 for all)
  *   hull_b    [B*hull_rows] facet offsets (they carry the intensities: b = n . D (ub/2 + stuck) + sum_i |n . D_i| ub_i / 2);

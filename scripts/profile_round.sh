@@ -43,5 +43,7 @@ shape refvehicle_f64 --horizon 15 --thrusters 16 --batch 4096 --dtype f64 --no-c
 shape n20nt16 --horizon 20 --thrusters 16 --batch 4096 --no-cpu-baseline
 shape nominal8 --faults 0 --no-cpu-baseline
 script_shape wrench_hull32 scripts/wrench_trace.py f32       # the two-stage step: linearise, kernel 11, allocation (N = 15, 16 thrusters, B = 16 384)
-script_shape wrench_f64 scripts/wrench_trace.py f64
+script_shape wrench_f64 scripts/wrench_trace.py f64      # the same on a float64 handle: kernel 13 (Riccati recursion)
+script_shape wrench_f64_n20 scripts/wrench_trace.py f64 20      # ... at BASELINE's horizon
+shape config5_16k --horizon 40 --thrusters 16 --batch 16384 --dtype f64 --no-cpu-baseline      # config 5's whole-node batch on one GPU (eight instances per resident wave)
 cat $OUT/headline/bench.json

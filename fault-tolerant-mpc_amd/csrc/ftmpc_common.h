@@ -43,10 +43,12 @@ constexpr int MAX_NT = 16;
 //   doubles [0, 160)            reference gradient (n <= 160)
 //   doubles [160, 160 + 8N)     wrench perturbations of all stages
 //   doubles [160 + 8N, ..+9(N+1)) stage storage of the sweeps when it does not fit in LDS
-//   then, 256-word aligned, the Hessian tiles (used by the instantiations with NB > 8)
+//   (see slot_backup_off_words) then, 256-word aligned, the Hessian tiles (used by the instantiations with NB > 8)
 __host__ __device__ constexpr int slot_gens_off() { return 160; }
 __host__ __device__ constexpr int slot_stage_off(int N) { return 160 + 8 * N; }
-__host__ __device__ constexpr int slot_tile_off_words(int N) { return ((2 * (160 + 8 * N + 9 * (N + 1)) + 255) / 256) * 256; }
+//   words: 5 x 192 (the interior-point iterate kept while the early polish of kernel 2 runs: five arrays of NV x 64 lanes, NV <= 3)
+__host__ __device__ constexpr int slot_backup_off_words(int N) { return 2 * (160 + 8 * N + 9 * (N + 1)); }
+__host__ __device__ constexpr int slot_tile_off_words(int N) { return ((slot_backup_off_words(N) + 5 * 192 + 255) / 256) * 256; }
 
 // constants shared by both kernels (passed by value as kernel argument)
 struct DeviceConsts {

@@ -923,6 +923,15 @@ static_assert(tile_row_ok(), "state-component permutation of the sensitivity til
 // Resident waves per SIMD of the NB = 8 instantiation (the headline shape: n <= 128).  2: 256 registers and <= 20 KiB of LDS per
 // wave -- Hessian tiles in the per-workgroup global slot, W_J in LDS, see OCC2 below; 1: the round-2 form (512 registers, all
 // tiles in LDS).  Measured, 65 536 double-fault instances: 17.5 ms at 1, 14.1-15.0 ms at 2.
+#ifndef FTMPC_F32_MU_POLISH
+#define FTMPC_F32_MU_POLISH 1e-5f      // leave the interior-point iteration for the active-set polish below this mu (0: never)
+#endif
+#ifndef FTMPC_F32_REFINE_AT_POLISH
+#define FTMPC_F32_REFINE_AT_POLISH 1   // the one float64 gradient is taken where the polish starts (not at mu_refine before it)
+#endif
+#ifndef FTMPC_F32_PW0
+#define FTMPC_F32_PW0 1e3f             // penalty of the polish over max diag(H)
+#endif
 #ifndef FTMPC_F32_OCC
 #define FTMPC_F32_OCC 2
 #endif
@@ -1329,23 +1338,38 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 
             dref[v] = 0.f;
         }
         const float inv2n = 1.0f / (float)(2 * n);
+        // EARLY ACTIVE-SET POLISH (FTMPC_F32_MU_POLISH > 0): once mu falls below it the bounds with z > s are taken as active and the
+        // problem on that set is solved by two multiplier steps with the penalty FTMPC_F32_PW0 max diag(H) on the active bounds -- the
+        // Newton matrix's own shape (Sigma = the penalty on the active variables, 0 elsewhere), so a round of the polish IS a pass of
+        // this loop: one factorisation, two solves.  Signs verified (an active bound with a negative multiplier leaves, a violated
+        // inactive one enters), at most three rounds; the interior-point iterate is kept in the global slot and taken up again if
+        // the set does not settle.  Starts from a float64 gradient at its own iterate.  (oracle/qp_oracle.py:polish_general is the
+        // same method on general rows; scripts/polish_box_study.py the fp32 study: 9.7 -> 8.0 passes, 1.6e-6 f_max from the exact
+        // solution against 9e-6 for the iteration run to mu 1e-11.)
+        int pol = 0;
+        bool pol_tried = !(FTMPC_F32_MU_POLISH > 0.f);
+        unsigned pact = 0u;      // bit 2 v: the lower bound of this lane's variable v is active, bit 2 v + 1: the upper one
+        float pw = 0.f;
+        float* const bkp = P.hscratch + (int64_t)blockIdx.x * P.tile_words + slot_backup_off_words(N);
         for (int it = 0; it <= C.max_iters; ++it) {
             wave_lds_fence();
             const int lane = lane_now();
             const int li = lane & 15, lq = lane >> 4;
             (void)li; (void)lq;
-            const bool do_ref = __builtin_amdgcn_readfirstlane(!refined && mu_last < (float)C.mu_refine);
+            const bool do_ref = __builtin_amdgcn_readfirstlane(!refined && mu_last < (float)C.mu_refine && (pol_tried || !FTMPC_F32_REFINE_AT_POLISH));
             float dcur[NV];
-            if (do_ref || it == 0) {
+            if (it == 0) {
 #pragma unroll
                 for (int v = 0; v < NV; ++v) dcur[v] = valid[v] ? ((sl[v] < su[v]) ? lo[v] + sl[v] : hi[v] - su[v]) : 0.f;
             }
-            if (do_ref) {
-                // one accurate (float64, structured) gradient at the current iterate
+            // one accurate (float64, structured) gradient at the current iterate
+            auto refresh = [&]() {
+                float dnow[NV];
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
+                    dnow[v] = valid[v] ? ((sl[v] < su[v]) ? lo[v] + sl[v] : hi[v] - su[v]) : 0.f;
                     const int e = v * 64 + lane;
-                    if (e < npadr) xvp[e] = dcur[v];
+                    if (e < npadr) xvp[e] = dnow[v];
                 }
                 wave_lds_fence();
                 constexpr int SAVAIL = (NPAD + SH::SEXTRA) * 4;       // bytes of LDS behind dvp
@@ -1359,12 +1383,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
                     const int e = v * 64 + lane;
-                    gref[v] = (valid[v] && e < n) ? gout[e] + 2.0 * C.rho * ((double)ubar[v] + (double)dcur[v]) : 0.0;
-                    dref[v] = dcur[v];
+                    gref[v] = (valid[v] && e < n) ? gout[e] + 2.0 * C.rho * ((double)ubar[v] + (double)dnow[v]) : 0.0;
+                    dref[v] = dnow[v];
                     grad[v] = valid[v] ? (float)gref[v] : 0.f;
                 }
                 refined = true;
                 STAMP(8);
+            };
+            if (do_ref) {
+                refresh();
             } else if (it == 0) {
             // gradient at the start point, gref + H (d - dref).  Later iterates do not need the product
             // again: the Newton system just solved gives  H dd = rhs - Sigma dd,  so the gradient follows
@@ -1454,12 +1481,72 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 
                 if (valid[v]) t += sl[v] * zl[v] + su[v] * zu[v];
             const float mu = wave_sum(t) * inv2n;
             mu_last = mu;
-            if (__builtin_amdgcn_readfirstlane(!(mu >= mu_stop))) {
+            if (__builtin_amdgcn_readfirstlane(!pol && !(mu >= mu_stop))) {
                 status = (mu == mu) ? 0 : 2;
                 break;
             }
             if (it == C.max_iters) break;
             ++nit;
+            if (__builtin_amdgcn_readfirstlane(!pol && !pol_tried && mu < FTMPC_F32_MU_POLISH)) {
+                pol_tried = true;
+                pol = 1;
+                refresh();
+                float hs = 0.f;
+#pragma unroll
+                for (int I = 0; I < NB; ++I) {      // max diag(H): lane (q, col) of the diagonal tile holds -H[16 I + col][16 I + 4 q + r]
+                    const f32x4 t4 = htiles.ld((I * (I + 1)) / 2 + I, lane);
+                    const int r = li - 4 * lq;
+                    const float dg = (r == 0) ? t4.x : (r == 1) ? t4.y : (r == 2) ? t4.z : t4.w;
+                    if (r >= 0 && r < 4 && 16 * I + li < n) hs = fmaxf(hs, -dg);
+                }
+                pw = FTMPC_F32_PW0 * wave_max(hs);
+                pact = 0u;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    bkp[(0 * NV + v) * 64 + lane] = sl[v];
+                    bkp[(1 * NV + v) * 64 + lane] = su[v];
+                    bkp[(2 * NV + v) * 64 + lane] = zl[v];
+                    bkp[(3 * NV + v) * 64 + lane] = zu[v];
+                    bkp[(4 * NV + v) * 64 + lane] = grad[v];
+                    const bool al = valid[v] && zl[v] > sl[v], au = valid[v] && zu[v] > su[v];
+                    pact |= (al ? 1u : 0u) << (2 * v) | (au ? 2u : 0u) << (2 * v);
+                    zl[v] = al ? zl[v] : 0.f;      // the multipliers of the inactive bounds: 0
+                    zu[v] = au ? zu[v] : 0.f;
+                }
+            }
+            // back to the interior-point iterate (the polish did not settle, or its matrix did not factorise)
+            auto pol_abandon = [&]() {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    sl[v] = bkp[(0 * NV + v) * 64 + lane];
+                    su[v] = bkp[(1 * NV + v) * 64 + lane];
+                    zl[v] = bkp[(2 * NV + v) * 64 + lane];
+                    zu[v] = bkp[(3 * NV + v) * 64 + lane];
+                    grad[v] = bkp[(4 * NV + v) * 64 + lane];
+                }
+                pol = 0;
+            };
+            // right-hand side of a multiplier step:  (H + Sigma_A) dd = -grad + C_A' (W s_A - lam),  lower row c = -e, upper row c = +e
+            auto pol_rhs = [&](int v) -> float {
+                float r = 0.f;
+                if (valid[v]) {
+                    r = -grad[v];
+                    if (pact >> (2 * v) & 1u) r -= pw * sl[v] - zl[v];
+                    if (pact >> (2 * v + 1) & 1u) r += pw * su[v] - zu[v];
+                }
+                return r;
+            };
+            // ... and its step: the gradient follows by the Newton identity, the multipliers by lam += W (c'dd - s)
+            auto pol_step = [&](int v, float r, float dd) {
+                if (valid[v]) {
+                    const bool al = pact >> (2 * v) & 1u, au = pact >> (2 * v + 1) & 1u;
+                    grad[v] += r - ((al ? pw : 0.f) + (au ? pw : 0.f)) * dd;
+                    if (al) zl[v] += pw * (-dd - sl[v]);
+                    if (au) zu[v] += pw * (dd - su[v]);
+                    sl[v] += dd;
+                    su[v] -= dd;
+                }
+            };
             // block column 0 of the Hessian from the global slot (NB > 8, and NB = 8 at two waves per SIMD): requested here, the
             // barrier weights below cover part of the trip
             f32x4 pre0[NB];
@@ -1472,6 +1559,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 
                 rsl[v] = __builtin_amdgcn_rcpf(sl[v]);
                 rsu[v] = __builtin_amdgcn_rcpf(su[v]);
                 Sig[v] = valid[v] ? zl[v] * rsl[v] + zu[v] * rsu[v] : 0.f;
+                if (pol) Sig[v] = ((pact >> (2 * v) & 1u) ? pw : 0.f) + ((pact >> (2 * v + 1) & 1u) ? pw : 0.f);
                 const int e = v * 64 + lane;
                 if (e < npadr) dvp[e] = Sig[v];
             }
@@ -1480,14 +1568,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 
             const bool ok = chol_reg<NB, TileStore<NLDS>, true, OCC2>(htiles, dvp, recbuf, n, lane, Tt, Wd, pre0, wlds);
             STAMP(5);
             if (__builtin_amdgcn_readfirstlane(!ok)) {
+                if (pol) {
+                    pol_abandon();
+                    continue;
+                }
                 status = 2;
                 break;
             }
-            // predictor: (H+Sig) da = -grad
+            // predictor: (H+Sig) da = -grad   [polish: the first multiplier step]
+            float rcl[NV], rcu[NV], rhs[NV];
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int e = v * 64 + lane;
-                if (e < npadr) xvp[e] = -grad[v];
+                rhs[v] = pol ? pol_rhs(v) : -grad[v];
+                if (e < npadr) xvp[e] = rhs[v];
             }
             wave_lds_fence();
             STAMP(7);
@@ -1500,7 +1594,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 
                 const int e = v * 64 + lane;
                 da[v] = (e < npadr && valid[v]) ? xvp[e] : 0.f;
                 dzl_a[v] = dzu_a[v] = 0.f;
-                if (valid[v]) {
+                if (pol) {
+                    pol_step(v, rhs[v], da[v]);
+                } else if (valid[v]) {
                     dzl_a[v] = -zl[v] - zl[v] * da[v] * rsl[v];
                     dzu_a[v] = -zu[v] + zu[v] * da[v] * rsu[v];
                     const float rda = __builtin_amdgcn_rcpf(da[v]);
@@ -1519,13 +1615,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 
             const float mu_aff = wave_sum(t) * inv2n;
             float sigma = mu_aff / mu;
             sigma = fminf(fmaxf(sigma * sigma * sigma, 0.f), 1.f);
-            // corrector
-            float rcl[NV], rcu[NV], rhs[NV];
+            // corrector   [polish: the second multiplier step]
             wave_lds_fence();
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 rcl[v] = rcu[v] = rhs[v] = 0.f;
-                if (valid[v]) {
+                if (pol) {
+                    rhs[v] = pol_rhs(v);
+                } else if (valid[v]) {
                     rcl[v] = sl[v] * zl[v] + da[v] * dzl_a[v] - sigma * mu;
                     rcu[v] = su[v] * zu[v] - da[v] * dzu_a[v] - sigma * mu;
                     rhs[v] = -(grad[v] - zl[v] + zu[v]) - rcl[v] * rsl[v] + rcu[v] * rsu[v];
@@ -1540,6 +1637,30 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 
             float dd[NV], dzl[NV], dzu[NV];
             ap = 1e30f;
             ad = 1e30f;
+            if (pol) {
+                bool changed = false;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const int e = v * 64 + lane;
+                    pol_step(v, rhs[v], (e < npadr && valid[v]) ? xvp[e] : 0.f);
+                    if (valid[v]) {
+                        const unsigned bl = 1u << (2 * v), bu = 2u << (2 * v);
+                        if (pact & bl) {
+                            if (zl[v] < 0.f) { zl[v] = 0.f; pact &= ~bl; changed = true; }
+                        } else if (sl[v] < -1e-6f * ubv[v]) { pact |= bl; changed = true; }
+                        if (pact & bu) {
+                            if (zu[v] < 0.f) { zu[v] = 0.f; pact &= ~bu; changed = true; }
+                        } else if (su[v] < -1e-6f * ubv[v]) { pact |= bu; changed = true; }
+                    }
+                }
+                STAMP(7);
+                if (!__any(changed)) {
+                    status = 0;
+                    break;
+                }
+                if (++pol > 3) pol_abandon();
+                continue;
+            }
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int e = v * 64 + lane;
@@ -1577,7 +1698,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 
 #pragma unroll
         for (int v = 0; v < NV; ++v)
             if (valid[v]) {
-                float u = (sl[v] < su[v]) ? sl[v] : ubv[v] - su[v];
+                float u = fminf(fmaxf((sl[v] < su[v]) ? sl[v] : ubv[v] - su[v], 0.f), ubv[v]);      // (a polished active bound sits at 0 +- rounding)
                 if (status == 2) u = ubar[v];
                 ubuf[kcol[v] * NT + s_act[acol[v]]] = u;
             }

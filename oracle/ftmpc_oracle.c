@@ -28,7 +28,7 @@
 #define MAX_NT 16
 
 typedef struct {
-    int32_t N, NT, max_iters, reserved;
+    int32_t N, NT, max_iters, flags; /* flags bit 0: no active-set polish (the interior-point iteration to mu_stop alone) */
     double dt, mass;
     double J[9];
     double D[6 * MAX_NT]; /* row-major 6 x NT, row stride NT */
@@ -378,9 +378,76 @@ static void chol_solve(const double* L, int n, double* x) {
     }
 }
 
-/* returns iterations; status: 0 converged, 1 maxiter, 2 numeric */
+/* Active-set polish of a box QP from an interior-point iterate (the box-row case of oracle/qp_oracle.py:polish_general; what
+ * ftmpc_solve_ric.hip and ftmpc_solve.hip run on the device): the bounds with z > s are taken as active and the problem on that set
+ * is solved by two method-of-multipliers steps with the penalty W = 1e6 max diag(H) on the active bounds,
+ *     (H + Sigma_A) dd = -(H d + g) + C_A' (W s_A - lam),   lam += W (C_A dd - s_A),
+ * then the signs are verified: an active bound with a negative multiplier leaves, an inactive bound that is violated enters; at
+ * most three rounds.  Returns the rounds run (> 0) with the exact solution on the verified set in d, or 0 (d untouched). */
+static int polish_box(const double* H, const double* g, const double* lo, const double* hi, int n, const double* sl, const double* su,
+                      const double* zl, const double* zu, double* d, double* M, double* w6) {
+    double *psl = w6, *psu = w6 + n, *pzl = w6 + 2 * n, *pzu = w6 + 3 * n, *r = w6 + 4 * n, *act = w6 + 5 * n;
+    double hs = 0;
+    for (int i = 0; i < n; ++i) {
+        if (H[(size_t)i * n + i] > hs) hs = H[(size_t)i * n + i];
+        const int al = zl[i] > sl[i], au = zu[i] > su[i];
+        act[i] = (double)(al + 2 * au);
+        psl[i] = sl[i];
+        psu[i] = su[i];
+        pzl[i] = al ? zl[i] : 0.0;
+        pzu[i] = au ? zu[i] : 0.0;
+    }
+    const double pw = 1e6 * hs;
+    for (int rd = 1; rd <= 3; ++rd) {
+        memcpy(M, H, (size_t)n * n * sizeof(double));
+        for (int i = 0; i < n; ++i) {
+            const int a = (int)act[i];
+            M[(size_t)i * n + i] += ((a & 1) ? pw : 0.0) + ((a & 2) ? pw : 0.0);
+        }
+        if (chol(M, n) != 0) return 0;
+        for (int in = 0; in < 2; ++in) {
+            for (int i = 0; i < n; ++i) {
+                double t = g[i];      /* the gradient H d + g at the polish's own iterate, d read back from the nearer slack */
+                const double* row = H + (size_t)i * n;
+                for (int k = 0; k < n; ++k) t += row[k] * ((psl[k] < psu[k]) ? lo[k] + psl[k] : hi[k] - psu[k]);
+                const int a = (int)act[i];
+                r[i] = -t - ((a & 1) ? pw * psl[i] - pzl[i] : 0.0) + ((a & 2) ? pw * psu[i] - pzu[i] : 0.0);
+            }
+            chol_solve(M, n, r);
+            for (int i = 0; i < n; ++i) {
+                const int a = (int)act[i];
+                if (a & 1) pzl[i] += pw * (-r[i] - psl[i]);
+                if (a & 2) pzu[i] += pw * (r[i] - psu[i]);
+                psl[i] += r[i];
+                psu[i] -= r[i];
+            }
+        }
+        int changed = 0;
+        for (int i = 0; i < n; ++i) {
+            int a = (int)act[i];
+            if (a & 1) {
+                if (pzl[i] < 0) { pzl[i] = 0; a &= ~1; changed = 1; }
+            } else if (psl[i] < -1e-10) { a |= 1; changed = 1; }
+            if (a & 2) {
+                if (pzu[i] < 0) { pzu[i] = 0; a &= ~2; changed = 1; }
+            } else if (psu[i] < -1e-10) { a |= 2; changed = 1; }
+            act[i] = (double)a;
+        }
+        if (!changed) {
+            for (int i = 0; i < n; ++i) {
+                const double di = (psl[i] < psu[i]) ? lo[i] + psl[i] : hi[i] - psu[i];
+                d[i] = di < lo[i] ? lo[i] : (di > hi[i] ? hi[i] : di);
+            }
+            return rd;
+        }
+    }
+    return 0;
+}
+
+/* returns iterations (polish rounds included); status: 0 converged, 1 maxiter, 2 numeric.  polish: once mu < 1e-7 the active-set
+ * polish above is tried (once); verified -> done with the exact solution, else the iteration runs on to mu_stop. */
 static int ipm_box(const double* H, const double* g, const double* lo, const double* hi, int n, int max_iters,
-                   double mu_stop, double* d, double* M, double* wk, int* status) {
+                   double mu_stop, int polish, double* d, double* M, double* wk, int* status) {
     double *sl = wk, *su = wk + n, *zl = wk + 2 * n, *zu = wk + 3 * n, *grad = wk + 4 * n, *Sig = wk + 5 * n,
            *da = wk + 6 * n, *dd = wk + 7 * n, *dzla = wk + 8 * n, *dzua = wk + 9 * n, *rcl = wk + 10 * n,
            *rcu = wk + 11 * n, *rhs = wk + 12 * n;
@@ -419,6 +486,15 @@ static int ipm_box(const double* H, const double* g, const double* lo, const dou
             break;
         }
         if (it == max_iters) break;
+        if (polish && mu < 1e-7) {
+            polish = 0;
+            const int rounds = polish_box(H, g, lo, hi, n, sl, su, zl, zu, d, M, da);      /* (da .. rhs: six vectors free here) */
+            if (rounds > 0) {
+                nit += rounds;
+                *status = 0;
+                break;
+            }
+        }
         ++nit;
         memcpy(M, H, (size_t)n * n * sizeof(double));
         for (int i = 0; i < n; ++i) {
@@ -507,7 +583,7 @@ static void* run_job(void* arg) {
         const int n = build_qp(c, j->x0 + b * 13, ub, j->stuck + b * NT, j->xref + b * j->xs,
                                j->uref ? j->uref + b * j->us : 0, j->warm ? j->warm + b * nm : 0, &W);
         int st = 0, nit = 0;
-        if (n > 0) nit = ipm_box(W.H, W.g, W.lo, W.hi, n, c->max_iters, c->mu_stop, d, M, wk, &st);
+        if (n > 0) nit = ipm_box(W.H, W.g, W.lo, W.hi, n, c->max_iters, c->mu_stop, !(c->flags & 1), d, M, wk, &st);
         const int na = n / N;
         for (int i = 0; i < NT; ++i) j->u0[b * NT + i] = 0;
         if (j->U) memset(j->U + b * nm, 0, (size_t)nm * sizeof(double));

@@ -347,7 +347,9 @@ def test_f64_wrench_space_kernel_other_vehicles_horizons_mixed_faults_warm_start
     mpc.set_profiling(True)
     mpc.solve(x0[:4], ub[:4], stuck[:4], xw.reshape(-1, order="F"))
     assert ("ftmpc_solve_ric64_kernel" if (sel == "auto" and N <= 40) else "ftmpc_solve_ws64_kernel") in mpc.last_kernel_ms()
-    ref = co.solve_batch_complete(cfg, x0, ub, stuck, xw, uref=uw, warmU=W0, nthreads=8)
+    # (kernel 12 finishes by the active-set polish and is held against the polished port; kernel 9 runs the iteration to mu 1e-13 alone)
+    ref = co.solve_batch_complete(cfg, x0, ub, stuck, xw, uref=uw, warmU=W0, nthreads=8, polish=(sel == "auto" and N <= 40))
+    co.exact_where_apart(cfg, ref, out["U"], x0, ub, stuck, xw, uref=uw, warmU=W0, tol=1e-6, tol_u0=1e-7, cap=8)      # (safety net: see there)
     assert (out["status"] == 0).all(), np.bincount(out["status"])
     assert np.abs(out["u0"] - ref["u0"]).max() / F_MAX < 1e-7, np.bincount(ref["how"])
     assert np.abs(out["U"] - ref["U"]).max() / F_MAX < 1e-6 and np.array_equal(W, out["U"])

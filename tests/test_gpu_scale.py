@@ -29,13 +29,17 @@ def _threads():
     return max(1, min(16, len(os.sched_getaffinity(0))))
 
 
-def _check_f64(mpc, cfg, x0, ub, stuck, xref):
+def _check_f64(mpc, cfg, x0, ub, stuck, xref, polish=False):
+    """polish: the kernel under test finishes by the active-set polish (kernel 12) and is held against the polished port -- the exact
+    solution on the verified set; the kernels that run the interior-point iteration to mu 1e-13 alone (3, 9) against the port doing
+    the same (where a bound is weakly active that iterate is itself up to ~5e-6 f_max from the exact solution in the later stages)."""
     out = mpc.solve(x0, ub, stuck, xref.reshape(-1, order="F"), return_U=True)
-    ref = co.solve_batch(cfg, x0, ub, stuck, xref, nthreads=_threads(), max_iters=60)
+    ref = co.solve_batch(cfg, x0, ub, stuck, xref, nthreads=_threads(), max_iters=60, polish=polish)
     # (one instance in ~8 000 of the config-5 batch stalls the interior-point ITERATION itself -- the C port, the NumPy mirror and
     # every float64 kernel alike run to their caps on it, 1.5e-6 f_max apart: it is left out here and counted)
     ok = ref["status"] == 0
     assert ok.sum() >= ok.size - max(1, ok.size // 4096) and (out["status"][ok] == 0).all(), (np.bincount(out["status"]), np.bincount(ref["status"]))
+    co.exact_where_apart(cfg, ref, out["U"], x0, ub, stuck, xref, tol=1e-6, tol_u0=1e-7, cap=8)      # (safety net: see there)
     err = np.abs(out["u0"][ok] - ref["u0"][ok]).max(axis=1) / F_MAX
     assert err.max() <= 1e-7, (err.max(), int(err.argmax()))
     assert np.abs(out["U"][ok] - ref["U"][ok]).max() / F_MAX <= 1e-6
@@ -51,7 +55,7 @@ def test_f64_persistent_loop_reference_vehicle(gpu_mpc_factory, sel):
     mpc = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40, kernel_select=sel)
     assert ("ws64" in mpc.kernel_name(6))
     x0, ub, stuck, xref = qo.make_batch(B, N, NT, 2, 5101)
-    out = _check_f64(mpc, qo.QPConfig(N=N, NT=NT), x0, ub, stuck, xref)
+    out = _check_f64(mpc, qo.QPConfig(N=N, NT=NT), x0, ub, stuck, xref, polish=sel == "auto")
     assert out["iters"].max() <= 40
 
 
@@ -63,7 +67,7 @@ def test_f64_persistent_loop_config5_shard(gpu_mpc_factory, sel, B):
     N, NT = 40, 16
     mpc = gpu_mpc_factory(N=N, NT=NT, dtype="f64", max_iters=40, kernel_select=sel)
     x0, ub, stuck, xref = qo.make_batch(B, N, NT, 2, 1005)
-    out = _check_f64(mpc, qo.QPConfig(N=N, NT=NT), x0, ub, stuck, xref)
+    out = _check_f64(mpc, qo.QPConfig(N=N, NT=NT), x0, ub, stuck, xref, polish=sel == "auto")
     mpc.set_profiling(True)
     mpc.solve(x0[:64], ub[:64], stuck[:64], xref.reshape(-1, order="F"))
     ran = mpc.last_kernel_ms()
@@ -222,4 +226,4 @@ def test_config4_sharded_hip_path_two_ranks_bitwise_equal_to_unsharded():
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    assert same and shape == (B, 8) and bad == 0 and 8.0 < iters < 12.0
+    assert same and shape == (B, 8) and bad == 0 and 6.5 < iters < 12.0

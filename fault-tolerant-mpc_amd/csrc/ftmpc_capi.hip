@@ -144,6 +144,22 @@ struct ftmpc_handle {
     double *d_sqU = nullptr, *d_sqQ = nullptr, *d_sqT = nullptr, *d_sqJ = nullptr;
     int32_t* d_sqF = nullptr;
     int64_t cap_sqp = 0;
+    // ... its launch sequence (a few hundred small launches per call) as a hipGraph: recorded the second time a call repeats the
+    // previous one's shape, replayed from then on; any reallocation or change of the constants starts over
+    uint64_t alloc_epoch = 0;          // bumped by every (re)allocation of a device buffer
+    struct SqpKey {
+        int64_t B = -1, xs = 0, us = 0;
+        const void *xref = nullptr, *uref = nullptr, *warm = nullptr;
+        int32_t iters = 0, backtracks = 0;
+        double tol = 0;
+        uint64_t epoch = 0, consts = 0;
+        bool operator==(const SqpKey& o) const {
+            return B == o.B && xs == o.xs && us == o.us && xref == o.xref && uref == o.uref && warm == o.warm && iters == o.iters &&
+                   backtracks == o.backtracks && tol == o.tol && epoch == o.epoch && consts == o.consts;
+        }
+    } sqp_key, sqp_seen;
+    hipGraphExec_t sqp_exec = nullptr;
+    int64_t sqp_graph_launches = 0;    // (diagnostic: ftmpc_sqp_graph_launches)
     int64_t cap_hullA = 0, cap_wrench = 0;
     // kernel 13: the two-stage form in float64 by the Riccati recursion (no terminal set, N <= 40, up to 128 hull rows)
     double* ricw_slot = nullptr;
@@ -254,6 +270,7 @@ int build_consts(const ftmpc_config& c, DeviceConsts& d, std::string& why) {
 
 template <typename T>
 int grow(ftmpc_handle* h, T** p, int64_t count) {
+    ++h->alloc_epoch;
     if (*p) (void)hipFree(*p);
     *p = nullptr;
     if (count <= 0) return FTMPC_OK;
@@ -527,7 +544,7 @@ int enqueue(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, cons
 
 extern "C" {
 
-int32_t ftmpc_version(void) { return 420; }
+int32_t ftmpc_version(void) { return 430; }
 
 #ifndef FTMPC_BUILD_ID
 #define FTMPC_BUILD_ID "unknown"
@@ -835,6 +852,7 @@ int ftmpc_destroy(ftmpc_handle* h) {
                     h->gEall, h->wg_slot, h->ws_slot, h->ws64_slot, h->ric_slot, h->ricw_slot, h->d_cbar, h->wsw_slot, h->hull_slot, h->d_tcost, h->d_cost, h->d_sqU, h->d_sqQ, h->d_sqT, h->d_sqJ, h->d_sqF, h->d_hullA, h->d_hullb, h->d_warmG, h->d_tau0, h->d_G, h->d_taud, h->d_hullset, h->d_ast2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (h->sqp_exec) (void)hipGraphExecDestroy(h->sqp_exec);
     if (h->h_qcnt) (void)hipHostFree(h->h_qcnt);
     if (h->ev_qcnt) (void)hipEventDestroy(h->ev_qcnt);
     if (h->pin_in.p) (void)hipHostFree(h->pin_in.p);
@@ -1064,19 +1082,12 @@ int ftmpc_eval_cost_batch(ftmpc_handle* h, int64_t B, const double* x0, const do
 
 // The line-search SQP over DEVICE buffers (h->d_x0 / d_ub / d_stuck and the given reference windows), enqueued on h->stream:
 // on return S describes where the results are (S.U the final sequences, S.J their cost, J0 the cost of the start point).
-static int sqp_enqueue(ftmpc_handle* h, int64_t B, const double* d_xref, int64_t xref_stride, const double* d_uref, int64_t uref_stride,
-                       const double* d_warm, int32_t sqp_iters, int32_t backtracks, double tol, ftmpc::SqpState& S, double** J0_out) {
+// the launches of one SQP solve on the handle's stream (launch = false: a replay, only the state the caller reads back is formed)
+static int sqp_record(ftmpc_handle* h, int64_t B, const double* d_xref, int64_t xref_stride, const double* d_uref, int64_t uref_stride,
+                      const double* d_warm, int32_t sqp_iters, int32_t backtracks, double tol, ftmpc::SqpState& S, double** J0_out, bool launch) {
     const int N = h->cfg.N, NT = h->cfg.NT;
     const int64_t nw = (int64_t)N * NT;
     int rc;
-    if (B > h->cap_sqp) {
-        h->cap_sqp = 0;
-        if ((rc = grow(h, &h->d_sqU, B * nw)) != FTMPC_OK || (rc = grow(h, &h->d_sqQ, B * nw)) != FTMPC_OK ||
-            (rc = grow(h, &h->d_sqT, B * nw)) != FTMPC_OK || (rc = grow(h, &h->d_sqJ, 4 * B)) != FTMPC_OK ||
-            (rc = grow(h, &h->d_sqF, 6 * B)) != FTMPC_OK)
-            return rc;
-        h->cap_sqp = B;
-    }
     hipStream_t s = h->stream;
     double *J = h->d_sqJ, *Jt = h->d_sqJ + B, *J0 = h->d_sqJ + 2 * B, *alpha = h->d_sqJ + 3 * B;
     S.B = B; S.N = N; S.NT = NT;
@@ -1087,6 +1098,11 @@ static int sqp_enqueue(ftmpc_handle* h, int64_t B, const double* d_xref, int64_t
     S.status = h->d_sqF + 5 * B;
     S.qstatus = h->d_status; S.qiters = h->d_iters;
     S.tol = tol;
+    if (!launch) {      // the iterate's buffer after the swaps of the major iterations
+        if (sqp_iters & 1) std::swap(S.U, S.Ut);
+        *J0_out = J0;
+        return FTMPC_OK;
+    }
     const unsigned gE = (unsigned)((B * nw + 255) / 256), gB = (unsigned)((B + 255) / 256);
     ftmpc::CostParams cp;
     cp.B = B;
@@ -1120,6 +1136,92 @@ static int sqp_enqueue(ftmpc_handle* h, int64_t B, const double* d_xref, int64_t
     }
     *J0_out = J0;
     return FTMPC_OK;
+}
+
+// One SQP solve on the handle's stream.  The sequence is sqp_iters x (linearise, QP kernels, open, backtracks x (trial, cost, decide),
+// close, count): ~300 launches of mostly tiny kernels for ten major iterations, launch-bound on small batches.  A call that repeats
+// the previous call's shape (batch, buffers, strides, counts, constants; no reallocation in between) is recorded into a hipGraph and
+// every further one replays it with ONE launch.  FTMPC_SQP_GRAPH=0 in the environment, profiling, or a failed capture leave the
+// direct launches.  (The closed loop of ftmpc_simulate_batch_ex moves its reference pointer every step: direct launches.)
+static int sqp_enqueue(ftmpc_handle* h, int64_t B, const double* d_xref, int64_t xref_stride, const double* d_uref, int64_t uref_stride,
+                       const double* d_warm, int32_t sqp_iters, int32_t backtracks, double tol, ftmpc::SqpState& S, double** J0_out) {
+    const int64_t nw = (int64_t)h->cfg.N * h->cfg.NT;
+    int rc;
+    if (B > h->cap_sqp) {
+        h->cap_sqp = 0;
+        if ((rc = grow(h, &h->d_sqU, B * nw)) != FTMPC_OK || (rc = grow(h, &h->d_sqQ, B * nw)) != FTMPC_OK ||
+            (rc = grow(h, &h->d_sqT, B * nw)) != FTMPC_OK || (rc = grow(h, &h->d_sqJ, 4 * B)) != FTMPC_OK ||
+            (rc = grow(h, &h->d_sqF, 6 * B)) != FTMPC_OK)
+            return rc;
+        h->cap_sqp = B;
+    }
+    static const bool graphs_on = [] {
+        const char* e = std::getenv("FTMPC_SQP_GRAPH");
+        return !(e && e[0] == '0');
+    }();
+    hipStream_t s = h->stream;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool outer_capture = hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+    if (!graphs_on || h->profiling || outer_capture || sqp_iters == 0)
+        return sqp_record(h, B, d_xref, xref_stride, d_uref, uref_stride, d_warm, sqp_iters, backtracks, tol, S, J0_out, true);
+    ftmpc_handle::SqpKey key;
+    key.B = B; key.xs = xref_stride; key.us = uref_stride;
+    key.xref = d_xref; key.uref = d_uref; key.warm = d_warm;
+    key.iters = sqp_iters; key.backtracks = backtracks; key.tol = tol;
+    key.epoch = h->alloc_epoch;
+    {   // the constants the kernels take by value, and the switches that pick kernels: FNV-1a over their bytes
+        uint64_t f = 1469598103934665603ull;
+        auto mix = [&](const void* p, size_t n) {
+            const unsigned char* b = static_cast<const unsigned char*>(p);
+            for (size_t i = 0; i < n; ++i) f = (f ^ b[i]) * 1099511628211ull;
+        };
+        mix(&h->dc, sizeof(h->dc));
+        const void* ptrs[2] = {h->d_tcost, h->rec};
+        mix(ptrs, sizeof(ptrs));
+        const int sw[8] = {h->use_f64, h->use_wg, h->use_ric64, h->nb_max, h->tset, h->sbounds, h->cfg.kernel_select, (int)h->lin_split_max};
+        mix(sw, sizeof(sw));
+        key.consts = f;
+    }
+    if (h->sqp_exec && key == h->sqp_key) {
+        if ((rc = sqp_record(h, B, d_xref, xref_stride, d_uref, uref_stride, d_warm, sqp_iters, backtracks, tol, S, J0_out, false)) != FTMPC_OK)
+            return rc;
+        HIP_TRY(h, hipGraphLaunch(h->sqp_exec, s));
+        ++h->sqp_graph_launches;
+        return FTMPC_OK;
+    }
+    if (h->sqp_exec) {
+        (void)hipGraphExecDestroy(h->sqp_exec);
+        h->sqp_exec = nullptr;
+    }
+    if (!(key == h->sqp_seen)) {      // first call of this shape: direct launches (it may still be a one-off)
+        h->sqp_seen = key;
+        return sqp_record(h, B, d_xref, xref_stride, d_uref, uref_stride, d_warm, sqp_iters, backtracks, tol, S, J0_out, true);
+    }
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        return sqp_record(h, B, d_xref, xref_stride, d_uref, uref_stride, d_warm, sqp_iters, backtracks, tol, S, J0_out, true);
+    }
+    ftmpc::SqpState Sc;
+    double* J0c = nullptr;
+    rc = sqp_record(h, B, d_xref, xref_stride, d_uref, uref_stride, d_warm, sqp_iters, backtracks, tol, Sc, &J0c, true);
+    hipGraph_t g = nullptr;
+    const hipError_t ec = hipStreamEndCapture(s, &g);
+    hipGraphExec_t ex = nullptr;
+    if (rc == FTMPC_OK && ec == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess && ex) {
+        (void)hipGraphDestroy(g);
+        h->sqp_exec = ex;
+        h->sqp_key = key;
+        if ((rc = sqp_record(h, B, d_xref, xref_stride, d_uref, uref_stride, d_warm, sqp_iters, backtracks, tol, S, J0_out, false)) != FTMPC_OK)
+            return rc;
+        HIP_TRY(h, hipGraphLaunch(h->sqp_exec, s));
+        ++h->sqp_graph_launches;
+        return FTMPC_OK;
+    }
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    h->sqp_seen = ftmpc_handle::SqpKey();      // (do not try again on every call)
+    h->sqp_seen.B = -2;
+    return sqp_record(h, B, d_xref, xref_stride, d_uref, uref_stride, d_warm, sqp_iters, backtracks, tol, S, J0_out, true);
 }
 
 int ftmpc_solve_sqp_batch(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, const double* stuck, const double* xref,
@@ -1158,6 +1260,8 @@ int ftmpc_solve_sqp_batch(ftmpc_handle* h, int64_t B, const double* x0, const do
     HIP_TRY(h, hipStreamSynchronize(s));
     return FTMPC_OK;
 }
+
+int64_t ftmpc_sqp_graph_launches(const ftmpc_handle* h) { return h ? h->sqp_graph_launches : -1; }
 
 int ftmpc_solve_batch_device(ftmpc_handle* h, int64_t B, const double* x0, const double* ub, const double* stuck,
                              const double* xref, int64_t xref_stride, const double* uref, int64_t uref_stride,

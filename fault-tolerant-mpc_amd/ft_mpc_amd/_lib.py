@@ -25,7 +25,7 @@ KERNEL_AUTO, KERNEL_DENSE, KERNEL_WORKGROUP = 0, 1, 2
 # every symbol include/ftmpc.h declares (tests check the list against the header)
 SYMBOLS = (
     "ftmpc_default_config", "ftmpc_create", "ftmpc_destroy", "ftmpc_last_error", "ftmpc_reserve",
-    "ftmpc_solve_batch", "ftmpc_solve_batch_device", "ftmpc_solve_sqp_batch", "ftmpc_solve_wrench_batch", "ftmpc_eval_cost_batch", "ftmpc_simulate_batch", "ftmpc_simulate_batch_ex", "ftmpc_simulate_wrench_batch", "ftmpc_last_handed_over", "ftmpc_allocate_batch", "ftmpc_shift_warm", "ftmpc_set_profiling",
+    "ftmpc_solve_batch", "ftmpc_solve_batch_device", "ftmpc_solve_sqp_batch", "ftmpc_sqp_graph_launches", "ftmpc_solve_wrench_batch", "ftmpc_eval_cost_batch", "ftmpc_simulate_batch", "ftmpc_simulate_batch_ex", "ftmpc_simulate_wrench_batch", "ftmpc_last_handed_over", "ftmpc_allocate_batch", "ftmpc_shift_warm", "ftmpc_set_profiling",
     "ftmpc_last_kernel_ms", "ftmpc_kernel_name", "ftmpc_routed_kernel_name", "ftmpc_multi_routed_kernel_name", "ftmpc_debug_build_qp", "ftmpc_version", "ftmpc_build_id",
     "ftmpc_multi_create", "ftmpc_multi_destroy", "ftmpc_multi_last_error", "ftmpc_multi_device_count", "ftmpc_multi_worker_cpus",
     "ftmpc_multi_shard_bounds", "ftmpc_multi_solve_batch", "ftmpc_multi_upload", "ftmpc_multi_step",
@@ -103,6 +103,8 @@ def load_library() -> C.CDLL:
     lib.ftmpc_simulate_batch_ex.argtypes = [vp, C.c_int64, C.c_int32, dp, dp, dp, dp, dp, dp, C.c_uint64, C.c_int32, C.c_int32, C.c_double, dp, ip]
     lib.ftmpc_simulate_wrench_batch.argtypes = [vp, C.c_int64, C.c_int32, dp, dp, dp, dp, C.c_int32, ip, dp, C.c_int32, dp, dp, dp, C.c_uint64, dp, ip, ip]
     lib.ftmpc_last_handed_over.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.ftmpc_sqp_graph_launches.argtypes = [vp]
+    lib.ftmpc_sqp_graph_launches.restype = C.c_int64
     lib.ftmpc_allocate_batch.argtypes = [vp, C.c_int64, dp, dp, dp, ip, ip]
     lib.ftmpc_shift_warm.argtypes = [C.c_int64, C.c_int32, C.c_int32, dp]
     lib.ftmpc_set_profiling.argtypes = [vp, C.c_int32]
@@ -134,7 +136,7 @@ def load_library() -> C.CDLL:
     lib.ftmpc_multi_worker_cpus.restype = C.c_int32
     for name in SYMBOLS:
         if name not in ("ftmpc_last_error", "ftmpc_kernel_name", "ftmpc_routed_kernel_name", "ftmpc_multi_routed_kernel_name", "ftmpc_version", "ftmpc_build_id", "ftmpc_multi_last_error",
-                        "ftmpc_multi_device_count", "ftmpc_multi_worker_cpus"):
+                        "ftmpc_multi_device_count", "ftmpc_multi_worker_cpus", "ftmpc_sqp_graph_launches"):
             getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib

@@ -423,6 +423,10 @@ class BatchedMPC:
                                                      _ptr(uh), _ptr(bad, C.c_int32)))
         return dict(x=x, u=uh, not_converged=bad)
 
+    def sqp_graph_launches(self) -> int:
+        """Calls of solve_sqp_device on this handle that were replayed from the recorded hipGraph (ftmpc_sqp_graph_launches)."""
+        return int(self.lib.ftmpc_sqp_graph_launches(self._h))
+
     def last_handed_over(self) -> int:
         """Instances of the last two-stage step that the one-wave fp32 kernel handed to the float64 kernel (ftmpc_last_handed_over)."""
         c = C.c_int64(0)

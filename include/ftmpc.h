@@ -227,6 +227,12 @@ int ftmpc_solve_sqp_batch(ftmpc_handle* h, int64_t B,
                           double* out_u0, double* out_U, double* out_cost, double* out_cost0,
                           int32_t* out_sqp_iters, int32_t* out_iters, int32_t* status);
 
+/* ftmpc_solve_sqp_batch is a few hundred small launches per call; a call that repeats the previous call's shape (batch size,
+ * strides, warm start or not, iteration counts, tolerance; the same handle constants, no workspace growth in between) is recorded
+ * into a hipGraph the second time and replayed with one launch from the third on.  FTMPC_SQP_GRAPH=0 in the environment keeps the
+ * direct launches (so does profiling).  Returns how many calls of this handle were replayed from a graph (diagnostic; -1: NULL). */
+int64_t ftmpc_sqp_graph_launches(const ftmpc_handle* h);
+
 /* Same contract with DEVICE pointers (HBM-resident inputs/outputs) enqueued on `stream`
  * (a hipStream_t passed as void*; NULL = the default stream).  Asynchronous: returns after
  * enqueue.  warmU is read only; pass the same buffer as out_U to update it in place. */

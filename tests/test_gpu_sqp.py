@@ -113,6 +113,48 @@ def test_on_device_sqp_equals_the_host_loop_bit_for_bit(gpu_mpc_factory, N, NT, 
     assert (dev["cost"] < dev["cost0"]).all() and (dev["sqp_iters"] >= 2).all()
 
 
+@pytest.mark.parametrize("N,NT,dtype,warm", [(20, 8, "f32", False), (15, 16, "f32", True), (15, 16, "f64", False)])
+def test_on_device_sqp_replayed_from_its_graph_equals_the_direct_launches(gpu_mpc_factory, N, NT, dtype, warm):
+    """ftmpc_solve_sqp_batch records its launch sequence into a hipGraph the second time a call repeats the previous one's shape and
+    replays it from then on (ftmpc_sqp_graph_launches counts the replays): call 1 is direct launches, call 2 records and replays, call 3
+    replays -- the same bits each time; another batch size goes back to direct launches, and the first shape records again afterwards;
+    different inputs of the same shape through the graph give what a fresh handle's direct launches give."""
+    T = load_terminal()
+    mpc = gpu_mpc_factory(N=N, NT=NT, dtype=dtype, terminal_cost=T)
+    B = 64
+    x0, ub, stuck, xref = qo.make_batch(2 * B, N, NT, 2, 8500 + N)
+    xr = xref.reshape(-1, order="F")
+    W = np.random.default_rng(6).uniform(0, rm.F_MAX, (2 * B, N, NT)) if warm else None
+    keys = ("U", "u0", "cost", "cost0", "sqp_iters", "iters", "status")
+
+    def run(m, lo, hi):
+        return m.solve_sqp_device(x0[lo:hi], ub[lo:hi], stuck[lo:hi], xr, warmU=None if W is None else W[lo:hi].copy(), sqp_iters=5)
+
+    a = run(mpc, 0, B)
+    assert mpc.sqp_graph_launches() == 0
+    b = run(mpc, 0, B)
+    assert mpc.sqp_graph_launches() == 1
+    c = run(mpc, 0, B)
+    assert mpc.sqp_graph_launches() == 2
+    for k in keys:
+        assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]), k
+    d = run(mpc, B, 2 * B)      # other inputs, same shape: through the graph
+    assert mpc.sqp_graph_launches() == 3
+    fresh = gpu_mpc_factory(N=N, NT=NT, dtype=dtype, terminal_cost=T)
+    e = run(fresh, B, 2 * B)
+    assert fresh.sqp_graph_launches() == 0
+    for k in keys:
+        assert np.array_equal(d[k], e[k]), k
+    run(mpc, 0, B // 2)         # another batch size: direct launches, the recorded graph is dropped
+    assert mpc.sqp_graph_launches() == 3
+    run(mpc, 0, B)
+    assert mpc.sqp_graph_launches() == 3
+    f = run(mpc, 0, B)
+    assert mpc.sqp_graph_launches() == 4
+    for k in keys:
+        assert np.array_equal(a[k], f[k]), k
+
+
 def test_closed_loop_with_the_sqp_at_every_step_equals_the_step_by_step_loop(gpu_mpc_factory):
     """ftmpc_simulate_batch_ex with sqp_iters > 0: plant, noise, warm-start shift and the line-search SQP of every step on the
     device.  Against the same loop driven from the host step by step (solve_sqp_device per step, the oracle's plant and its

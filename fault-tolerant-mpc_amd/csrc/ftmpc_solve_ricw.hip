@@ -30,9 +30,10 @@ __host__ __device__ constexpr int64_t var_off(int N) { return (int64_t)N * 2 * 2
 __host__ __device__ constexpr int64_t row_off(int N) { return var_off(N) + (int64_t)NVAR * ((N + 3) / 4) * 64; }
 __host__ __device__ constexpr int64_t xdev_off(int N, int MH) { return row_off(N) + (int64_t)NROW * ((N + 3) / 4) * mhs_of(MH) * 64; }
 // terminal-set rows (row i = lane + 64 j, j < 2): s | z | carried primal residual | ds_a | dz_a | active | penalty
-constexpr int NTROW = 7;
+constexpr int NTROW = 8;          // (+ the carried residual of the iterate kept while the early polish runs)
 __host__ __device__ constexpr int64_t trow_off(int N, int MH) { return xdev_off(N, MH) + (int64_t)N * 16; }
-__host__ __device__ constexpr int64_t slot_doubles(int N, int MH) { return trow_off(N, MH) + (int64_t)NTROW * 2 * 64; }
+__host__ __device__ constexpr int64_t xdev0_off(int N, int MH) { return trow_off(N, MH) + (int64_t)NTROW * 2 * 64; }      // dx of that iterate
+__host__ __device__ constexpr int64_t slot_doubles(int N, int MH) { return xdev0_off(N, MH) + (int64_t)N * 16; }
 }  // namespace rickw
 
 struct SolveRicwParams {
@@ -166,7 +167,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
         const int MT = TS ? Q.term_rows : 0;
         double* const tst = slot + trow_off(N, MH);
         auto tref = [&](int arr, int j) -> double& { return tst[(int64_t)(arr * 2 + j) * 64 + lane]; };
-        enum { T_S = 0, T_Z = 1, T_RP = 2, T_DSA = 3, T_DZA = 4, T_ACT = 5, T_W = 6 };
+        enum { T_S = 0, T_Z = 1, T_RP = 2, T_DSA = 3, T_DZA = 4, T_ACT = 5, T_W = 6, T_RP0 = 7 };
         auto tvalid = [&](int j) { return TS && lane + 64 * j < MT; };
         if constexpr (TS) {
             for (int i = lane; i < MTP * 9; i += 64) s_tA[i] = (i < MT * 9) ? Q.termA[i] : 0.0;
@@ -592,8 +593,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
         wave_global_fence();
 
         // ---------------- interior-point iterations over the hull rows ----------------
-        int status = 1, nit = 0;
-        for (int it = 0; it <= C.max_iters; ++it) {
+        // The iteration is LEFT EARLY, at mu 1e-7, for the active-set polish below (as kernels 11 and 12 do): verified there, the
+        // instance is done with the exact solution on its active set and the last interior-point passes are saved; not verified, the
+        // iterate kept aside (rows in the predictor's arrays, which the polish does not use) is taken up again and run to mu_stop,
+        // where the polish is tried once more.
+        int status = 1, nit = 0, it = 0;
+        bool verified = false;
+        double mu_target = fmax(C.mu_stop, 1e-7);
+        double* const xdev0 = slot + xdev0_off(N, MH);
+        for (int phase = 0; phase < 2; ++phase) {
+        for (; it <= C.max_iters; ++it) {
             double csum = 0.0;
             for (int v = 0; v < nv; ++v)
                 for (int c = 0; c < MHS; ++c)
@@ -612,7 +621,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
                 status = 2;
                 break;
             }
-            if (mu < C.mu_stop && rpn < 1e-9) {
+            if (mu < mu_target && rpn < 1e-9) {
                 status = 0;
                 break;
             }
@@ -727,13 +736,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
         }
 
         // ---------------- active-set polish (oracle/qp_oracle.py:polish_general; ftmpc_solve_f64.hip MODE 1) ----------------
-        bool verified = false;
         if (status == 0) {
             constexpr double PW0 = 1e6, PRES_TOL = 1e-10;
             const double pw = PW0 * hs;
+            for (int i = lane; i < N * 16; i += 64) xdev0[i] = xdev[i];
             for (int v = 0; v < nv; ++v) {
                 vref(V_D0, v) = vref(V_D, v);
                 for (int c = 0; c < MHS; ++c) {
+                    rref(R_DSA, v, c) = rref(R_S, v, c);
+                    rref(R_DZA, v, c) = rref(R_Z, v, c);
                     const bool act = rvalid(v, c) && rref(R_Z, v, c) > rref(R_S, v, c);
                     rref(R_ACT, v, c) = act ? 1.0 : 0.0;
                     if (!act) rref(R_Z, v, c) = 0.0;
@@ -746,6 +757,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
             };
             if constexpr (TS) {      // terminal rows: active set, true slack (the carried residual has closed), penalty pw / |A_T,i GN|^2
                 for (int j = 0; j < 2; ++j) {
+                    tref(T_DSA, j) = tref(T_S, j);
+                    tref(T_DZA, j) = tref(T_Z, j);
+                    tref(T_RP0, j) = tref(T_RP, j);
                     const bool act = tvalid(j) && tref(T_Z, j) > tref(T_S, j);
                     tref(T_ACT, j) = act ? 1.0 : 0.0;
                     if (!act) tref(T_Z, j) = 0.0;
@@ -819,6 +833,27 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FTMPC_R
                 }
                 verified = __builtin_amdgcn_readfirstlane(!__any(changed));
             }
+        }
+        if (status != 0 || verified || !(mu_target > C.mu_stop)) break;
+        // the early polish did not settle: back to the interior-point iterate, on to mu_stop
+        for (int i = lane; i < N * 16; i += 64) xdev[i] = xdev0[i];
+        for (int v = 0; v < nv; ++v) {
+            vref(V_D, v) = vref(V_D0, v);
+            for (int c = 0; c < MHS; ++c) {
+                rref(R_S, v, c) = rref(R_DSA, v, c);
+                rref(R_Z, v, c) = rref(R_DZA, v, c);
+            }
+        }
+        if constexpr (TS) {
+            for (int j = 0; j < 2; ++j) {
+                tref(T_S, j) = tref(T_DSA, j);
+                tref(T_Z, j) = tref(T_DZA, j);
+                tref(T_RP, j) = tref(T_RP0, j);
+            }
+        }
+        wave_global_fence();
+        status = 1;
+        mu_target = C.mu_stop;
         }
         // ---------------- outputs ----------------
         wave_lds_fence();

@@ -14,6 +14,8 @@ import numpy as np
 def _wrench_chunk(args):
     from oracle import qp_oracle as qo
     kw, x0, ub, stuck, xref, uref, warmG, term, iters, lo = args
+    kw = dict(kw)
+    mu_polish = kw.pop("mu_polish", None)
     cfg = qo.QPConfig(**kw)
     n = x0.shape[0]
     G = np.full((n, cfg.N, 6), np.nan)
@@ -24,7 +26,7 @@ def _wrench_chunk(args):
         for b in range(n):
             try:
                 _, T, st[b], nit[b], qp = qo.solve_wrench_instance(cfg, x0[b], ub[b], stuck[b], xref, uref=uref, warmG=None if warmG is None else warmG[b],
-                                                                   term_set=term, iters=iters)
+                                                                   term_set=term, iters=iters, mu_polish=mu_polish)
             except ValueError:       # flat hull: the healthy thrusters do not span R^6
                 st[b] = 3
                 continue
@@ -34,7 +36,7 @@ def _wrench_chunk(args):
     return lo, G, st, nit, act
 
 
-def solve_wrench_batch(N, NT, x0, ub, stuck, xref, uref=None, warmG=None, term_set=None, iters=60, workers=None):
+def solve_wrench_batch(N, NT, x0, ub, stuck, xref, uref=None, warmG=None, term_set=None, iters=60, workers=None, mu_polish=None):
     """oracle/qp_oracle.py:solve_wrench_instance for every instance of a batch.  Returns dict(G [B,N,6], status [B] (3: flat hull),
     iters [B], active [B,2] = rows with z > s among the hull / terminal rows)."""
     import multiprocessing as mp
@@ -46,7 +48,7 @@ def solve_wrench_batch(N, NT, x0, ub, stuck, xref, uref=None, warmG=None, term_s
         except AttributeError:
             workers = os.cpu_count() or 1
         workers = max(1, min(workers, 16, B // 8 or 1))
-    kw = dict(N=N, NT=NT)
+    kw = dict(N=N, NT=NT, mu_polish=mu_polish)      # (mu_polish: see qp_oracle.ipm_general)
     step = max(1, (B + 4 * workers - 1) // (4 * workers))
     jobs = [(kw, x0[lo:lo + step], ub[lo:lo + step], stuck[lo:lo + step], xref, uref, None if warmG is None else warmG[lo:lo + step], term_set, iters, lo)
             for lo in range(0, B, step)]

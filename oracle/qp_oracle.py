@@ -482,7 +482,7 @@ def solve_box_state_instance(cfg: QPConfig, x0, ub, stuck, xref, xlb=None, xub=N
     return U[0].copy(), U, st, nit, qp
 
 
-def ipm_general(H, g, C, h, d0, nfeas, iters=40, mu_stop=1e-10, rp_stop=1e-9, trace=None, polish=True):
+def ipm_general(H, g, C, h, d0, nfeas, iters=40, mu_stop=1e-10, rp_stop=1e-9, trace=None, polish=True, mu_polish=None):
     """Mehrotra predictor-corrector for  min 1/2 d'Hd + g'd  s.t.  C d + s = h, s >= 0  -- the algorithm of the
     float64 kernel's general-constraint mode (csrc/ftmpc_solve_f64.hip, MODE != 0), step for step:
       * start at d0; the first `nfeas` rows (box or hull rows) are strictly feasible there and keep s = h - C d exactly;
@@ -498,6 +498,8 @@ def ipm_general(H, g, C, h, d0, nfeas, iters=40, mu_stop=1e-10, rp_stop=1e-9, tr
         solution on the active set the iterate identifies, verified by its signs; every polish round that factorises counts
         as an iteration.  An interior-point iterate at mu 1e-10 is up to 7e-5 f_max from the exact solution where rows
         are weakly active (z ~ s ~ 1e-5); the polished one agrees with the active-set certificate solve_general_exact to 1e-9.
+      * mu_polish (kernel 13, csrc/ftmpc_solve_ricw.hip: 1e-7): the iteration is LEFT at that mu (primal residual closed) for the
+        polish; verified -> done, the last interior-point iterations saved; else the iterate is taken up again and run to mu_stop.
     Returns (d, s, z, iterations, status)."""
     n, m = g.size, h.size
     d = d0.copy()
@@ -521,6 +523,12 @@ def ipm_general(H, g, C, h, d0, nfeas, iters=40, mu_stop=1e-10, rp_stop=1e-9, tr
         if mu < mu_stop and rpn < rp_stop:
             status = 0
             break
+        if polish and mu_polish is not None and mu < mu_polish and rpn < rp_stop:
+            mu_polish = None      # (once)
+            dp, lam, rounds, verified = polish_general(H, g, C, h, d, s, z)
+            nit += rounds
+            if verified:
+                return dp, np.maximum(h - C @ dp, 0.0), lam, nit, 0
         if it == iters:
             break
         nit += 1
@@ -655,10 +663,12 @@ def kkt_general(H, g, C, h, d, z):
             float(np.abs(r * z).max()))
 
 
-def solve_wrench_instance(cfg: QPConfig, x0, ub, stuck, xref, uref=None, warmG=None, hull=None, term_set=None, iters=40, mu_stop=1e-10):
-    """Full oracle step of the generalized-force formulation.  Returns (tau0 (6,), T (N,6), status, iterations, qp dict)."""
+def solve_wrench_instance(cfg: QPConfig, x0, ub, stuck, xref, uref=None, warmG=None, hull=None, term_set=None, iters=40, mu_stop=1e-10,
+                          mu_polish=None):
+    """Full oracle step of the generalized-force formulation.  Returns (tau0 (6,), T (N,6), status, iterations, qp dict).
+    mu_polish: see ipm_general (1e-7 mirrors kernel 13's iteration counts; the solution is the same exact one either way)."""
     qp = build_qp_wrench(cfg, x0, ub, stuck, xref, uref, warmG, hull, term_set)
-    d, s, z, nit, st = ipm_general(qp["H"], qp["g"], qp["C"], qp["h"], qp["d0"], qp["nhull"], iters=iters, mu_stop=mu_stop)
+    d, s, z, nit, st = ipm_general(qp["H"], qp["g"], qp["C"], qp["h"], qp["d0"], qp["nhull"], iters=iters, mu_stop=mu_stop, mu_polish=mu_polish)
     T = qp["Tbar"] + (d.reshape(cfg.N, 6) if st != 2 else 0.0)
     qp.update(d=d, z=z, s=s)
     return T[0].copy(), T, st, nit, qp

@@ -62,7 +62,7 @@ def test_wrench_step_against_the_oracle(gpu_mpc_factory, N, NT, nf, B):
                 zonotope_hrep(cfg.D, ub[b], stuck[b])
             continue
         assert out["status"][b] == 0
-        tau0, T, st, nit, qp = qo.solve_wrench_instance(cfg, x0[b], ub[b], stuck[b], xref)
+        tau0, T, st, nit, qp = qo.solve_wrench_instance(cfg, x0[b], ub[b], stuck[b], xref, mu_polish=1e-7)      # (kernel 13 leaves the iteration there)
         assert st == 0 and max(qo.kkt_general(qp["H"], qp["g"], qp["C"], qp["h"], qp["d"], qp["z"])) < 1e-8
         assert np.abs(out["G"][b] - T).max() / F_MAX <= TOL, (b, np.abs(out["G"][b] - T).max())
         assert abs(int(out["iters"][b]) - nit) <= 1
@@ -200,7 +200,7 @@ def test_generic_vehicle_with_more_than_32_facets(gpu_mpc_factory, dtype, N, nf)
     assert mpc.last_handed_over() == 0
     for b in range(B):
         assert out["status"][b] == 0 and out["alloc_status"][b] == 0, (b, out["status"][b], out["alloc_status"][b])
-        tau0, T, st, nit, qp = qo.solve_wrench_instance(cfg, x0[b], ub[b], stuck[b], xref)
+        tau0, T, st, nit, qp = qo.solve_wrench_instance(cfg, x0[b], ub[b], stuck[b], xref, mu_polish=1e-7)
         assert st == 0 and qp["mh"] == hull["rows"] or qp["mh"] <= hull["rows"]
         assert np.abs(out["G"][b] - T).max() / F_MAX <= TOL, (b, np.abs(out["G"][b] - T).max() / F_MAX)
         assert abs(int(out["iters"][b]) - nit) <= 1
@@ -254,7 +254,7 @@ def test_reference_formulation_at_the_baseline_horizon(gpu_mpc_factory, dtype):
     term = load_terminal().term_set
     At, bt = term.A, term.b.reshape(-1)
     x0, ub, stuck, xref = _near_terminal_set(B, N, NT, 2, 9400, At, bt, scale=1.0)
-    ref = ob.solve_wrench_batch(N, NT, x0, ub, stuck, xref, term_set=(At, bt), iters=60)
+    ref = ob.solve_wrench_batch(N, NT, x0, ub, stuck, xref, term_set=(At, bt), iters=60, mu_polish=1e-7)
     mpc = gpu_mpc_factory(N=N, NT=NT, dtype=dtype, max_iters=60, terminal_set=term)
     out = mpc.solve_wrench(x0, ub, stuck, xref.reshape(-1, order="F"), return_G=True)
     assert mpc.last_handed_over() == 0

@@ -929,6 +929,9 @@ static_assert(tile_row_ok(), "state-component permutation of the sensitivity til
 #ifndef FTMPC_F32_REFINE_AT_POLISH
 #define FTMPC_F32_REFINE_AT_POLISH 1   // the one float64 gradient is taken where the polish starts (not at mu_refine before it)
 #endif
+#ifndef FTMPC_F32_REGRAD_DD
+#define FTMPC_F32_REGRAD_DD 2e-4f      // polish rounds after the first: another float64 gradient when the round's first step exceeds this (x ub)
+#endif
 #ifndef FTMPC_F32_PW0
 #define FTMPC_F32_PW0 1e3f             // penalty of the polish over max diag(H)
 #endif
@@ -1392,6 +1395,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 
         // solution against 9e-6 for the iteration run to mu 1e-11.)
         int pol = 0;
         bool pol_tried = !(FTMPC_F32_MU_POLISH > 0.f);
+        bool pol_grad = false;   // the float64 gradient has been taken inside this polish
         unsigned pact = 0u;      // bit 2 v: the lower bound of this lane's variable v is active, bit 2 v + 1: the upper one
         float pw = 0.f;
         float* const bkp = P.hscratch + (int64_t)blockIdx.x * P.tile_words + slot_backup_off_words(N);
@@ -1591,6 +1595,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 
                 }
                 return r;
             };
+            // the signs on the set: an active bound whose multiplier came out negative leaves, an inactive bound that is violated enters
+            auto pol_signs = [&]() -> bool {
+                bool changed = false;
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+                    if (valid[v]) {
+                        const unsigned bl = 1u << (2 * v), bu = 2u << (2 * v);
+                        if (pact & bl) {
+                            if (zl[v] < 0.f) { zl[v] = 0.f; pact &= ~bl; changed = true; }
+                        } else if (sl[v] < -1e-6f * ubv[v]) { pact |= bl; changed = true; }
+                        if (pact & bu) {
+                            if (zu[v] < 0.f) { zu[v] = 0.f; pact &= ~bu; changed = true; }
+                        } else if (su[v] < -1e-6f * ubv[v]) { pact |= bu; changed = true; }
+                    }
+                return __any(changed);
+            };
             // ... and its step: the gradient follows by the Newton identity, the multipliers by lam += W (c'dd - s)
             auto pol_step = [&](int v, float r, float dd) {
                 if (valid[v]) {
@@ -1667,7 +1687,28 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 
             // a step taken from the interior-point iterate at mu 1e-5 leaves kappa eps |dd| in the flat directions (1.4e-4 f_max measured)
             // The register-resident factor is parked in the global slot around the call (28 off-diagonal tiles; the inverse diagonal
             // blocks are in LDS): left live across it, the allocator spilled it piecemeal through the whole loop (12.2 -> 21.5 ms).
-            if (pol == 1) {
+            // The signs are checked after the FIRST step already: a set that fails them goes straight to the next round (new
+            // factorisation) without the gradient and the second step, which would be thrown away with it -- so the float64 gradient is
+            // taken once per instance, in the round whose set survives its first step (38 % of the instances need a second round).
+            // A later round takes it again when its first step was long: that step moves the free variables by what the change of the
+            // set is worth, and the recurrence would hide what the fp32 solve leaves of it (9e-5 f_max, worst of 160 000, without).
+            bool regrad = false;
+            if (pol) {
+                if (pol_signs()) {
+                    if (++pol > 3) pol_abandon();
+                    continue;
+                }
+                regrad = !pol_grad;
+                if (!regrad) {
+                    float ddm = 0.f;
+#pragma unroll
+                    for (int v = 0; v < NV; ++v)
+                        if (valid[v]) ddm = fmaxf(ddm, fabsf(da[v]) * __builtin_amdgcn_rcpf(ubv[v]));
+                    regrad = wave_max(ddm) > FTMPC_F32_REGRAD_DD;
+                }
+                pol_grad = true;
+            }
+            if (regrad) {
                 if constexpr (OCC2) {
                     typedef __attribute__((address_space(1))) f32x4 glb_f32x4;
                     glb_f32x4* const fpark = (glb_f32x4*)(P.hscratch + (int64_t)blockIdx.x * P.tile_words + slot_factor_off_words(N));
@@ -1718,23 +1759,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 
             ap = 1e30f;
             ad = 1e30f;
             if (pol) {
-                bool changed = false;
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
                     const int e = v * 64 + lane;
                     pol_step(v, rhs[v], (e < npadr && valid[v]) ? xvp[e] : 0.f);
-                    if (valid[v]) {
-                        const unsigned bl = 1u << (2 * v), bu = 2u << (2 * v);
-                        if (pact & bl) {
-                            if (zl[v] < 0.f) { zl[v] = 0.f; pact &= ~bl; changed = true; }
-                        } else if (sl[v] < -1e-6f * ubv[v]) { pact |= bl; changed = true; }
-                        if (pact & bu) {
-                            if (zu[v] < 0.f) { zu[v] = 0.f; pact &= ~bu; changed = true; }
-                        } else if (su[v] < -1e-6f * ubv[v]) { pact |= bu; changed = true; }
-                    }
                 }
+                const bool changed = pol_signs();
                 STAMP(7);
-                if (!__any(changed)) {
+                if (!changed) {
                     status = 0;
                     break;
                 }

@@ -69,8 +69,10 @@ def test_large_batches_against_the_c_oracle(gpu_mpc_factory, nfault, B):
     assert (out["status"] == 0).all(), np.bincount(out["status"])
     ref = co.solve_batch(_cfg(N, NT), x0, ub, stuck, xref, nthreads=min(32, os.cpu_count() or 1), max_iters=60, mu_stop=1e-13)
     assert (ref["status"] == 0).all()
-    assert np.abs(out["u0"] - ref["u0"]).max() / F_MAX <= 1e-4
-    assert np.abs(out["U"] - ref["U"]).max() / F_MAX <= TOL_U
+    # (north_star's tolerance is 1e-4; since the polish takes its float64 gradient between its two steps the worst of 230 000 instances
+    # over five batches is 1.8e-5 -- an instance that went back to the interior-point iteration --, 99.9 % are within 7e-7)
+    assert np.abs(out["u0"] - ref["u0"]).max() / F_MAX <= 3e-5
+    assert np.abs(out["U"] - ref["U"]).max() / F_MAX <= 5e-5
 
 
 @pytest.mark.parametrize("N,nfault", [(3, 2), (6, 0), (18, 2), (23, 2), (26, 2)])

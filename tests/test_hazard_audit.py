@@ -31,10 +31,11 @@ def test_no_hazard_in_any_kernel(device_asm):
     # MFMA chain, a branch, v_accvgpr_read of the result 3 wait states later (table: 10).  That one is real -- the GPU
     # returned wrong factors until the consumer was padded (scripts/check_hazards.py header) -- so the build pads it.
     comp = [(n, f) for n, s in summary.items() for f in s["compiler"]]
-    assert all(f["rule"] in ("mfma_use", "mfma_srcab") and any(k in n for k in ("ftmpc_solve_wg32_kernel", "ftmpc_solve_ws32_kernel", "ftmpc_solve_hull32_kernel"))
+    assert all(f["rule"] in ("mfma_use", "mfma_srcab") and any(k in n for k in ("ftmpc_solve_wg32_kernel", "ftmpc_solve_ws32_kernel", "ftmpc_solve_hull32_kernel", "ftmpc_solve_f32_kernelILi8"))
                for n, f in comp), [(n, f["rule"]) for n, f in comp if "wg32" not in n and "ws32" not in n][:5]
     # (the workgroup kernels 7 and 8 share the factorisation where the pattern sits; kernel 11 with the terminal set has one such
-    # read behind its float64 / fp32 branch -- the build pads every one of them, see test_elided_stream_is_clean_and_shorter)
+    # read behind its float64 / fp32 branch; kernel 2 <8> since the polish: one v_mov over the first register of a finished MFMA's
+    # destination 9 wait states after it, table 10 -- the build pads every one of them, see test_elided_stream_is_clean_and_shorter)
 
 
 def test_elided_stream_is_clean_and_shorter(device_asm, tmp_path):

@@ -48,9 +48,10 @@ __host__ __device__ constexpr int slot_gens_off() { return 160; }
 __host__ __device__ constexpr int slot_stage_off(int N) { return 160 + 8 * N; }
 //   words: 5 x 192 (the interior-point iterate kept while the early polish of kernel 2 runs: five arrays of NV x 64 lanes, NV <= 3)
 __host__ __device__ constexpr int slot_backup_off_words(int N) { return 2 * (160 + 8 * N + 9 * (N + 1)); }
-//   256-word aligned: 28 x 256 words, the off-diagonal factor tiles parked around the float64 gradient of the polish (kernel 2, NB = 8)
+//   256-word aligned: 55 x 256 words, the factor tiles parked around the float64 gradient of the polish (kernel 2: NB (NB - 1) / 2
+//   off-diagonal tiles, and the NB inverse diagonal blocks where they live in registers)
 __host__ __device__ constexpr int slot_factor_off_words(int N) { return ((slot_backup_off_words(N) + 5 * 192 + 255) / 256) * 256; }
-__host__ __device__ constexpr int slot_tile_off_words(int N) { return slot_factor_off_words(N) + 28 * 256; }
+__host__ __device__ constexpr int slot_tile_off_words(int N) { return slot_factor_off_words(N) + 55 * 256; }
 
 // constants shared by both kernels (passed by value as kernel argument)
 struct DeviceConsts {

@@ -17,8 +17,10 @@
 //      every accumulator seeded directly from the LDS tile; diagonal tiles factorised and inverted
 //      with v_readlane / fused DPP FMAs / v_permlane swaps), solved with packed VALU FMAs and
 //      DPP / permlane reductions, and whose gradient follows the step through the solved Newton
-//      system around one accurate float64 reference gradient (struct_grad).
-// The algorithm is the one restated in oracle/qp_oracle.py (ipm_box); the reference solves
+//      system around one accurate float64 reference gradient (struct_grad),
+//   4. leaves that iteration at mu 1e-5 for an ACTIVE-SET POLISH (the bounds with z > s as the set, two multiplier steps with a
+//      diagonal penalty per round, signs verified; a round is a pass of the same loop) -- see the interior-point loop below.
+// The algorithm is the one restated in oracle/qp_oracle.py (ipm_box) and oracle/ftmpc_oracle.c (ipm_box + polish_box); the reference solves
 // the corresponding NLP with CasADi/IPOPT (ft_mpc/controllers/spiraling_mpc.py:87-238,319-354)
 // followed by a cvxpy min-norm allocation (controllers/tools/control_allocator.py:65-94).
 //
@@ -927,7 +929,7 @@ static_assert(tile_row_ok(), "state-component permutation of the sensitivity til
 #define FTMPC_F32_MU_POLISH 1e-5f      // leave the interior-point iteration for the active-set polish below this mu (0: never)
 #endif
 #ifndef FTMPC_F32_REFINE_AT_POLISH
-#define FTMPC_F32_REFINE_AT_POLISH 1   // the one float64 gradient is taken where the polish starts (not at mu_refine before it)
+#define FTMPC_F32_REFINE_AT_POLISH 1   // the float64 gradient is taken inside the polish, between its two steps (not at mu_refine before it)
 #endif
 #ifndef FTMPC_F32_REGRAD_DD
 #define FTMPC_F32_REGRAD_DD 2e-4f      // polish rounds after the first: another float64 gradient when the round's first step exceeds this (x ub)
@@ -1685,8 +1687,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 
             // step (on the gradient the recurrence carried from the start point) lands next to the solution of the active set, the
             // second, from the exact gradient there, is then a true refinement step: its own error scales with its (tiny) length, where
             // a step taken from the interior-point iterate at mu 1e-5 leaves kappa eps |dd| in the flat directions (1.4e-4 f_max measured)
-            // The register-resident factor is parked in the global slot around the call (28 off-diagonal tiles; the inverse diagonal
-            // blocks are in LDS): left live across it, the allocator spilled it piecemeal through the whole loop (12.2 -> 21.5 ms).
+            // The register-resident factor is parked in the global slot around the call (the off-diagonal tiles; the inverse diagonal
+            // blocks too where they are not in LDS): left live across it, the allocator spilled it piecemeal through the whole loop (12.2 -> 21.5 ms).
             // The signs are checked after the FIRST step already: a set that fails them goes straight to the next round (new
             // factorisation) without the gradient and the second step, which would be thrown away with it -- so the float64 gradient is
             // taken once per instance, in the round whose set survives its first step (38 % of the instances need a second round).
@@ -1709,22 +1711,26 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 
                 pol_grad = true;
             }
             if (regrad) {
-                if constexpr (OCC2) {
-                    typedef __attribute__((address_space(1))) f32x4 glb_f32x4;
-                    glb_f32x4* const fpark = (glb_f32x4*)(P.hscratch + (int64_t)blockIdx.x * P.tile_words + slot_factor_off_words(N));
-                    int slotn = 0;
+                typedef __attribute__((address_space(1))) f32x4 glb_f32x4;
+                glb_f32x4* const fpark = (glb_f32x4*)(P.hscratch + (int64_t)blockIdx.x * P.tile_words + slot_factor_off_words(N));
+                int slotn = 0;
 #pragma unroll
-                    for (int I = 1; I < NB; ++I)
+                for (int I = 1; I < NB; ++I)
 #pragma unroll
-                        for (int J = 0; J < I; ++J) fpark[(slotn++) * 64 + lane] = Tt[tidx(I, J)];
-                    refresh();
-                    slotn = 0;
+                    for (int J = 0; J < I; ++J) fpark[(slotn++) * 64 + lane] = Tt[tidx(I, J)];
+                if constexpr (!OCC2) {      // (NB = 8 at two waves keeps the inverse diagonal blocks in LDS)
 #pragma unroll
-                    for (int I = 1; I < NB; ++I)
+                    for (int J = 0; J < NB; ++J) fpark[(slotn++) * 64 + lane] = Wd[J];
+                }
+                refresh();
+                slotn = 0;
 #pragma unroll
-                        for (int J = 0; J < I; ++J) Tt[tidx(I, J)] = fpark[(slotn++) * 64 + lane];
-                } else {
-                    refresh();
+                for (int I = 1; I < NB; ++I)
+#pragma unroll
+                    for (int J = 0; J < I; ++J) Tt[tidx(I, J)] = fpark[(slotn++) * 64 + lane];
+                if constexpr (!OCC2) {
+#pragma unroll
+                    for (int J = 0; J < NB; ++J) Wd[J] = fpark[(slotn++) * 64 + lane];
                 }
             }
             ap = wave_min(ap);

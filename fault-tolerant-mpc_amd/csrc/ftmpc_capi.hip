@@ -141,7 +141,8 @@ struct ftmpc_handle {
     double* d_cost = nullptr;
     int64_t cap_cost = 0;
     // on-device SQP (ftmpc_solve_sqp_batch): iterate, QP solution, trial point | J, Jt, J0, alpha | flags and counters
-    double *d_sqU = nullptr, *d_sqQ = nullptr, *d_sqT = nullptr, *d_sqJ = nullptr;
+    double *d_sqU = nullptr, *d_sqQ = nullptr, *d_sqT = nullptr, *d_sqJ = nullptr, *d_sqJall = nullptr;
+    int64_t cap_sqJall = 0;
     int32_t* d_sqF = nullptr;
     int64_t cap_sqp = 0;
     // ... its launch sequence (a few hundred small launches per call) as a hipGraph: recorded the second time a call repeats the
@@ -849,7 +850,7 @@ int ftmpc_destroy(ftmpc_handle* h) {
     void* ptrs[] = {h->rec, h->d_x0, h->d_ub, h->d_stuck, h->d_xref, h->d_uref, h->d_warm, h->d_u0, h->d_U,
                     h->d_status, h->d_iters, h->hs[0], h->hs[1], h->hs[2], h->d_dbgH, h->d_dbgv, h->Hs, h->Ls, h->Eall, h->d_dbgH64, h->d_dbgv64,
                     h->d_atau, h->d_aub, h->d_au, h->d_ast, h->d_ait, h->d_qlist, h->d_qctl, h->d_term, h->d_eN, h->gHs, h->gLs,
-                    h->gEall, h->wg_slot, h->ws_slot, h->ws64_slot, h->ric_slot, h->ricw_slot, h->d_cbar, h->wsw_slot, h->hull_slot, h->d_tcost, h->d_cost, h->d_sqU, h->d_sqQ, h->d_sqT, h->d_sqJ, h->d_sqF, h->d_hullA, h->d_hullb, h->d_warmG, h->d_tau0, h->d_G, h->d_taud, h->d_hullset, h->d_ast2};
+                    h->gEall, h->wg_slot, h->ws_slot, h->ws64_slot, h->ric_slot, h->ricw_slot, h->d_cbar, h->wsw_slot, h->hull_slot, h->d_tcost, h->d_cost, h->d_sqU, h->d_sqQ, h->d_sqT, h->d_sqJ, h->d_sqJall, h->d_sqF, h->d_hullA, h->d_hullb, h->d_warmG, h->d_tau0, h->d_G, h->d_taud, h->d_hullset, h->d_ast2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->sqp_exec) (void)hipGraphExecDestroy(h->sqp_exec);
@@ -1082,6 +1083,9 @@ int ftmpc_eval_cost_batch(ftmpc_handle* h, int64_t B, const double* x0, const do
 
 // The line-search SQP over DEVICE buffers (h->d_x0 / d_ub / d_stuck and the given reference windows), enqueued on h->stream:
 // on return S describes where the results are (S.U the final sequences, S.J their cost, J0 the cost of the start point).
+#ifndef FTMPC_SQP_LINESEARCH_AT_ONCE
+#define FTMPC_SQP_LINESEARCH_AT_ONCE 1
+#endif
 // the launches of one SQP solve on the handle's stream (launch = false: a replay, only the state the caller reads back is formed)
 static int sqp_record(ftmpc_handle* h, int64_t B, const double* d_xref, int64_t xref_stride, const double* d_uref, int64_t uref_stride,
                       const double* d_warm, int32_t sqp_iters, int32_t backtracks, double tol, ftmpc::SqpState& S, double** J0_out, bool launch) {
@@ -1124,10 +1128,25 @@ static int sqp_record(ftmpc_handle* h, int64_t B, const double* d_xref, int64_t 
                      h->d_iters, s, -1);
         if (rc != FTMPC_OK) return rc;
         hipLaunchKernelGGL(ftmpc::ftmpc_sqp_open_kernel, dim3(gB), dim3(256), 0, s, S);
-        for (int bt = 0; bt < backtracks; ++bt) {
-            hipLaunchKernelGGL(ftmpc::ftmpc_sqp_trial_kernel, dim3(gE), dim3(256), 0, s, S);
-            cost(S.Ut, Jt);
-            hipLaunchKernelGGL(ftmpc::ftmpc_sqp_decide_kernel, dim3(gB), dim3(256), 0, s, S);
+        if (FTMPC_SQP_LINESEARCH_AT_ONCE) {
+            // every trial point of the line search in one launch, the first acceptable one picked in a second (the alpha = 1,
+            // 1/2, ... rounds of trial / cost / decide are 3 x backtracks dependent launches for the same result)
+            ftmpc::CostParams ct = cp;
+            ct.U = S.U;
+            ct.Uq = S.Uq;
+            ct.todo = S.todo;
+            ct.ntrial = backtracks;
+            ct.out = h->d_sqJall;
+            hipLaunchKernelGGL(ftmpc::ftmpc_cost_kernel, dim3((unsigned)((B * backtracks + 63) / 64)), dim3(64), 0, s, h->dc, ct);
+            S.Jall = h->d_sqJall;
+            S.ntrial = backtracks;
+            hipLaunchKernelGGL(ftmpc::ftmpc_sqp_pick_kernel, dim3(gB), dim3(256), 0, s, S);
+        } else {
+            for (int bt = 0; bt < backtracks; ++bt) {
+                hipLaunchKernelGGL(ftmpc::ftmpc_sqp_trial_kernel, dim3(gE), dim3(256), 0, s, S);
+                cost(S.Ut, Jt);
+                hipLaunchKernelGGL(ftmpc::ftmpc_sqp_decide_kernel, dim3(gB), dim3(256), 0, s, S);
+            }
         }
         hipLaunchKernelGGL(ftmpc::ftmpc_sqp_close_kernel, dim3(gE), dim3(256), 0, s, S);     // new iterate -> Ut
         hipLaunchKernelGGL(ftmpc::ftmpc_sqp_count_kernel, dim3(gB), dim3(256), 0, s, S);
@@ -1141,7 +1160,7 @@ static int sqp_record(ftmpc_handle* h, int64_t B, const double* d_xref, int64_t 
 // One SQP solve on the handle's stream.  The sequence is sqp_iters x (linearise, QP kernels, open, backtracks x (trial, cost, decide),
 // close, count): ~300 launches of mostly tiny kernels for ten major iterations, launch-bound on small batches.  A call that repeats
 // the previous call's shape (batch, buffers, strides, counts, constants; no reallocation in between) is recorded into a hipGraph and
-// every further one replays it with ONE launch.  FTMPC_SQP_GRAPH=0 in the environment, profiling, or a failed capture leave the
+// every further one replays it with ONE launch (small batches; see FTMPC_SQP_GRAPH below).  Profiling or a failed capture leave the
 // direct launches.  (The closed loop of ftmpc_simulate_batch_ex moves its reference pointer every step: direct launches.)
 static int sqp_enqueue(ftmpc_handle* h, int64_t B, const double* d_xref, int64_t xref_stride, const double* d_uref, int64_t uref_stride,
                        const double* d_warm, int32_t sqp_iters, int32_t backtracks, double tol, ftmpc::SqpState& S, double** J0_out) {
@@ -1155,10 +1174,19 @@ static int sqp_enqueue(ftmpc_handle* h, int64_t B, const double* d_xref, int64_t
             return rc;
         h->cap_sqp = B;
     }
-    static const bool graphs_on = [] {
+    if (B * backtracks > h->cap_sqJall) {
+        h->cap_sqJall = 0;
+        if ((rc = grow(h, &h->d_sqJall, B * backtracks)) != FTMPC_OK) return rc;
+        h->cap_sqJall = B * backtracks;
+    }
+    // FTMPC_SQP_GRAPH: 0 never, 1 always; unset: batches up to 512 (measured, ten major iterations: 7.0 -> 6.2 ms at B = 256; at
+    // B = 1 024 the replay is SLOWER than the direct launches, 10.0 against 7.6 ms -- a captured step always launches the full
+    // persistent grids, the direct path shrinks those whose work list was empty the step before)
+    static const int graphs_mode = [] {
         const char* e = std::getenv("FTMPC_SQP_GRAPH");
-        return !(e && e[0] == '0');
+        return !e ? 2 : (e[0] == '0' ? 0 : 1);
     }();
+    const bool graphs_on = graphs_mode == 1 || (graphs_mode == 2 && B <= 512);
     hipStream_t s = h->stream;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool outer_capture = hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;

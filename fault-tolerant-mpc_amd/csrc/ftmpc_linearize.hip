@@ -392,7 +392,12 @@ struct CostParams {
     int64_t uref_stride;
     const double* U;        // [B*N*NT]
     const TermCost* tcost;  // or nullptr
-    double* out;            // [B]
+    double* out;            // [B]  (ntrial > 0: [B*ntrial])
+    // line search of the SQP, all trial points in one launch (ntrial > 0): lane b * ntrial + j evaluates the point
+    // U + 2^-j (clip(Uq, 0, ub) - U) of instance b -- what ftmpc_sqp_trial_kernel would store for alpha = 2^-j -- for the instances with todo set
+    const double* Uq = nullptr;
+    const int32_t* todo = nullptr;
+    int32_t ntrial = 0;
 };
 
 namespace {
@@ -426,8 +431,12 @@ __device__ inline void centre_rhs(const DeviceConsts& C, const double s[13], con
 }  // namespace
 
 __global__ void __launch_bounds__(64) ftmpc_cost_kernel(const DeviceConsts C, const CostParams P) {
-    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t lane_id = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t b = P.ntrial > 0 ? lane_id / P.ntrial : lane_id;
     if (b >= P.B) return;
+    const int jt = P.ntrial > 0 ? (int)(lane_id - b * P.ntrial) : 0;
+    if (P.ntrial > 0 && !P.todo[b]) return;
+    const double alpha = ldexp(1.0, -jt);      // (a power of two: alpha * step is exact, the point is the one the trial kernel stores)
     const int N = C.N, NT = C.NT;
     double s[13];
     {
@@ -453,7 +462,8 @@ __global__ void __launch_bounds__(64) ftmpc_cost_kernel(const DeviceConsts C, co
         double gen[6] = {0, 0, 0, 0, 0, 0};
         for (int i = 0; i < NT; ++i) {
             const bool healthy = P.ub[b * NT + i] > 0.0;
-            const double u = healthy ? P.U[(b * N + k) * NT + i] : 0.0;
+            double u = healthy ? P.U[(b * N + k) * NT + i] : 0.0;
+            if (P.ntrial > 0 && healthy) u = u + alpha * (fmin(fmax(P.Uq[(b * N + k) * NT + i], 0.0), P.ub[b * NT + i]) - u);
             cost += C.rho * u * u;
             const double t = u + P.stuck[b * NT + i];
             for (int g = 0; g < 6; ++g) gen[g] += C.D[g * MAX_NT + i] * t;
@@ -490,7 +500,7 @@ __global__ void __launch_bounds__(64) ftmpc_cost_kernel(const DeviceConsts C, co
             if (P.tcost) cost += term_cost_nq(*P.tcost, e, nullptr);
         }
     }
-    P.out[b] = cost;
+    P.out[lane_id] = cost;
 }
 
 }  // namespace ftmpc

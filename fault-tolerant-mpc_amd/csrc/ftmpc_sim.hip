@@ -138,6 +138,8 @@ struct SqpState {
     const int32_t* qstatus; // [B] of the last QP
     const int32_t* qiters;  // [B]
     double tol;
+    const double* Jall = nullptr;   // [B*ntrial] costs of all trial points of a line search (ftmpc_cost_kernel, ntrial > 0)
+    int32_t ntrial = 0;
 };
 
 // U = clip(warm, 0, ub) (or 0); active = 1; counters = 0
@@ -196,6 +198,25 @@ __global__ void ftmpc_sqp_decide_kernel(const SqpState S) {
     } else {
         S.alpha[b] *= 0.5;
     }
+}
+// the whole line search at once: the costs of the trial points alpha = 1, 1/2, ... are all there (S.Jall); the first that decreases the
+// TRUE cost enough is accepted -- what `backtracks` rounds of trial / cost / decide arrive at, in one launch instead of 3 x backtracks
+__global__ void ftmpc_sqp_pick_kernel(const SqpState S) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= S.B || !S.todo[b]) return;
+    const double J = S.J[b];
+    double alpha = S.alpha[b];
+    for (int j = 0; j < S.ntrial; ++j) {
+        const double Jt = S.Jall[b * S.ntrial + j];
+        if (Jt < J - S.tol * (1.0 + fabs(J))) {
+            S.J[b] = Jt;
+            S.improved[b] = 1;
+            S.todo[b] = 0;
+            break;
+        }
+        alpha *= 0.5;
+    }
+    S.alpha[b] = alpha;
 }
 // close the line search: U += alpha step where a trial point was accepted; an instance without progress stops
 __global__ void ftmpc_sqp_close_kernel(const SqpState S) {

@@ -229,8 +229,8 @@ int ftmpc_solve_sqp_batch(ftmpc_handle* h, int64_t B,
 
 /* ftmpc_solve_sqp_batch is a few hundred small launches per call; a call that repeats the previous call's shape (batch size,
  * strides, warm start or not, iteration counts, tolerance; the same handle constants, no workspace growth in between) is recorded
- * into a hipGraph the second time and replayed with one launch from the third on.  FTMPC_SQP_GRAPH=0 in the environment keeps the
- * direct launches (so does profiling).  Returns how many calls of this handle were replayed from a graph (diagnostic; -1: NULL). */
+ * into a hipGraph the second time and replayed with one launch from the third on -- for batches up to 512 instances, where it
+ * pays (FTMPC_SQP_GRAPH=1 in the environment: for every batch size; =0: never; profiling keeps the direct launches too).  Returns how many calls of this handle were replayed from a graph (diagnostic; -1: NULL). */
 int64_t ftmpc_sqp_graph_launches(const ftmpc_handle* h);
 
 /* Same contract with DEVICE pointers (HBM-resident inputs/outputs) enqueued on `stream`

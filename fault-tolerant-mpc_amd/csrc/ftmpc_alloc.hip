@@ -26,6 +26,9 @@ struct AllocParams {
     int32_t* iters;      // [B] or nullptr
     int32_t max_iters;
     double tol;          // |D u - tau|_inf <= tol (1 + |tau|_inf)
+    // list mode (the instances kernel 11 handed over, allocated after kernel 13 has re-solved them): lane i serves list[i], i < *count
+    const int32_t* list = nullptr;
+    const int32_t* count = nullptr;
 };
 
 namespace {
@@ -107,8 +110,12 @@ __global__ void __launch_bounds__(64) ftmpc_allocate_kernel(const DeviceConsts C
     __shared__ double Dm[6 * MAX_NT];
     for (int i = threadIdx.x; i < 6 * MAX_NT; i += 64) Dm[i] = C.D[i];
     __syncthreads();
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= P.B) return;
+    if (P.list) {
+        if (b >= *P.count) return;
+        b = P.list[b];
+    }
     const int NT = C.NT;
     double tau[6], ubv[MAX_NT];
     double tmax = 0.0;
@@ -307,14 +314,18 @@ __global__ void __launch_bounds__(64) ftmpc_allocate_kernel(const DeviceConsts C
 // wrench the HEALTHY thrusters have to produce: tau_0 - D stuck (the reference's u_res = u + u_nom + u_comp,
 // spiraling_mpc.py:301-302, i.e. the total wrench minus the uncontrollable part D f_fault)
 __global__ void __launch_bounds__(256) ftmpc_healthy_wrench_kernel(const DeviceConsts C, int64_t B, const double* tau0, const double* stuck,
-                                                                  double* out) {
+                                                                  double* out, const int32_t* list = nullptr, const int32_t* count = nullptr) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * 6) return;
-    const int64_t b = i / 6;
+    int64_t b = i / 6;
     const int g = (int)(i - 6 * b);
-    double t = tau0[i];
+    if (list) {      // (list mode: see AllocParams)
+        if (b >= *count) return;
+        b = list[b];
+    }
+    double t = tau0[b * 6 + g];
     for (int k = 0; k < C.NT; ++k) t -= C.D[g * MAX_NT + k] * stuck[b * C.NT + k];
-    out[i] = t;
+    out[b * 6 + g] = t;
 }
 
 }  // namespace ftmpc

@@ -147,6 +147,8 @@ struct ftmpc_handle {
     int64_t cap_sqp = 0;
     // ... its launch sequence (a few hundred small launches per call) as a hipGraph: recorded the second time a call repeats the
     // previous one's shape, replayed from then on; any reallocation or change of the constants starts over
+    hipStream_t stream2 = nullptr;     // the two-stage step: allocation beside kernel 13's hand-over pass
+    hipEvent_t ev_fork = nullptr, ev_alloc = nullptr;
     uint64_t alloc_epoch = 0;          // bumped by every (re)allocation of a device buffer
     struct SqpKey {
         int64_t B = -1, xs = 0, us = 0;
@@ -723,6 +725,13 @@ int ftmpc_create(const ftmpc_config* cfg, ftmpc_handle** out) {
         h->h_qcnt = nullptr;      // (no hint: every launch takes its full grid)
         (void)hipGetLastError();
     }
+    if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_alloc, hipEventDisableTiming) != hipSuccess) {
+        if (h->stream2) (void)hipStreamDestroy(h->stream2);
+        h->stream2 = nullptr;      // (no overlap: the two-stage step allocates after kernel 13, on the one stream)
+        (void)hipGetLastError();
+    }
     if (sbad || grow(h, &h->d_qctl, 8) != FTMPC_OK) {
         g_create_error = "stream / event / work-list allocation failed";
         ftmpc_destroy(h);
@@ -854,6 +863,9 @@ int ftmpc_destroy(ftmpc_handle* h) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->sqp_exec) (void)hipGraphExecDestroy(h->sqp_exec);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_alloc) (void)hipEventDestroy(h->ev_alloc);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->h_qcnt) (void)hipHostFree(h->h_qcnt);
     if (h->ev_qcnt) (void)hipEventDestroy(h->ev_qcnt);
     if (h->pin_in.p) (void)hipHostFree(h->pin_in.p);
@@ -1476,6 +1488,26 @@ static int wrench_enqueue(ftmpc_handle* h, int64_t B, int32_t hull_rows, bool ha
     }
     const bool handed = hull_fp32(h, hull_rows);
     h->wrench_handed = handed;
+    // allocation of the batch on a second stream, beside kernel 13's pass over the hand-over list (not while profiling: the
+    // event pairs of ftmpc_last_kernel_ms sit on one stream)
+    const bool overlap = handed && hull_ricw(h, hull_rows) && !h->profiling && h->stream2 != nullptr;
+    if (overlap) {
+        HIP_TRY(h, hipEventRecord(h->ev_fork, s));
+        HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+        hipLaunchKernelGGL(ftmpc::ftmpc_healthy_wrench_kernel, dim3((unsigned)((B * 6 + 255) / 256)), dim3(256), 0, h->stream2, h->dc, B,
+                           (const double*)h->d_tau0, (const double*)h->d_stuck, h->d_taud, (const int32_t*)nullptr, (const int32_t*)nullptr);
+        ftmpc::AllocParams a0;
+        a0.B = B;
+        a0.tau = h->d_taud;
+        a0.ub = h->d_ub;
+        a0.out_u = h->d_u0;
+        a0.status = h->d_ast2;
+        a0.iters = h->d_ast2 + B;
+        a0.max_iters = 50;
+        a0.tol = 1e-8;
+        hipLaunchKernelGGL(ftmpc::ftmpc_allocate_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, h->stream2, h->dc, a0);
+        HIP_TRY(h, hipEventRecord(h->ev_alloc, h->stream2));
+    }
     if (hull_ricw(h, hull_rows)) {      // kernel 13: the whole batch, or what kernel 11 handed over
         ftmpc::SolveRicwParams q;
         std::memset(&q, 0, sizeof(q));
@@ -1542,8 +1574,6 @@ static int wrench_enqueue(ftmpc_handle* h, int64_t B, int32_t hull_rows, bool ha
     HIP_TRY(h, hipGetLastError());
     }
     // second stage: min-norm allocation of the wrench the healthy thrusters have to produce
-    hipLaunchKernelGGL(ftmpc::ftmpc_healthy_wrench_kernel, dim3((unsigned)((B * 6 + 255) / 256)), dim3(256), 0, s, h->dc, B,
-                       (const double*)h->d_tau0, (const double*)h->d_stuck, h->d_taud);
     ftmpc::AllocParams ap;
     ap.B = B;
     ap.tau = h->d_taud;
@@ -1553,7 +1583,22 @@ static int wrench_enqueue(ftmpc_handle* h, int64_t B, int32_t hull_rows, bool ha
     ap.iters = h->d_ast2 + B;
     ap.max_iters = 50;
     ap.tol = 1e-8;
-    hipLaunchKernelGGL(ftmpc::ftmpc_allocate_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, h->dc, ap);
+    auto allocate = [&](hipStream_t st, const int32_t* list, const int32_t* count) {
+        hipLaunchKernelGGL(ftmpc::ftmpc_healthy_wrench_kernel, dim3((unsigned)((B * 6 + 255) / 256)), dim3(256), 0, st, h->dc, B,
+                           (const double*)h->d_tau0, (const double*)h->d_stuck, h->d_taud, list, count);
+        ftmpc::AllocParams a = ap;
+        a.list = list;
+        a.count = count;
+        hipLaunchKernelGGL(ftmpc::ftmpc_allocate_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, h->dc, a);
+    };
+    if (overlap) {
+        // the handed-over instances (a few dozen of a regular batch, one wave each: ~2 ms of latency, the device nearly idle) run
+        // on kernel 13 while the second stream allocates everything kernel 11 certified; their own allocation follows in list mode
+        HIP_TRY(h, hipStreamWaitEvent(s, h->ev_alloc, 0));
+        allocate(s, h->d_ast2 + 2 * h->cap_wrench, h->d_qctl);
+    } else {
+        allocate(s, nullptr, nullptr);
+    }
     HIP_TRY(h, hipGetLastError());
     return FTMPC_OK;
 }

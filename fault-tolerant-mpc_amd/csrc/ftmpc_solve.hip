@@ -1091,22 +1091,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 
                 }
             }
         }
-        // OCC2: the product H d0 of the start gradient (d0 = box centre - ubar) is formed where the finished tiles pass through the
-        // registers (finish_tile), not by re-reading all of them from the global slot afterwards: d0 and the product's accumulator
-        // sit in the stage storage of struct_grad, idle until the first refresh
-        float* const d0v = work + SH::WORK;
-        float* const hd0 = work + SH::WORK + NPAD;
-        static_assert(!OCC2 || 2 * NPAD <= SH::SEXTRA, "d0 | H d0 behind the vector workspace");
-        if constexpr (OCC2) {
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const int e = v * 64 + lane;
-                if (e < npadr) {
-                    d0v[e] = (kcol[v] != 255) ? 0.5f * ubv[v] - ubar[v] : 0.f;
-                    hd0[e] = 0.f;
-                }
-            }
-        }
         // the sensitivity G = d c_{k+1} / d U as accumulator tiles: G[X] reg s of lane (q, col) is row 4q+s
         // (tile_row order: the 9 costed components sit in registers 0..2 of row-groups 0..2) of column 16X+col
         int kX[OCC2 ? 1 : NB];
@@ -1135,9 +1119,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 
         // each tile exactly as its lanes hold it (one b128 per lane, conflict free): the factorisation loads a tile STRAIGHT
         // INTO the MFMA accumulator that collects the Schur terms (sum T'T - H), so no VALU instruction touches it.
         float* const mtab = work;     // MAX_NT x MAX_NT words; the vector workspace is idle until the interior-point iterations
-        float hrow = 0.f;      // OCC2: this lane's part of (H d0)[16 I + li] over the tiles of block row I finished so far
-        float hdmax = 0.f;     // OCC2: the largest diagonal entry of H this lane has seen (the polish's penalty scale)
-        auto finish_tile = [&](int I, int J, bool mv = true) {     // I, J are constants after unrolling
+        auto finish_tile = [&](int I, int J) {     // I, J are constants after unrolling
             f32x4 h = acc[(I * (I + 1)) / 2 + J];
             if (J >= I - 1) {
 #pragma unroll
@@ -1154,32 +1136,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 
                 }
             }
             htiles.st((I * (I + 1)) / 2 + J, lane, -h);
-            if constexpr (OCC2) {
-                if (mv) {
-                    // lane (q, col) holds H[16 I + col][16 J + 4 q + r]: one register image serves both triangles --
-                    //   (H d0)[16 I + col]     += sum_r h[r] d0[16 J + 4 q + r]     (kept in hrow over J; over the row groups at the end of the row)
-                    //   (H d0)[16 J + 4 q + r] += h[r] d0[16 I + col]               (I > J; over the 16 columns, then lane (q, 0) adds it in LDS)
-                    const f32x4 d4 = lds4(d0v + 16 * J + 4 * lq);
-                    hrow += (h.x * d4.x + h.y * d4.y) + (h.z * d4.z + h.w * d4.w);
-                    if (J < I) {
-                        const float dI = d0v[16 * I + li];
-                        float c0 = h.x * dI, c1 = h.y * dI, c2 = h.z * dI, c3 = h.w * dI;
-                        row_sum16x4(c0, c1, c2, c3);
-                        if (li == 0) {
-                            f32x4 y4 = lds4(hd0 + 16 * J + 4 * lq);
-                            y4 += f32x4{c0, c1, c2, c3};
-                            *reinterpret_cast<f32x4*>(hd0 + 16 * J + 4 * lq) = y4;
-                        }
-                    } else {
-                        const float yr = quad_sum(hrow);
-                        if (lq == 0) hd0[16 * I + li] += yr;
-                        hrow = 0.f;
-                        const int r = li - 4 * lq;      // the diagonal tile: lane (q, col) holds H[16 I + col][16 I + 4 q + r]
-                        const float dg = (r == 0) ? h.x : (r == 1) ? h.y : (r == 2) ? h.z : h.w;
-                        if (r >= 0 && r < 4 && 16 * I + li < n) hdmax = fmaxf(hdmax, dg);
-                    }
-                }
-            }
         };
 
         STAMP(0);
@@ -1306,7 +1262,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 
         for (int I = 0; I < NB; ++I)
             if (I > ((N * na - 1) >> 4)) {
 #pragma unroll
-                for (int J = 0; J <= I; ++J) finish_tile(I, J, false);
+                for (int J = 0; J <= I; ++J) finish_tile(I, J);
             }
         // column gradients back to the column-per-lane order: column 64v + lane sits in tile 4v + lq
         {
@@ -1442,13 +1398,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 
             };
             if (do_ref) {
                 refresh();
-            } else if (OCC2 && it == 0) {
-                // gradient at the start point: g + H d0, the product formed during the build (finish_tile)
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    const int e = v * 64 + lane;
-                    grad[v] = valid[v] ? gv[v] + hd0[e < npadr ? e : 0] : 0.f;
-                }
             } else if (it == 0) {
             // gradient at the start point, gref + H (d - dref).  Later iterates do not need the product
             // again: the Newton system just solved gives  H dd = rhs - Sigma dd,  so the gradient follows
@@ -1548,16 +1497,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NB == 
                 pol_tried = true;
                 pol = 1;
                 float hs = 0.f;
-                if constexpr (OCC2) {
-                    hs = hdmax;      // (seen in finish_tile)
-                } else {
 #pragma unroll
-                    for (int I = 0; I < NB; ++I) {      // max diag(H): lane (q, col) of the diagonal tile holds -H[16 I + col][16 I + 4 q + r]
-                        const f32x4 t4 = htiles.ld((I * (I + 1)) / 2 + I, lane);
-                        const int r = li - 4 * lq;
-                        const float dg = (r == 0) ? t4.x : (r == 1) ? t4.y : (r == 2) ? t4.z : t4.w;
-                        if (r >= 0 && r < 4 && 16 * I + li < n) hs = fmaxf(hs, -dg);
-                    }
+                for (int I = 0; I < NB; ++I) {      // max diag(H): lane (q, col) of the diagonal tile holds -H[16 I + col][16 I + 4 q + r]
+                    const f32x4 t4 = htiles.ld((I * (I + 1)) / 2 + I, lane);
+                    const int r = li - 4 * lq;
+                    const float dg = (r == 0) ? t4.x : (r == 1) ? t4.y : (r == 2) ? t4.z : t4.w;
+                    if (r >= 0 && r < 4 && 16 * I + li < n) hs = fmaxf(hs, -dg);
                 }
                 pw = FTMPC_F32_PW0 * wave_max(hs);
                 pact = 0u;
